@@ -1,0 +1,172 @@
+"""CPU oracle for the env-stepping hot path — TEST INFRASTRUCTURE ONLY.
+
+A plain-C restatement (oracle/orc_*.c) of the reference's step()/reset() dynamics, wrapped with
+ctypes.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+package, and only as the checker / reported CPU baseline.  The product package
+(custom_gymnasium_environments_amd) never imports it and has no CPU fallback.
+
+Parity status: PINNED — every env restated here is checked against golden vectors produced by
+executing the reference's own Python in the build container (tests/golden/gen/*.py); see
+tests/test_oracle_*.py.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libcge_oracle.so")
+
+
+def build(force=False):
+    srcs = [f for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    stale = force or not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH) for f in srcs)
+    if stale:
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def _p(a, dtype=None):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    if dtype is not None:
+        assert a.dtype == np.dtype(dtype), (a.dtype, dtype)
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _declare(L):
+    vp, i32, i64, u32, u64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_uint64, C.c_double
+    L.orc_mt_new.restype = vp
+    L.orc_mt_free.argtypes = [vp]
+    L.orc_mt_py_seed.argtypes = [vp, u64]
+    L.orc_mt_np_seed.argtypes = [vp, u32]
+    L.orc_mt_next_u32.argtypes = [vp]; L.orc_mt_next_u32.restype = u32
+    L.orc_mt_random.argtypes = [vp]; L.orc_mt_random.restype = dbl
+    L.orc_mt_randbelow.argtypes = [vp, u32]; L.orc_mt_randbelow.restype = u32
+    L.orc_mt_randint.argtypes = [vp, i32, i32]; L.orc_mt_randint.restype = i32
+    L.orc_mt_uniform.argtypes = [vp, dbl, dbl]; L.orc_mt_uniform.restype = dbl
+    L.orc_mt_normal.argtypes = [vp, dbl, dbl]; L.orc_mt_normal.restype = dbl
+    L.orc_mt_get.argtypes = [vp, vp, vp]
+    L.orc_hash_action_export.argtypes = [u64, u64, u64, u32, u32]; L.orc_hash_action_export.restype = u32
+
+    L.orc_snake_create.argtypes = [i64, i32, i32]; L.orc_snake_create.restype = vp
+    L.orc_snake_destroy.argtypes = [vp]
+    L.orc_snake_seed.argtypes = [vp, vp]
+    L.orc_snake_reset.argtypes = [vp, vp, vp]
+    L.orc_snake_step.argtypes = [vp, vp, vp, vp, vp, vp, vp]; L.orc_snake_step.restype = i32
+    L.orc_snake_rollout.argtypes = [vp, i32, u64, i64, i64, vp, vp, vp]
+    L.orc_snake_info.argtypes = [vp, i32, vp]
+    L.orc_snake_state_bytes.argtypes = [vp]; L.orc_snake_state_bytes.restype = C.c_size_t
+    L.orc_snake_get_state.argtypes = [vp, vp]
+    L.orc_snake_set_state.argtypes = [vp, vp]
+
+
+NEXT_STEP, SAME_STEP, DISABLED = 0, 1, 2
+
+
+class MT:
+    """One MT19937 stream with CPython `random` and NumPy-legacy helpers (for RNG known answers)."""
+
+    def __init__(self):
+        self.h = lib().orc_mt_new()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_mt_free(self.h)
+            self.h = None
+
+    def py_seed(self, s): lib().orc_mt_py_seed(self.h, s); return self
+    def np_seed(self, s): lib().orc_mt_np_seed(self.h, s); return self
+    def next_u32(self): return lib().orc_mt_next_u32(self.h)
+    def random(self): return lib().orc_mt_random(self.h)
+    def randbelow(self, n): return lib().orc_mt_randbelow(self.h, n)
+    def randint(self, a, b): return lib().orc_mt_randint(self.h, a, b)
+    def uniform(self, a, b): return lib().orc_mt_uniform(self.h, a, b)
+    def normal(self, loc, scale): return lib().orc_mt_normal(self.h, loc, scale)
+
+    def state(self):
+        mt = np.zeros(624, np.uint32)
+        idx = C.c_int(0)
+        lib().orc_mt_get(self.h, _p(mt), C.addressof(idx))
+        return mt, idx.value
+
+
+def hash_action(a_seed, env, t, n, j=0):
+    return lib().orc_hash_action_export(a_seed, env, t, n, j)
+
+
+class SnakeOracle:
+    """Batch of independent SnakeEnvClassic restatements (oracle/orc_snake.c)."""
+
+    def __init__(self, n, grid=10, mode=SAME_STEP):
+        self.n, self.grid, self.mode = int(n), int(grid), int(mode)
+        self.h = lib().orc_snake_create(self.n, self.grid, self.mode)
+        if not self.h:
+            raise ValueError("orc_snake_create failed")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_snake_destroy(self.h)
+            self.h = None
+
+    def seed(self, seeds):
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        assert seeds.shape == (self.n,)
+        lib().orc_snake_seed(self.h, _p(seeds))
+
+    def reset(self, mask=None):
+        obs = np.zeros((self.n, self.grid, self.grid), np.int8)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        lib().orc_snake_reset(self.h, _p(m), _p(obs))
+        return obs
+
+    def step(self, actions, want_final=False):
+        a = np.ascontiguousarray(actions, dtype=np.int32)
+        obs = np.zeros((self.n, self.grid, self.grid), np.int8)
+        rew = np.zeros(self.n, np.float32)
+        te = np.zeros(self.n, np.uint8)
+        tr = np.zeros(self.n, np.uint8)
+        fin = np.zeros_like(obs) if want_final else None
+        bad = lib().orc_snake_step(self.h, _p(a), _p(obs), _p(rew), _p(te), _p(tr), _p(fin))
+        if bad:
+            raise ValueError(f"Invalid action in {bad} env(s)")
+        return (obs, rew, te, tr, fin) if want_final else (obs, rew, te, tr)
+
+    def rollout(self, k, a_seed, t0=0, env0=0):
+        obs = np.zeros((self.n, self.grid, self.grid), np.int8)
+        rs = np.zeros(self.n, np.float32)
+        dc = np.zeros(self.n, np.int32)
+        lib().orc_snake_rollout(self.h, k, a_seed, t0, env0, _p(obs), _p(rs), _p(dc))
+        return obs, rs, dc
+
+    def info(self, field):
+        out = np.zeros(self.n, np.int32)
+        lib().orc_snake_info(self.h, field, _p(out))
+        return out
+
+    def get_state(self):
+        rec = lib().orc_snake_state_bytes(self.h)
+        buf = np.zeros((self.n, rec), np.uint8)
+        lib().orc_snake_get_state(self.h, _p(buf))
+        return buf
+
+    def set_state(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        assert buf.shape == (self.n, lib().orc_snake_state_bytes(self.h))
+        lib().orc_snake_set_state(self.h, _p(buf))
