@@ -1,0 +1,9 @@
+"""custom_gymnasium_environments_amd — MI355X-native batched stepper for the Gymnasium environments of
+hasnainfarid/Custom_Gymnasium_Environments.  Hand-written HIP kernels (csrc/*.hip) behind a C ABI
+(include/cge_amd.h) behind gymnasium.vector.VectorEnv-shaped Python classes on torch-ROCm tensors."""
+from ._native import NativeLibraryError, lib as native_lib  # noqa: F401
+from .vector_env import AutoresetMode, DeviceVectorEnv  # noqa: F401
+from .snake import SnakeVectorEnv  # noqa: F401
+
+__all__ = ["SnakeVectorEnv", "AutoresetMode", "DeviceVectorEnv", "NativeLibraryError", "native_lib"]
+__version__ = "0.1.0"

@@ -1,0 +1,80 @@
+"""ctypes binding of libcge_amd.so (the C ABI declared in include/cge_amd.h).
+
+There is deliberately NO fallback: if the HIP library is missing or fails to load, importing an
+env class still works (so the package can be inspected on a CPU box) but creating one raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcge_amd.so")
+
+CGE_OK = 0
+STATUS_NAMES = {0: "CGE_OK", -1: "CGE_ERR_INVALID_ARG", -2: "CGE_ERR_HIP", -3: "CGE_ERR_UNSUPPORTED",
+                -4: "CGE_ERR_NO_DEVICE"}
+AUTORESET_NEXT_STEP, AUTORESET_SAME_STEP, AUTORESET_DISABLED = 0, 1, 2
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+class SnakeConfig(C.Structure):
+    _fields_ = [("grid_size", C.c_int32), ("max_steps", C.c_int32), ("autoreset_mode", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+# name -> (restype, argtypes); also the list tests check against include/cge_amd.h
+_vp, _i32, _i64, _u32, _u64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_size_t
+SIGNATURES = {
+    "cge_version": (C.c_char_p, []),
+    "cge_hash_action": (_u32, [_u64, _u64, _u64, _u32, _u32]),
+    "cge_snake_create": (C.c_int, [C.POINTER(SnakeConfig), _i64, C.c_int, _i64, C.POINTER(_vp)]),
+    "cge_snake_destroy": (C.c_int, [_vp]),
+    "cge_snake_seed": (C.c_int, [_vp, _vp, _u64, _vp]),
+    "cge_snake_reset": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "cge_snake_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cge_snake_rollout": (C.c_int, [_vp, _i32, _vp, _u64, _i64, _vp, _i64, _vp, _vp, _vp]),
+    "cge_snake_info": (C.c_int, [_vp, _i32, _vp, _vp]),
+    "cge_snake_state_bytes": (_sz, [_vp]),
+    "cge_snake_get_state": (C.c_int, [_vp, _vp, _vp]),
+    "cge_snake_set_state": (C.c_int, [_vp, _vp, _vp]),
+    "cge_snake_error_count": (_i64, [_vp, _vp]),
+    "cge_snake_device_bytes": (_sz, [_vp]),
+    "cge_snake_last_error": (C.c_char_p, [_vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libcge_amd.so once; raise NativeLibraryError (never fall back) if that is impossible."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryError(
+                f"{LIB_PATH} not found: build it with `python -m custom_gymnasium_environments_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        try:
+            L = C.CDLL(LIB_PATH)
+        except OSError as e:
+            raise NativeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(L, name)
+            except AttributeError as e:
+                raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status, handle=None, last_error=None, what=""):
+    if status == CGE_OK:
+        return
+    msg = ""
+    if handle is not None and last_error is not None:
+        raw = last_error(handle)
+        msg = raw.decode() if raw else ""
+    raise NativeLibraryError(f"{what} failed: {STATUS_NAMES.get(status, status)} {msg}".strip())

@@ -1,0 +1,672 @@
+// snake.hip — batched SnakeEnvClassic for MI355X (gfx950): kernels + C ABI (include/cge_amd.h).
+//
+// Re-expresses /root/reference/snake_env_classic/snake_env.py  reset :49-65, step :67-119,
+// _place_food :121-129, _get_observation :131-143 for N independent instances, one lane per env.
+//
+// Device representation (per env, all integer, bit-exact with the reference's Python objects):
+//   occ   CELLS bits       occupancy of the body            (`new_head in self.snake`, obs value 1)
+//   dirs  2 bits per cell  direction the head LEFT that cell (replaces the Python list's order:
+//                          the tail advances by following its own cell's direction, O(1), no ring
+//                          buffer traffic; list.insert(0,..)/pop() become two bit updates)
+//   m0    head:10 tail:10 food:10 dir:2      m1  steps:16 score:10 flags     m2  episodes
+// stored struct-of-arrays as COLS columns of uint4 (column c of env i at state[c*N+i]) so a
+// wavefront's loads/stores are 16 B per lane, fully coalesced.  The whole record lives in VGPRs
+// during a step (static-index select chains, cge_device.hpp), the RNG block is touched only by
+// the lanes that place food.  The (N,G,G) int8 observation is built in LDS (one row per lane,
+// dword stride G*G/4 — odd for G=10, so conflict-free) and streamed out as 16-byte stores.
+#include <cstring>
+#include <vector>
+
+#include "cge_device.hpp"
+#include "cge_host.hpp"
+
+namespace cge {
+namespace snake {
+
+constexpr int bitlen(int n) {
+    int k = 0;
+    while (n) { ++k; n >>= 1; }
+    return k;
+}
+
+enum : uint32_t { F_NEEDS_RESET = 1u, F_BOARD_FULL = 2u, F_FOOD_VALID = 4u };
+
+template <int G>
+struct Lay {
+    static constexpr int CELLS = G * G;
+    static constexpr int OCCW = (CELLS + 31) / 32;
+    static constexpr int DIRW = (CELLS + 15) / 16;
+    static constexpr int NW = OCCW + DIRW + 3;
+    static constexpr int COLS = (NW + 3) / 4;
+    static constexpr int OBS_DW = CELLS / 4;
+    static constexpr int KBITS = bitlen(G);  // CPython: k = n.bit_length() for _randbelow(G)
+    static constexpr int BLOCK = (CELLS <= 144) ? 256 : 64;
+    static_assert(CELLS % 4 == 0, "obs rows are staged as dwords: G must be even");
+    static_assert(CELLS <= 1023, "cell index is packed in 10 bits");
+};
+
+template <int G>
+struct Env {
+    using L = Lay<G>;
+    uint32_t occ[L::OCCW];
+    uint32_t dirs[L::DIRW];
+    uint32_t head, tail, food, dir, steps, score, flags, episodes;
+
+    __device__ __forceinline__ void load(const uint4 *__restrict__ state, int64_t n, int64_t i) {
+        uint32_t raw[L::COLS * 4];
+#pragma unroll
+        for (int c = 0; c < L::COLS; ++c) {
+            uint4 v = state[(int64_t)c * n + i];
+            raw[4 * c] = v.x; raw[4 * c + 1] = v.y; raw[4 * c + 2] = v.z; raw[4 * c + 3] = v.w;
+        }
+        unpack(raw);
+    }
+    __device__ __forceinline__ void store(uint4 *__restrict__ state, int64_t n, int64_t i) const {
+        uint32_t raw[L::COLS * 4];
+        pack(raw);
+#pragma unroll
+        for (int c = 0; c < L::COLS; ++c)
+            state[(int64_t)c * n + i] = make_uint4(raw[4 * c], raw[4 * c + 1], raw[4 * c + 2], raw[4 * c + 3]);
+    }
+    __host__ __device__ __forceinline__ void unpack(const uint32_t *raw) {
+#pragma unroll
+        for (int k = 0; k < L::OCCW; ++k) occ[k] = raw[k];
+#pragma unroll
+        for (int k = 0; k < L::DIRW; ++k) dirs[k] = raw[L::OCCW + k];
+        const uint32_t m0 = raw[L::OCCW + L::DIRW], m1 = raw[L::OCCW + L::DIRW + 1];
+        head = m0 & 1023u; tail = (m0 >> 10) & 1023u; food = (m0 >> 20) & 1023u; dir = m0 >> 30;
+        steps = m1 & 0xffffu; score = (m1 >> 16) & 1023u; flags = m1 >> 26;
+        episodes = raw[L::OCCW + L::DIRW + 2];
+    }
+    __host__ __device__ __forceinline__ void pack(uint32_t *raw) const {
+#pragma unroll
+        for (int k = 0; k < L::OCCW; ++k) raw[k] = occ[k];
+#pragma unroll
+        for (int k = 0; k < L::DIRW; ++k) raw[L::OCCW + k] = dirs[k];
+        raw[L::OCCW + L::DIRW] = head | (tail << 10) | (food << 20) | (dir << 30);
+        raw[L::OCCW + L::DIRW + 1] = steps | (score << 16) | (flags << 26);
+        raw[L::OCCW + L::DIRW + 2] = episodes;
+#pragma unroll
+        for (int k = L::NW; k < L::COLS * 4; ++k) raw[k] = 0;
+    }
+
+    __device__ __forceinline__ uint32_t occupied(uint32_t cell) const { return (sel(occ, cell >> 5) >> (cell & 31u)) & 1u; }
+    __device__ __forceinline__ uint32_t length() const {
+        uint32_t c = 0;
+#pragma unroll
+        for (int k = 0; k < L::OCCW; ++k) c += __popc(occ[k]);
+        return c;
+    }
+
+    // snake_env.py:121-129 — row drawn first, then column, whole pair redrawn while on the snake
+    __device__ __forceinline__ void place_food(uint32_t *mt_block) {
+        if (length() >= (uint32_t)L::CELLS) {  // reference spins forever here; reported via info, never silent
+            flags = (flags | F_BOARD_FULL) & ~F_FOOD_VALID;
+            return;
+        }
+        MtStream rng;
+        rng.open(mt_block);
+        uint32_t cell;
+        do {
+            uint32_t r = rng.template randbelow<L::KBITS>(G);
+            uint32_t c = rng.template randbelow<L::KBITS>(G);
+            cell = r * G + c;
+        } while (occupied(cell));
+        rng.close();
+        food = cell;
+        flags |= F_FOOD_VALID;
+    }
+
+    // snake_env.py:49-65
+    __device__ __forceinline__ void reset(uint32_t *mt_block) {
+#pragma unroll
+        for (int k = 0; k < L::OCCW; ++k) occ[k] = 0;
+#pragma unroll
+        for (int k = 0; k < L::DIRW; ++k) dirs[k] = 0;
+        constexpr uint32_t center = (G / 2) * G + (G / 2);
+        head = tail = center;
+        occ[center >> 5] |= 1u << (center & 31u);
+        dir = 1;
+        score = 0;
+        steps = 0;
+        flags &= ~F_NEEDS_RESET;
+        place_food(mt_block);
+    }
+
+    // snake_env.py:67-119; returns terminated
+    __device__ __forceinline__ bool step(uint32_t action, uint32_t max_steps, uint32_t *mt_block, float &reward) {
+        const int d = (int)action - (int)dir;
+        if (d != 2 && d != -2) dir = action;                                      // :73-74
+        const uint32_t hr = head / G, hc = head - hr * G;
+        int nr = (int)hr, nc = (int)hc;
+        if (dir == 0) nr -= 1; else if (dir == 1) nc += 1; else if (dir == 2) nr += 1; else nc -= 1;   // :77-85
+        const bool wall = (unsigned)nr >= (unsigned)G || (unsigned)nc >= (unsigned)G;             // :88-89
+        const uint32_t ncell = wall ? head : (uint32_t)(nr * G + nc);
+        if (wall || occupied(ncell)) {                                            // :90, :93-94 (tail cell counts)
+            reward = -10.0f;
+            return true;
+        }
+        {   // :97 insert(0, new_head): remember which way the head left its old cell
+            const uint32_t w = head >> 4, sh = (head & 15u) * 2u;
+            andnot_word(dirs, w, 3u << sh);
+            or_word(dirs, w, dir << sh);
+        }
+        or_word(occ, ncell >> 5, 1u << (ncell & 31u));
+        head = ncell;
+        reward = 0.0f;
+        if ((flags & F_FOOD_VALID) && ncell == food) {                            // :101-104
+            score += 1;
+            reward = 10.0f;
+            place_food(mt_block);
+        } else {                                                                  // :107 pop()
+            const uint32_t td = (sel(dirs, tail >> 4) >> ((tail & 15u) * 2u)) & 3u;
+            andnot_word(occ, tail >> 5, 1u << (tail & 31u));
+            const int delta = td == 0 ? -G : td == 1 ? 1 : td == 2 ? G : -1;
+            tail = (uint32_t)((int)tail + delta);
+        }
+        steps += 1;                                                               // :109
+        return steps >= max_steps;                                                // :113-114
+    }
+
+    // snake_env.py:131-143 — one int8 row of G*G cells as OBS_DW dwords; `row` may be LDS or global
+    __device__ __forceinline__ void write_obs(uint32_t *row) const {
+#pragma unroll
+        for (int j = 0; j < L::OBS_DW; ++j) {
+            const uint32_t b = (occ[(4 * j) >> 5] >> ((4 * j) & 31)) & 0xFu;
+            row[j] = (b * 0x00204081u) & 0x01010101u;   // 4 occupancy bits -> 4 bytes of 0/1
+        }
+        if (flags & F_FOOD_VALID) reinterpret_cast<int8_t *>(row)[food] = 2;
+    }
+};
+
+struct Params {
+    uint4 *state;
+    uint32_t *mt;
+    int64_t n, env0;
+    const int32_t *actions;
+    const uint8_t *mask;
+    int8_t *obs;
+    float *reward;
+    uint8_t *terminated, *truncated;
+    int8_t *final_obs;
+    int32_t mode, max_steps, k_steps;
+    uint64_t a_seed;
+    int64_t t0, obs_step_stride;
+    float *reward_sum;
+    int32_t *done_count;
+    unsigned long long *err_count;
+};
+
+template <int G>
+__global__ __launch_bounds__(Lay<G>::BLOCK) void step_kernel(Params p) {
+    using L = Lay<G>;
+    __shared__ uint4 tile4[L::BLOCK * L::OBS_DW / 4];
+    uint32_t *tile = reinterpret_cast<uint32_t *>(tile4);
+    const int64_t first = (int64_t)blockIdx.x * L::BLOCK;
+    const int64_t i = first + threadIdx.x;
+    if (i < p.n) {
+        Env<G> e;
+        e.load(p.state, p.n, i);
+        uint32_t *mtb = p.mt + i * MT_STRIDE;
+        const int32_t a = p.actions[i];
+        float r = 0.0f;
+        bool term = false;
+        if (p.mode == CGE_AUTORESET_NEXT_STEP && (e.flags & F_NEEDS_RESET)) {
+            e.reset(mtb);
+        } else if ((uint32_t)a > 3u) {
+            atomicAdd(p.err_count, 1ull);   // reference: ValueError (snake_env.py:69-70)
+        } else {
+            term = e.step((uint32_t)a, (uint32_t)p.max_steps, mtb, r);
+            if (term) {
+                e.episodes += 1;
+                if (p.mode == CGE_AUTORESET_SAME_STEP) {
+                    if (p.final_obs) e.write_obs(reinterpret_cast<uint32_t *>(p.final_obs + i * L::CELLS));
+                    e.reset(mtb);
+                } else if (p.mode == CGE_AUTORESET_NEXT_STEP) {
+                    e.flags |= F_NEEDS_RESET;
+                }
+            }
+        }
+        e.write_obs(tile + threadIdx.x * L::OBS_DW);
+        e.store(p.state, p.n, i);
+        p.reward[i] = r;
+        p.terminated[i] = term ? 1 : 0;
+        p.truncated[i] = 0;   // reference never truncates (snake_env.py:119)
+    }
+    __syncthreads();
+    const int64_t live = p.n - first < L::BLOCK ? p.n - first : L::BLOCK;
+    store_tile<L::BLOCK>(tile, p.obs + first * L::CELLS, (uint32_t)(live * L::CELLS));
+}
+
+// k fused steps per launch: state stays in VGPRs, only obs (+ optional explicit actions) touch HBM per step
+template <int G>
+__global__ __launch_bounds__(Lay<G>::BLOCK) void rollout_kernel(Params p) {
+    using L = Lay<G>;
+    __shared__ uint4 tile4[L::BLOCK * L::OBS_DW / 4];
+    uint32_t *tile = reinterpret_cast<uint32_t *>(tile4);
+    const int64_t first = (int64_t)blockIdx.x * L::BLOCK;
+    const int64_t i = first + threadIdx.x;
+    const bool live_lane = i < p.n;
+    const int64_t live = p.n - first < L::BLOCK ? p.n - first : L::BLOCK;
+    Env<G> e;
+    uint32_t *mtb = nullptr;
+    uint64_t key = 0;
+    float rsum = 0.0f;
+    int32_t dcount = 0;
+    if (live_lane) {
+        e.load(p.state, p.n, i);
+        mtb = p.mt + i * MT_STRIDE;
+        key = hash_env_key(p.a_seed, (uint64_t)(p.env0 + i));
+    }
+    for (int t = 0; t < p.k_steps; ++t) {
+        if (live_lane) {
+            if (p.mode == CGE_AUTORESET_NEXT_STEP && (e.flags & F_NEEDS_RESET)) {
+                e.reset(mtb);
+            } else {
+                const uint32_t a = p.actions ? (uint32_t)p.actions[(int64_t)t * p.n + i]
+                                             : hash_action_from_key(key, (uint64_t)(p.t0 + t), 4u, 0u);
+                if (a > 3u) {
+                    atomicAdd(p.err_count, 1ull);
+                } else {
+                    float r;
+                    const bool term = e.step(a, (uint32_t)p.max_steps, mtb, r);
+                    rsum += r;
+                    if (term) {
+                        ++dcount;
+                        e.episodes += 1;
+                        if (p.mode == CGE_AUTORESET_SAME_STEP) e.reset(mtb);
+                        else if (p.mode == CGE_AUTORESET_NEXT_STEP) e.flags |= F_NEEDS_RESET;
+                    }
+                }
+            }
+            if (p.obs) e.write_obs(tile + threadIdx.x * L::OBS_DW);
+        }
+        if (p.obs) {
+            __syncthreads();
+            store_tile<L::BLOCK>(tile, p.obs + (int64_t)t * p.obs_step_stride + first * L::CELLS, (uint32_t)(live * L::CELLS));
+            __syncthreads();
+        }
+    }
+    if (live_lane) {
+        e.store(p.state, p.n, i);
+        if (p.reward_sum) p.reward_sum[i] = rsum;
+        if (p.done_count) p.done_count[i] = dcount;
+    }
+}
+
+template <int G>
+__global__ __launch_bounds__(Lay<G>::BLOCK) void reset_kernel(Params p) {
+    using L = Lay<G>;
+    __shared__ uint4 tile4[L::BLOCK * L::OBS_DW / 4];
+    uint32_t *tile = reinterpret_cast<uint32_t *>(tile4);
+    const int64_t first = (int64_t)blockIdx.x * L::BLOCK;
+    const int64_t i = first + threadIdx.x;
+    if (i < p.n) {
+        Env<G> e;
+        e.load(p.state, p.n, i);
+        if (!p.mask || p.mask[i]) {
+            e.reset(p.mt + i * MT_STRIDE);
+            e.store(p.state, p.n, i);
+        }
+        if (p.obs) e.write_obs(tile + threadIdx.x * L::OBS_DW);
+    }
+    if (p.obs) {
+        __syncthreads();
+        const int64_t live = p.n - first < L::BLOCK ? p.n - first : L::BLOCK;
+        store_tile<L::BLOCK>(tile, p.obs + first * L::CELLS, (uint32_t)(live * L::CELLS));
+    }
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void info_kernel(const uint4 *__restrict__ state, int64_t n, int field, int32_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    Env<G> e;
+    e.load(state, n, i);
+    int32_t v = 0;
+    const bool fv = e.flags & F_FOOD_VALID;
+    switch (field) {
+        case CGE_SNAKE_INFO_SCORE: v = (int32_t)e.score; break;
+        case CGE_SNAKE_INFO_LENGTH: v = (int32_t)e.length(); break;
+        case CGE_SNAKE_INFO_STEPS: v = (int32_t)e.steps; break;
+        case CGE_SNAKE_INFO_DIRECTION: v = (int32_t)e.dir; break;
+        case CGE_SNAKE_INFO_FOOD_R: v = fv ? (int32_t)(e.food / G) : -1; break;
+        case CGE_SNAKE_INFO_FOOD_C: v = fv ? (int32_t)(e.food % G) : -1; break;
+        case CGE_SNAKE_INFO_BOARD_FULL: v = (e.flags & F_BOARD_FULL) ? 1 : 0; break;
+        case CGE_SNAKE_INFO_EPISODES: v = (int32_t)e.episodes; break;
+        case CGE_SNAKE_INFO_HEAD_R: v = (int32_t)(e.head / G); break;
+        case CGE_SNAKE_INFO_HEAD_C: v = (int32_t)(e.head % G); break;
+        case CGE_SNAKE_INFO_NEEDS_RESET: v = (e.flags & F_NEEDS_RESET) ? 1 : 0; break;
+    }
+    out[i] = v;
+}
+
+// ------------------------------------------------------------------ host side
+struct Ops {
+    int cells, cols, block, nw;
+    void (*step)(const Params &, hipStream_t);
+    void (*rollout)(const Params &, hipStream_t);
+    void (*reset)(const Params &, hipStream_t);
+    void (*info)(const uint4 *, int64_t, int, int32_t *, hipStream_t);
+    void (*decode)(const uint32_t *raw, int32_t *hdr, uint16_t *body);
+    void (*encode)(const int32_t *hdr, const uint16_t *body, uint32_t *raw);
+};
+
+template <int G>
+void decode_env(const uint32_t *raw, int32_t *hdr, uint16_t *body) {
+    using L = Lay<G>;
+    Env<G> e;
+    e.unpack(raw);
+    int len = 0;
+    for (int k = 0; k < L::OCCW; ++k) len += __builtin_popcount(e.occ[k]);
+    const bool fv = e.flags & F_FOOD_VALID;
+    hdr[0] = len; hdr[1] = (int32_t)e.dir;
+    hdr[2] = fv ? (int32_t)(e.food / G) : -1; hdr[3] = fv ? (int32_t)(e.food % G) : -1;
+    hdr[4] = (int32_t)e.score; hdr[5] = (int32_t)e.steps; hdr[6] = (e.flags & F_NEEDS_RESET) ? 1 : 0;
+    // walk tail -> head along the stored directions, emit head first
+    std::vector<uint16_t> order;
+    uint32_t c = e.tail;
+    for (int k = 0; k < len; ++k) {
+        order.push_back((uint16_t)c);
+        if (c == e.head) break;
+        const uint32_t td = (e.dirs[c >> 4] >> ((c & 15u) * 2u)) & 3u;
+        c = (uint32_t)((int)c + (td == 0 ? -G : td == 1 ? 1 : td == 2 ? G : -1));
+    }
+    for (int k = 0; k < L::CELLS; ++k) body[k] = k < (int)order.size() ? order[order.size() - 1 - k] : 0xFFFF;
+}
+
+template <int G>
+void encode_env(const int32_t *hdr, const uint16_t *body, uint32_t *raw) {
+    using L = Lay<G>;
+    Env<G> e;
+    memset(&e, 0, sizeof e);
+    const int len = hdr[0];
+    for (int k = 0; k < len; ++k) e.occ[body[k] >> 5] |= 1u << (body[k] & 31u);
+    for (int k = len - 1; k >= 1; --k) {   // body[k] is older than body[k-1]
+        const int from = body[k], to = body[k - 1];
+        const uint32_t d = to == from - G ? 0u : to == from + 1 ? 1u : to == from + G ? 2u : 3u;
+        e.dirs[from >> 4] |= d << ((from & 15) * 2);
+    }
+    e.head = body[0];
+    e.tail = body[len - 1];
+    e.dir = (uint32_t)hdr[1];
+    const bool fv = hdr[2] >= 0;
+    e.food = fv ? (uint32_t)(hdr[2] * G + hdr[3]) : 0u;
+    e.score = (uint32_t)hdr[4];
+    e.steps = (uint32_t)hdr[5];
+    e.flags = (hdr[6] ? F_NEEDS_RESET : 0u) | (fv ? F_FOOD_VALID : 0u);
+    e.episodes = 0;
+    e.pack(raw);
+}
+
+template <int G>
+Ops make_ops() {
+    using L = Lay<G>;
+    Ops o;
+    o.cells = L::CELLS; o.cols = L::COLS; o.block = L::BLOCK; o.nw = L::NW;
+    o.step = [](const Params &p, hipStream_t s) {
+        hipLaunchKernelGGL(step_kernel<G>, dim3((unsigned)((p.n + L::BLOCK - 1) / L::BLOCK)), dim3(L::BLOCK), 0, s, p);
+    };
+    o.rollout = [](const Params &p, hipStream_t s) {
+        hipLaunchKernelGGL(rollout_kernel<G>, dim3((unsigned)((p.n + L::BLOCK - 1) / L::BLOCK)), dim3(L::BLOCK), 0, s, p);
+    };
+    o.reset = [](const Params &p, hipStream_t s) {
+        hipLaunchKernelGGL(reset_kernel<G>, dim3((unsigned)((p.n + L::BLOCK - 1) / L::BLOCK)), dim3(L::BLOCK), 0, s, p);
+    };
+    o.info = [](const uint4 *st, int64_t n, int field, int32_t *out, hipStream_t s) {
+        hipLaunchKernelGGL(info_kernel<G>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st, n, field, out);
+    };
+    o.decode = decode_env<G>;
+    o.encode = encode_env<G>;
+    return o;
+}
+
+static bool ops_for(int grid, Ops &o) {
+    switch (grid) {
+        case 6: o = make_ops<6>(); return true;
+        case 8: o = make_ops<8>(); return true;
+        case 10: o = make_ops<10>(); return true;
+        case 12: o = make_ops<12>(); return true;
+        case 16: o = make_ops<16>(); return true;
+        case 20: o = make_ops<20>(); return true;
+    }
+    return false;
+}
+
+}  // namespace snake
+}  // namespace cge
+
+using namespace cge;
+
+struct cge_snake : HandleBase {
+    cge_snake_config cfg{};
+    snake::Ops ops{};
+    uint4 *state = nullptr;
+    uint32_t *mt = nullptr;
+    unsigned long long *err = nullptr;
+
+    snake::Params params() const {
+        snake::Params p{};
+        p.state = state; p.mt = mt; p.n = n; p.env0 = env0;
+        p.mode = cfg.autoreset_mode; p.max_steps = cfg.max_steps; p.err_count = err;
+        return p;
+    }
+};
+
+extern "C" {
+
+const char *cge_version(void) { return "cge_amd 0.1 (gfx950)"; }
+
+uint32_t cge_hash_action(uint64_t a_seed, uint64_t env, uint64_t t, uint32_t n, uint32_t j) {
+    return hash_action_from_key(hash_env_key(a_seed, env), t, n, j);
+}
+
+int cge_snake_create(const cge_snake_config *cfg, int64_t n_envs, int device, int64_t env_index0, cge_snake **out) {
+    if (!cfg || !out || n_envs <= 0 || env_index0 < 0) return CGE_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (cfg->autoreset_mode < 0 || cfg->autoreset_mode > 2 || cfg->max_steps < 0 || cfg->max_steps > 65535)
+        return CGE_ERR_INVALID_ARG;
+    snake::Ops ops;
+    if (!snake::ops_for(cfg->grid_size, ops)) return CGE_ERR_UNSUPPORTED;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return CGE_ERR_NO_DEVICE;
+    cge_snake *h = new cge_snake();
+    h->cfg = *cfg;
+    if (h->cfg.max_steps == 0) h->cfg.max_steps = 1000;   // snake_env.py:47
+    h->ops = ops;
+    h->n = n_envs; h->env0 = env_index0; h->device = device;
+    DeviceGuard g(device);
+    const size_t state_bytes = (size_t)ops.cols * n_envs * sizeof(uint4);
+    const size_t mt_bytes = (size_t)n_envs * MT_STRIDE * sizeof(uint32_t);
+    hipError_t e;
+    if ((e = hipMalloc(&h->state, state_bytes)) != hipSuccess || (e = hipMalloc(&h->mt, mt_bytes)) != hipSuccess ||
+        (e = hipMalloc(&h->err, sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMemset(h->state, 0, state_bytes)) != hipSuccess || (e = hipMemset(h->err, 0, sizeof(unsigned long long))) != hipSuccess) {
+        if (h->state) (void)hipFree(h->state);
+        if (h->mt) (void)hipFree(h->mt);
+        if (h->err) (void)hipFree(h->err);
+        delete h;
+        return CGE_ERR_HIP;
+    }
+    h->device_bytes = state_bytes + mt_bytes + sizeof(unsigned long long);
+    // default streams: random.seed(env_index0 + i); default state: reset() so a handle is always steppable
+    e = launch_mt_seed(h->mt, MT_STRIDE, n_envs, nullptr, 0, env_index0, 0, nullptr);
+    if (e == hipSuccess) {
+        snake::Params p = h->params();
+        h->ops.reset(p, nullptr);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) {
+        (void)hipFree(h->state); (void)hipFree(h->mt); (void)hipFree(h->err);
+        delete h;
+        return CGE_ERR_HIP;
+    }
+    *out = h;
+    return CGE_OK;
+}
+
+int cge_snake_destroy(cge_snake *h) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    DeviceGuard g(h->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(h->state);
+    (void)hipFree(h->mt);
+    (void)hipFree(h->err);
+    delete h;
+    return CGE_OK;
+}
+
+int cge_snake_seed(cge_snake *h, const uint64_t *seeds, uint64_t base_seed, void *stream) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    DeviceGuard g(h->device);
+    CGE_TRY(h, launch_mt_seed(h->mt, MT_STRIDE, h->n, seeds, base_seed, h->env0, 0, as_stream(stream)));
+    return CGE_OK;
+}
+
+int cge_snake_reset(cge_snake *h, const uint8_t *mask, int8_t *obs_out, void *stream) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    DeviceGuard g(h->device);
+    snake::Params p = h->params();
+    p.mask = mask;
+    p.obs = obs_out;
+    h->ops.reset(p, as_stream(stream));
+    CGE_TRY(h, hipGetLastError());
+    return CGE_OK;
+}
+
+int cge_snake_step(cge_snake *h, const int32_t *actions, int8_t *obs_out, float *reward_out, uint8_t *terminated_out,
+                   uint8_t *truncated_out, int8_t *final_obs_out, void *stream) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    if (!actions || !obs_out || !reward_out || !terminated_out || !truncated_out)
+        return h->fail(CGE_ERR_INVALID_ARG, "cge_snake_step: null actions/obs/reward/terminated/truncated pointer");
+    DeviceGuard g(h->device);
+    snake::Params p = h->params();
+    p.actions = actions; p.obs = obs_out; p.reward = reward_out;
+    p.terminated = terminated_out; p.truncated = truncated_out; p.final_obs = final_obs_out;
+    h->ops.step(p, as_stream(stream));
+    CGE_TRY(h, hipGetLastError());
+    return CGE_OK;
+}
+
+int cge_snake_rollout(cge_snake *h, int32_t k_steps, const int32_t *actions, uint64_t action_seed, int64_t t0,
+                      int8_t *obs_out, int64_t obs_step_stride, float *reward_sum_out, int32_t *done_count_out, void *stream) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    if (k_steps < 0 || obs_step_stride < 0 || (obs_step_stride != 0 && obs_step_stride < h->n * h->ops.cells) ||
+        (obs_step_stride & 3))
+        return h->fail(CGE_ERR_INVALID_ARG, "cge_snake_rollout: bad k_steps / obs_step_stride");
+    if (k_steps == 0) return CGE_OK;
+    DeviceGuard g(h->device);
+    snake::Params p = h->params();
+    p.k_steps = k_steps; p.actions = actions; p.a_seed = action_seed; p.t0 = t0;
+    p.obs = obs_out; p.obs_step_stride = obs_step_stride;
+    p.reward_sum = reward_sum_out; p.done_count = done_count_out;
+    h->ops.rollout(p, as_stream(stream));
+    CGE_TRY(h, hipGetLastError());
+    return CGE_OK;
+}
+
+int cge_snake_info(cge_snake *h, int32_t field_id, int32_t *out, void *stream) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    if (!out || field_id < 0 || field_id > CGE_SNAKE_INFO_NEEDS_RESET)
+        return h->fail(CGE_ERR_INVALID_ARG, "cge_snake_info: bad field id / null out");
+    DeviceGuard g(h->device);
+    h->ops.info(h->state, h->n, field_id, out, as_stream(stream));
+    CGE_TRY(h, hipGetLastError());
+    return CGE_OK;
+}
+
+size_t cge_snake_state_bytes(const cge_snake *h) {
+    if (!h) return 0;
+    size_t b = 8 * 4 + (size_t)MT_N * 4 + (size_t)h->ops.cells * 2;
+    return (b + 3) & ~(size_t)3;
+}
+
+int cge_snake_get_state(cge_snake *h, void *host_buf, void *stream) {
+    if (!h || !host_buf) return CGE_ERR_INVALID_ARG;
+    DeviceGuard g(h->device);
+    const int64_t n = h->n;
+    const int cols = h->ops.cols;
+    std::vector<uint4> st((size_t)cols * n);
+    std::vector<uint32_t> mt((size_t)n * MT_STRIDE);
+    CGE_TRY(h, hipStreamSynchronize(as_stream(stream)));
+    CGE_TRY(h, hipMemcpy(st.data(), h->state, st.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+    CGE_TRY(h, hipMemcpy(mt.data(), h->mt, mt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    const size_t rec = cge_snake_state_bytes(h);
+    std::vector<uint32_t> raw((size_t)cols * 4);
+    for (int64_t i = 0; i < n; ++i) {
+        for (int c = 0; c < cols; ++c) {
+            const uint4 v = st[(size_t)c * n + i];
+            raw[4 * c] = v.x; raw[4 * c + 1] = v.y; raw[4 * c + 2] = v.z; raw[4 * c + 3] = v.w;
+        }
+        uint8_t *p = (uint8_t *)host_buf + (size_t)i * rec;
+        int32_t *hdr = (int32_t *)p;
+        uint32_t *omt = (uint32_t *)(p + 32);
+        uint16_t *body = (uint16_t *)(p + 32 + MT_N * 4);
+        h->ops.decode(raw.data(), hdr, body);
+        // incremental-twist stream -> CPython layout (words >= idx generated but unconsumed)
+        const uint32_t *w = &mt[(size_t)i * MT_STRIDE];
+        uint32_t pos = w[MT_POS], pretw = w[MT_PRETW];
+        memcpy(omt, w, MT_N * 4);
+        if (pretw >= (uint32_t)MT_N) {
+            hdr[7] = (int32_t)pos;
+        } else if (pos == 0) {
+            hdr[7] = MT_N;
+        } else {
+            for (uint32_t k = pos; k < (uint32_t)MT_N; ++k) {
+                const uint32_t k1 = k + 1 == (uint32_t)MT_N ? 0 : k + 1;
+                const uint32_t km = k + MT_M >= (uint32_t)MT_N ? k + MT_M - MT_N : k + MT_M;
+                const uint32_t t = (omt[k] & 0x80000000u) | (omt[k1] & 0x7fffffffu);
+                omt[k] = omt[km] ^ (t >> 1) ^ ((t & 1u) ? 0x9908b0dfu : 0u);
+            }
+            hdr[7] = (int32_t)pos;
+        }
+    }
+    return CGE_OK;
+}
+
+int cge_snake_set_state(cge_snake *h, const void *host_buf, void *stream) {
+    if (!h || !host_buf) return CGE_ERR_INVALID_ARG;
+    DeviceGuard g(h->device);
+    const int64_t n = h->n;
+    const int cols = h->ops.cols, cells = h->ops.cells;
+    const size_t rec = cge_snake_state_bytes(h);
+    std::vector<uint4> st((size_t)cols * n);
+    std::vector<uint32_t> mt((size_t)n * MT_STRIDE, 0u);
+    std::vector<uint32_t> raw((size_t)cols * 4);
+    for (int64_t i = 0; i < n; ++i) {
+        const uint8_t *p = (const uint8_t *)host_buf + (size_t)i * rec;
+        const int32_t *hdr = (const int32_t *)p;
+        const uint16_t *body = (const uint16_t *)(p + 32 + MT_N * 4);
+        if (hdr[0] < 1 || hdr[0] > cells || hdr[1] < 0 || hdr[1] > 3 || hdr[7] < 0 || hdr[7] > MT_N)
+            return h->fail(CGE_ERR_INVALID_ARG, "cge_snake_set_state: malformed record");
+        for (int k = 0; k < hdr[0]; ++k)
+            if (body[k] >= cells) return h->fail(CGE_ERR_INVALID_ARG, "cge_snake_set_state: body cell out of range");
+        h->ops.encode(hdr, body, raw.data());
+        for (int c = 0; c < cols; ++c) st[(size_t)c * n + i] = make_uint4(raw[4 * c], raw[4 * c + 1], raw[4 * c + 2], raw[4 * c + 3]);
+        uint32_t *w = &mt[(size_t)i * MT_STRIDE];
+        memcpy(w, p + 32, MT_N * 4);
+        if (hdr[7] >= MT_N) { w[MT_POS] = 0; w[MT_PRETW] = 0; }
+        else { w[MT_POS] = (uint32_t)hdr[7]; w[MT_PRETW] = MT_N; }
+    }
+    CGE_TRY(h, hipStreamSynchronize(as_stream(stream)));
+    CGE_TRY(h, hipMemcpy(h->state, st.data(), st.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    CGE_TRY(h, hipMemcpy(h->mt, mt.data(), mt.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return CGE_OK;
+}
+
+int64_t cge_snake_error_count(cge_snake *h, void *stream) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    DeviceGuard g(h->device);
+    unsigned long long v = 0;
+    if (hipStreamSynchronize(as_stream(stream)) != hipSuccess) return CGE_ERR_HIP;
+    if (hipMemcpy(&v, h->err, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return CGE_ERR_HIP;
+    if (v && hipMemset(h->err, 0, sizeof v) != hipSuccess) return CGE_ERR_HIP;
+    return (int64_t)v;
+}
+
+size_t cge_snake_device_bytes(const cge_snake *h) { return h ? h->device_bytes : 0; }
+
+const char *cge_snake_last_error(const cge_snake *h) { return h ? h->last_error.c_str() : "null handle"; }
+
+}  // extern "C"
