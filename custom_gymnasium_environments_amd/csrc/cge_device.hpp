@@ -30,63 +30,106 @@ __host__ __device__ inline uint32_t hash_action_from_key(uint64_t key, uint64_t 
 // ------------------------------------------------------------------ MT19937 (family P / L)
 constexpr int MT_N = 624;
 constexpr int MT_M = 397;
-constexpr int MT_STRIDE = 640;  // words per stream block: mt[624], pos, pretw, 14 pad (=2560 B, 20 x 128-B lines)
-constexpr int MT_POS = 624;     // next word index, 0..623
-constexpr int MT_PRETW = 625;   // words in [pos, pretw) are already twisted (imported CPython state); 0 or 624
+constexpr int MT_STRIDE = 640;  // words per stream block: mt[624] + pad (=2560 B, 20 x 128-B lines)
+// The stream cursor lives in the ENV's state record, not in the block, so a draw never starts with a
+// dependent "load the cursor" round trip:
+//   pos    next word index, 0..623
+//   pretw  words in [pos, pretw) are already twisted (a CPython state imported by set_state); 0 or 624
+// Words are twisted one at a time, in place, exactly when they are consumed (incremental form of
+// the reference generator's 624-word batch regeneration; identical output sequence).
 
-// A stream handle kept in registers while an env draws.  `open` costs one 8-byte load, each
-// draw 3 independent 4-byte loads + 1 store inside the env's own block, `close` one 8-byte store.
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+__device__ __forceinline__ uint32_t mt_twist(uint32_t a, uint32_t b, uint32_t c) {
+    const uint32_t t = (a & 0x80000000u) | (b & 0x7fffffffu);
+    return c ^ (t >> 1) ^ ((t & 1u) ? 0x9908b0dfu : 0u);
+}
+
+// Serial stream: one memory round trip per draw (3 independent loads + 1 store).  For rare/long paths.
 struct MtStream {
     uint32_t *w;
     uint32_t pos, pretw;
 
-    __device__ __forceinline__ void open(uint32_t *block) {
-        w = block;
-        uint2 pp = *reinterpret_cast<const uint2 *>(block + MT_POS);
-        pos = pp.x;
-        pretw = pp.y;
-    }
-    __device__ __forceinline__ void close() { *reinterpret_cast<uint2 *>(w + MT_POS) = make_uint2(pos, pretw); }
+    __device__ __forceinline__ MtStream(uint32_t *block, uint32_t pos_, uint32_t pretw_) : w(block), pos(pos_), pretw(pretw_) {}
 
     __device__ __forceinline__ uint32_t next() {
         uint32_t p = pos, y;
         if (p < pretw) {
             y = w[p];
         } else {
-            uint32_t p1 = p + 1 == MT_N ? 0 : p + 1;
-            uint32_t pm = p + MT_M >= MT_N ? p + MT_M - MT_N : p + MT_M;
-            uint32_t a = w[p], b = w[p1], c = w[pm];
-            uint32_t t = (a & 0x80000000u) | (b & 0x7fffffffu);
-            y = c ^ (t >> 1) ^ ((t & 1u) ? 0x9908b0dfu : 0u);
+            const uint32_t p1 = p + 1 == MT_N ? 0 : p + 1;
+            const uint32_t pm = p + MT_M >= MT_N ? p + MT_M - MT_N : p + MT_M;
+            y = mt_twist(w[p], w[p1], w[pm]);
             w[p] = y;
         }
         ++p;
         if (p == MT_N) { p = 0; pretw = 0; }
         pos = p;
-        y ^= y >> 11;
-        y ^= (y << 7) & 0x9d2c5680u;
-        y ^= (y << 15) & 0xefc60000u;
-        y ^= y >> 18;
-        return y;
+        return mt_temper(y);
     }
-    // CPython Random._randbelow_with_getrandbits(n) with k = n.bit_length() known at compile time
-    template <int KBITS>
-    __device__ __forceinline__ uint32_t randbelow(uint32_t n) {
-        uint32_t r = next() >> (32 - KBITS);
-        while (r >= n) r = next() >> (32 - KBITS);
-        return r;
-    }
-    __device__ __forceinline__ uint32_t randbelow_k(uint32_t n, int kbits) {
+    // CPython Random._randbelow_with_getrandbits(n), k = n.bit_length()
+    __device__ __forceinline__ uint32_t randbelow(uint32_t n, int kbits) {
         uint32_t r = next() >> (32 - kbits);
         while (r >= n) r = next() >> (32 - kbits);
         return r;
     }
     // CPython random.random() == NumPy legacy random_sample(): 53-bit double from two words
     __device__ __forceinline__ double random53() {
-        uint32_t a = next() >> 5, b = next() >> 6;
+        const uint32_t a = next() >> 5, b = next() >> 6;
         return (a * 67108864.0 + b) / 9007199254740992.0;
     }
     __device__ __forceinline__ double uniform(double lo, double hi) { return lo + (hi - lo) * random53(); }
+};
+
+// Windowed stream: fetches everything the next W draws can need in ONE round trip (2W+1 independent
+// 4-byte loads inside the env's own block: w[pos..pos+W] and w[pos+397..pos+397+W-1], indices mod 624),
+// hands out the twisted words from registers, then writes back only the words actually consumed.
+// No entry of the window depends on another (397 is not congruent to any |j'-j| <= W mod 624).
+template <int W>
+struct MtWindow {
+    uint32_t a[W + 1];
+    uint32_t c[W];
+
+    __device__ __forceinline__ void load(const uint32_t *__restrict__ blk, uint32_t pos) {
+#pragma unroll
+        for (int j = 0; j <= W; ++j) {
+            uint32_t k = pos + j;
+            k -= k >= (uint32_t)MT_N ? MT_N : 0;
+            a[j] = blk[k];
+        }
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            uint32_t k = pos + MT_M + j;
+            k -= k >= (uint32_t)MT_N ? MT_N : 0;
+            c[j] = blk[k];
+        }
+    }
+    // untempered word number j (static index) of the stream starting at (pos, pretw)
+    __device__ __forceinline__ uint32_t twisted(int j, uint32_t pos, uint32_t pretw) const {
+        const uint32_t y = mt_twist(a[j], a[j + 1], c[j]);
+        return (pos + j < pretw) ? a[j] : y;
+    }
+    __device__ __forceinline__ uint32_t draw(int j, uint32_t pos, uint32_t pretw) const { return mt_temper(twisted(j, pos, pretw)); }
+    // persist the first `used` words and advance the cursor
+    __device__ __forceinline__ void commit(uint32_t *__restrict__ blk, uint32_t &pos, uint32_t &pretw, uint32_t used) const {
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            uint32_t k = pos + j;
+            if ((uint32_t)j < used && k >= pretw) {
+                const uint32_t y = mt_twist(a[j], a[j + 1], c[j]);
+                k -= k >= (uint32_t)MT_N ? MT_N : 0;
+                blk[k] = y;
+            }
+        }
+        uint32_t p = pos + used;
+        if (p >= (uint32_t)MT_N) { p -= MT_N; pretw = 0; }
+        pos = p;
+    }
 };
 
 // ------------------------------------------------------------------ small register arrays

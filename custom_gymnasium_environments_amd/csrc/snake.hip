@@ -8,12 +8,15 @@
 //   dirs  2 bits per cell  direction the head LEFT that cell (replaces the Python list's order:
 //                          the tail advances by following its own cell's direction, O(1), no ring
 //                          buffer traffic; list.insert(0,..)/pop() become two bit updates)
-//   m0    head:10 tail:10 food:10 dir:2      m1  steps:16 score:10 flags     m2  episodes
+//   head, tail, food, dir, steps, score, flags, episodes, and the env's MT19937 cursor (pos, pretw)
 // stored struct-of-arrays as COLS columns of uint4 (column c of env i at state[c*N+i]) so a
-// wavefront's loads/stores are 16 B per lane, fully coalesced.  The whole record lives in VGPRs
-// during a step (static-index select chains, cge_device.hpp), the RNG block is touched only by
-// the lanes that place food.  The (N,G,G) int8 observation is built in LDS (one row per lane,
-// dword stride G*G/4 — odd for G=10, so conflict-free) and streamed out as 16-byte stores.
+// wavefront's loads/stores are 16 B per lane, fully coalesced.  For the benchmark grid (G=10) the
+// scalars are packed into the spare bits of the occ/dirs words: 48 B per env (3 columns).
+// The whole record lives in VGPRs during a step (static-index mask/select chains, cge_device.hpp).
+// Food placement (the only RNG use) fetches a window of the env's MT19937 block in ONE round trip,
+// issued before the observation is staged so its latency hides behind that work.
+// The (N,G,G) int8 observation is built in LDS (one row per lane, dword stride G*G/4 — odd for
+// G=10, so conflict-free) and streamed out as 16-byte-per-lane stores.
 #include <cstring>
 #include <vector>
 
@@ -30,17 +33,21 @@ constexpr int bitlen(int n) {
 }
 
 enum : uint32_t { F_NEEDS_RESET = 1u, F_BOARD_FULL = 2u, F_FOOD_VALID = 4u };
+constexpr int FOOD_WINDOW = 8;   // MT words fetched per round trip by _place_food (mean use: 3.2 for G=10)
 
 template <int G>
 struct Lay {
     static constexpr int CELLS = G * G;
     static constexpr int OCCW = (CELLS + 31) / 32;
     static constexpr int DIRW = (CELLS + 15) / 16;
-    static constexpr int NW = OCCW + DIRW + 3;
+    // G=10: occ uses 100 of 128 bits, dirs 200 of 224 -> scalars live in the spare bits, 12 words total
+    static constexpr bool TIGHT = (G == 10);
+    static constexpr int NW = TIGHT ? 12 : OCCW + DIRW + 4;
     static constexpr int COLS = (NW + 3) / 4;
     static constexpr int OBS_DW = CELLS / 4;
     static constexpr int KBITS = bitlen(G);  // CPython: k = n.bit_length() for _randbelow(G)
     static constexpr int BLOCK = (CELLS <= 144) ? 256 : 64;
+    static constexpr int MAX_STEPS_LIMIT = TIGHT ? 4095 : 65535;
     static_assert(CELLS % 4 == 0, "obs rows are staged as dwords: G must be even");
     static_assert(CELLS <= 1023, "cell index is packed in 10 bits");
 };
@@ -50,7 +57,7 @@ struct Env {
     using L = Lay<G>;
     uint32_t occ[L::OCCW];
     uint32_t dirs[L::DIRW];
-    uint32_t head, tail, food, dir, steps, score, flags, episodes;
+    uint32_t head, tail, food, dir, steps, score, flags, episodes, mt_pos, mt_pretw;
 
     __device__ __forceinline__ void load(const uint4 *__restrict__ state, int64_t n, int64_t i) {
         uint32_t raw[L::COLS * 4];
@@ -73,52 +80,95 @@ struct Env {
         for (int k = 0; k < L::OCCW; ++k) occ[k] = raw[k];
 #pragma unroll
         for (int k = 0; k < L::DIRW; ++k) dirs[k] = raw[L::OCCW + k];
-        const uint32_t m0 = raw[L::OCCW + L::DIRW], m1 = raw[L::OCCW + L::DIRW + 1];
-        head = m0 & 1023u; tail = (m0 >> 10) & 1023u; food = (m0 >> 20) & 1023u; dir = m0 >> 30;
-        steps = m1 & 0xffffu; score = (m1 >> 16) & 1023u; flags = m1 >> 26;
-        episodes = raw[L::OCCW + L::DIRW + 2];
+        if constexpr (L::TIGHT) {
+            // word 3: occ bits 96..99 | steps:12 @4 | score:7 @16 | flags:3 @23
+            // word 10: dirs of cells 96..99 (8 bits) | head:7 @8 | tail:7 @15 | food:7 @22 | dir:2 @29
+            // word 11: mt_pos:10 | mt_pretw!=0 @10 | episodes:21 @11
+            const uint32_t m1 = raw[3], m0 = raw[10], m2 = raw[11];
+            occ[3] = m1 & 0xFu;
+            steps = (m1 >> 4) & 0xFFFu; score = (m1 >> 16) & 0x7Fu; flags = (m1 >> 23) & 7u;
+            dirs[6] = m0 & 0xFFu;
+            head = (m0 >> 8) & 0x7Fu; tail = (m0 >> 15) & 0x7Fu; food = (m0 >> 22) & 0x7Fu; dir = (m0 >> 29) & 3u;
+            mt_pos = m2 & 1023u; mt_pretw = (m2 & 1024u) ? (uint32_t)MT_N : 0u; episodes = m2 >> 11;
+        } else {
+            const uint32_t m0 = raw[L::OCCW + L::DIRW], m1 = raw[L::OCCW + L::DIRW + 1], m3 = raw[L::OCCW + L::DIRW + 3];
+            head = m0 & 1023u; tail = (m0 >> 10) & 1023u; food = (m0 >> 20) & 1023u; dir = m0 >> 30;
+            steps = m1 & 0xffffu; score = (m1 >> 16) & 1023u; flags = m1 >> 26;
+            episodes = raw[L::OCCW + L::DIRW + 2];
+            mt_pos = m3 & 1023u; mt_pretw = (m3 & 1024u) ? (uint32_t)MT_N : 0u;
+        }
     }
     __host__ __device__ __forceinline__ void pack(uint32_t *raw) const {
 #pragma unroll
         for (int k = 0; k < L::OCCW; ++k) raw[k] = occ[k];
 #pragma unroll
         for (int k = 0; k < L::DIRW; ++k) raw[L::OCCW + k] = dirs[k];
-        raw[L::OCCW + L::DIRW] = head | (tail << 10) | (food << 20) | (dir << 30);
-        raw[L::OCCW + L::DIRW + 1] = steps | (score << 16) | (flags << 26);
-        raw[L::OCCW + L::DIRW + 2] = episodes;
+        if constexpr (L::TIGHT) {
+            raw[3] = (occ[3] & 0xFu) | (steps << 4) | (score << 16) | (flags << 23);
+            raw[10] = (dirs[6] & 0xFFu) | (head << 8) | (tail << 15) | (food << 22) | (dir << 29);
+            raw[11] = mt_pos | (mt_pretw ? 1024u : 0u) | (episodes << 11);
+        } else {
+            raw[L::OCCW + L::DIRW] = head | (tail << 10) | (food << 20) | (dir << 30);
+            raw[L::OCCW + L::DIRW + 1] = steps | (score << 16) | (flags << 26);
+            raw[L::OCCW + L::DIRW + 2] = episodes;
+            raw[L::OCCW + L::DIRW + 3] = mt_pos | (mt_pretw ? 1024u : 0u);
 #pragma unroll
-        for (int k = L::NW; k < L::COLS * 4; ++k) raw[k] = 0;
+            for (int k = L::NW; k < L::COLS * 4; ++k) raw[k] = 0;
+        }
     }
 
     __device__ __forceinline__ uint32_t occupied(uint32_t cell) const { return (sel(occ, cell >> 5) >> (cell & 31u)) & 1u; }
-    __device__ __forceinline__ uint32_t length() const {
+    __host__ __device__ __forceinline__ uint32_t length() const {
         uint32_t c = 0;
 #pragma unroll
-        for (int k = 0; k < L::OCCW; ++k) c += __popc(occ[k]);
+        for (int k = 0; k < L::OCCW; ++k) c += (uint32_t)__builtin_popcount(occ[k]);
         return c;
     }
 
-    // snake_env.py:121-129 — row drawn first, then column, whole pair redrawn while on the snake
-    __device__ __forceinline__ void place_food(uint32_t *mt_block) {
-        if (length() >= (uint32_t)L::CELLS) {  // reference spins forever here; reported via info, never silent
+    // snake_env.py:123 would spin forever on a full board: reported via info (sticky), never silent
+    __device__ __forceinline__ bool can_place_food() {
+        if (length() >= (uint32_t)L::CELLS) {
             flags = (flags | F_BOARD_FULL) & ~F_FOOD_VALID;
-            return;
+            return false;
         }
-        MtStream rng;
-        rng.open(mt_block);
-        uint32_t cell;
-        do {
-            uint32_t r = rng.template randbelow<L::KBITS>(G);
-            uint32_t c = rng.template randbelow<L::KBITS>(G);
-            cell = r * G + c;
-        } while (occupied(cell));
-        rng.close();
-        food = cell;
+        return true;
+    }
+
+    // snake_env.py:121-129 — `random.randint(0,G-1)` twice (row first, then column), each
+    // _randbelow(G): r = next_u32 >> (32-k), redrawn while r >= G; the pair is redrawn while it lies
+    // on the snake.  `win` was loaded at the current cursor; a reload happens only if 8 words were
+    // not enough (0.6 % of placements for G=10).
+    __device__ __forceinline__ void place_food(uint32_t *__restrict__ blk, MtWindow<FOOD_WINDOW> &win) {
+        uint32_t phase = 0, row = 0;
+        for (;;) {
+            uint32_t used = 0;
+            bool done = false;
+#pragma unroll
+            for (int j = 0; j < FOOD_WINDOW; ++j) {
+                if (!done) {
+                    const uint32_t r = win.draw(j, mt_pos, mt_pretw) >> (32 - L::KBITS);
+                    used = j + 1;
+                    if (r < (uint32_t)G) {
+                        if (phase == 0) {
+                            row = r;
+                            phase = 1;
+                        } else {
+                            phase = 0;
+                            const uint32_t cell = row * G + r;
+                            if (!occupied(cell)) { food = cell; done = true; }
+                        }
+                    }
+                }
+            }
+            win.commit(blk, mt_pos, mt_pretw, used);
+            if (done) break;
+            win.load(blk, mt_pos);
+        }
         flags |= F_FOOD_VALID;
     }
 
-    // snake_env.py:49-65
-    __device__ __forceinline__ void reset(uint32_t *mt_block) {
+    // snake_env.py:49-65 without the trailing _place_food()
+    __device__ __forceinline__ void reset_body() {
 #pragma unroll
         for (int k = 0; k < L::OCCW; ++k) occ[k] = 0;
 #pragma unroll
@@ -130,11 +180,11 @@ struct Env {
         score = 0;
         steps = 0;
         flags &= ~F_NEEDS_RESET;
-        place_food(mt_block);
     }
 
-    // snake_env.py:67-119; returns terminated
-    __device__ __forceinline__ bool step(uint32_t action, uint32_t max_steps, uint32_t *mt_block, float &reward) {
+    // snake_env.py:67-119 without _place_food(); returns terminated, sets `ate`
+    __device__ __forceinline__ bool move(uint32_t action, uint32_t max_steps, float &reward, bool &ate) {
+        ate = false;
         const int d = (int)action - (int)dir;
         if (d != 2 && d != -2) dir = action;                                      // :73-74
         const uint32_t hr = head / G, hc = head - hr * G;
@@ -157,7 +207,7 @@ struct Env {
         if ((flags & F_FOOD_VALID) && ncell == food) {                            // :101-104
             score += 1;
             reward = 10.0f;
-            place_food(mt_block);
+            ate = true;
         } else {                                                                  // :107 pop()
             const uint32_t td = (sel(dirs, tail >> 4) >> ((tail & 15u) * 2u)) & 3u;
             andnot_word(occ, tail >> 5, 1u << (tail & 31u));
@@ -169,12 +219,14 @@ struct Env {
     }
 
     // snake_env.py:131-143 — one int8 row of G*G cells as OBS_DW dwords; `row` may be LDS or global
-    __device__ __forceinline__ void write_obs(uint32_t *row) const {
+    __device__ __forceinline__ void write_obs_body(uint32_t *row) const {
 #pragma unroll
         for (int j = 0; j < L::OBS_DW; ++j) {
             const uint32_t b = (occ[(4 * j) >> 5] >> ((4 * j) & 31)) & 0xFu;
             row[j] = (b * 0x00204081u) & 0x01010101u;   // 4 occupancy bits -> 4 bytes of 0/1
         }
+    }
+    __device__ __forceinline__ void write_obs_food(uint32_t *row) const {
         if (flags & F_FOOD_VALID) reinterpret_cast<int8_t *>(row)[food] = 2;
     }
 };
@@ -197,6 +249,46 @@ struct Params {
     unsigned long long *err_count;
 };
 
+// One env transition with fused auto-reset.  Everything except the food draw happens first; the RNG
+// window load is issued, the obs body is staged while it is in flight, then the food is placed.
+template <int G>
+__device__ __forceinline__ void transition(Env<G> &e, const Params &p, int64_t i, uint32_t action, bool valid_action,
+                                           uint32_t *__restrict__ obs_row, float &reward, bool &term) {
+    using L = Lay<G>;
+    uint32_t *__restrict__ blk = p.mt + i * MT_STRIDE;
+    bool need_food = false;
+    reward = 0.0f;
+    term = false;
+    if (p.mode == CGE_AUTORESET_NEXT_STEP && (e.flags & F_NEEDS_RESET)) {
+        e.reset_body();
+        need_food = true;
+    } else if (!valid_action) {
+        atomicAdd(p.err_count, 1ull);   // reference: ValueError (snake_env.py:69-70)
+    } else {
+        term = e.move(action, (uint32_t)p.max_steps, reward, need_food);
+        if (term) {
+            e.episodes += 1;
+            if (p.mode == CGE_AUTORESET_SAME_STEP) {
+                if (p.final_obs) {   // terminal observation, rare lanes only: direct row store
+                    uint32_t *frow = reinterpret_cast<uint32_t *>(p.final_obs + i * L::CELLS);
+                    e.write_obs_body(frow);
+                    e.write_obs_food(frow);
+                }
+                e.reset_body();
+                need_food = true;
+            } else if (p.mode == CGE_AUTORESET_NEXT_STEP) {
+                e.flags |= F_NEEDS_RESET;
+            }
+        }
+    }
+    if (need_food) need_food = e.can_place_food();
+    MtWindow<FOOD_WINDOW> win;
+    if (need_food) win.load(blk, e.mt_pos);
+    if (obs_row) e.write_obs_body(obs_row);
+    if (need_food) e.place_food(blk, win);
+    if (obs_row) e.write_obs_food(obs_row);
+}
+
 template <int G>
 __global__ __launch_bounds__(Lay<G>::BLOCK) void step_kernel(Params p) {
     using L = Lay<G>;
@@ -207,31 +299,14 @@ __global__ __launch_bounds__(Lay<G>::BLOCK) void step_kernel(Params p) {
     if (i < p.n) {
         Env<G> e;
         e.load(p.state, p.n, i);
-        uint32_t *mtb = p.mt + i * MT_STRIDE;
         const int32_t a = p.actions[i];
-        float r = 0.0f;
-        bool term = false;
-        if (p.mode == CGE_AUTORESET_NEXT_STEP && (e.flags & F_NEEDS_RESET)) {
-            e.reset(mtb);
-        } else if ((uint32_t)a > 3u) {
-            atomicAdd(p.err_count, 1ull);   // reference: ValueError (snake_env.py:69-70)
-        } else {
-            term = e.step((uint32_t)a, (uint32_t)p.max_steps, mtb, r);
-            if (term) {
-                e.episodes += 1;
-                if (p.mode == CGE_AUTORESET_SAME_STEP) {
-                    if (p.final_obs) e.write_obs(reinterpret_cast<uint32_t *>(p.final_obs + i * L::CELLS));
-                    e.reset(mtb);
-                } else if (p.mode == CGE_AUTORESET_NEXT_STEP) {
-                    e.flags |= F_NEEDS_RESET;
-                }
-            }
-        }
-        e.write_obs(tile + threadIdx.x * L::OBS_DW);
+        float r;
+        bool term;
+        transition<G>(e, p, i, (uint32_t)a, (uint32_t)a <= 3u, tile + threadIdx.x * L::OBS_DW, r, term);
         e.store(p.state, p.n, i);
         p.reward[i] = r;
         p.terminated[i] = term ? 1 : 0;
-        p.truncated[i] = 0;   // reference never truncates (snake_env.py:119)
+        if (p.truncated) p.truncated[i] = 0;   // reference never truncates (snake_env.py:119)
     }
     __syncthreads();
     const int64_t live = p.n - first < L::BLOCK ? p.n - first : L::BLOCK;
@@ -249,37 +324,23 @@ __global__ __launch_bounds__(Lay<G>::BLOCK) void rollout_kernel(Params p) {
     const bool live_lane = i < p.n;
     const int64_t live = p.n - first < L::BLOCK ? p.n - first : L::BLOCK;
     Env<G> e;
-    uint32_t *mtb = nullptr;
     uint64_t key = 0;
     float rsum = 0.0f;
     int32_t dcount = 0;
     if (live_lane) {
         e.load(p.state, p.n, i);
-        mtb = p.mt + i * MT_STRIDE;
         key = hash_env_key(p.a_seed, (uint64_t)(p.env0 + i));
     }
+    uint32_t *row = p.obs ? tile + threadIdx.x * L::OBS_DW : nullptr;
     for (int t = 0; t < p.k_steps; ++t) {
         if (live_lane) {
-            if (p.mode == CGE_AUTORESET_NEXT_STEP && (e.flags & F_NEEDS_RESET)) {
-                e.reset(mtb);
-            } else {
-                const uint32_t a = p.actions ? (uint32_t)p.actions[(int64_t)t * p.n + i]
-                                             : hash_action_from_key(key, (uint64_t)(p.t0 + t), 4u, 0u);
-                if (a > 3u) {
-                    atomicAdd(p.err_count, 1ull);
-                } else {
-                    float r;
-                    const bool term = e.step(a, (uint32_t)p.max_steps, mtb, r);
-                    rsum += r;
-                    if (term) {
-                        ++dcount;
-                        e.episodes += 1;
-                        if (p.mode == CGE_AUTORESET_SAME_STEP) e.reset(mtb);
-                        else if (p.mode == CGE_AUTORESET_NEXT_STEP) e.flags |= F_NEEDS_RESET;
-                    }
-                }
-            }
-            if (p.obs) e.write_obs(tile + threadIdx.x * L::OBS_DW);
+            const uint32_t a = p.actions ? (uint32_t)p.actions[(int64_t)t * p.n + i]
+                                         : hash_action_from_key(key, (uint64_t)(p.t0 + t), 4u, 0u);
+            float r;
+            bool term;
+            transition<G>(e, p, i, a, a <= 3u, row, r, term);
+            rsum += r;
+            dcount += term ? 1 : 0;
         }
         if (p.obs) {
             __syncthreads();
@@ -304,17 +365,38 @@ __global__ __launch_bounds__(Lay<G>::BLOCK) void reset_kernel(Params p) {
     if (i < p.n) {
         Env<G> e;
         e.load(p.state, p.n, i);
-        if (!p.mask || p.mask[i]) {
-            e.reset(p.mt + i * MT_STRIDE);
-            e.store(p.state, p.n, i);
+        uint32_t *row = p.obs ? tile + threadIdx.x * L::OBS_DW : nullptr;
+        uint32_t *blk = p.mt + i * MT_STRIDE;
+        const bool doit = !p.mask || p.mask[i];
+        bool need_food = false;
+        if (doit) {
+            e.reset_body();
+            need_food = e.can_place_food();
         }
-        if (p.obs) e.write_obs(tile + threadIdx.x * L::OBS_DW);
+        MtWindow<FOOD_WINDOW> win;
+        if (need_food) win.load(blk, e.mt_pos);
+        if (row) e.write_obs_body(row);
+        if (need_food) e.place_food(blk, win);
+        if (row) e.write_obs_food(row);
+        if (doit) e.store(p.state, p.n, i);
     }
     if (p.obs) {
         __syncthreads();
         const int64_t live = p.n - first < L::BLOCK ? p.n - first : L::BLOCK;
         store_tile<L::BLOCK>(tile, p.obs + first * L::CELLS, (uint32_t)(live * L::CELLS));
     }
+}
+
+// after (re)seeding: the streams restart at word 0 with nothing pre-twisted
+template <int G>
+__global__ __launch_bounds__(256) void rewind_kernel(uint4 *__restrict__ state, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    Env<G> e;
+    e.load(state, n, i);
+    e.mt_pos = 0;
+    e.mt_pretw = 0;
+    e.store(state, n, i);
 }
 
 template <int G>
@@ -343,22 +425,24 @@ __global__ __launch_bounds__(256) void info_kernel(const uint4 *__restrict__ sta
 
 // ------------------------------------------------------------------ host side
 struct Ops {
-    int cells, cols, block, nw;
+    int cells, cols, block, nw, max_steps_limit;
+    void (*rewind)(uint4 *, int64_t, hipStream_t);
     void (*step)(const Params &, hipStream_t);
     void (*rollout)(const Params &, hipStream_t);
     void (*reset)(const Params &, hipStream_t);
     void (*info)(const uint4 *, int64_t, int, int32_t *, hipStream_t);
-    void (*decode)(const uint32_t *raw, int32_t *hdr, uint16_t *body);
+    void (*decode)(const uint32_t *raw, int32_t *hdr, uint16_t *body, uint32_t *mt_pos, uint32_t *mt_pretw);
     void (*encode)(const int32_t *hdr, const uint16_t *body, uint32_t *raw);
 };
 
 template <int G>
-void decode_env(const uint32_t *raw, int32_t *hdr, uint16_t *body) {
+void decode_env(const uint32_t *raw, int32_t *hdr, uint16_t *body, uint32_t *mt_pos, uint32_t *mt_pretw) {
     using L = Lay<G>;
     Env<G> e;
     e.unpack(raw);
-    int len = 0;
-    for (int k = 0; k < L::OCCW; ++k) len += __builtin_popcount(e.occ[k]);
+    *mt_pos = e.mt_pos;
+    *mt_pretw = e.mt_pretw;
+    const int len = (int)e.length();
     const bool fv = e.flags & F_FOOD_VALID;
     hdr[0] = len; hdr[1] = (int32_t)e.dir;
     hdr[2] = fv ? (int32_t)(e.food / G) : -1; hdr[3] = fv ? (int32_t)(e.food % G) : -1;
@@ -396,6 +480,9 @@ void encode_env(const int32_t *hdr, const uint16_t *body, uint32_t *raw) {
     e.steps = (uint32_t)hdr[5];
     e.flags = (hdr[6] ? F_NEEDS_RESET : 0u) | (fv ? F_FOOD_VALID : 0u);
     e.episodes = 0;
+    // canonical CPython cursor -> incremental cursor
+    if (hdr[7] >= MT_N) { e.mt_pos = 0; e.mt_pretw = 0; }
+    else { e.mt_pos = (uint32_t)hdr[7]; e.mt_pretw = MT_N; }
     e.pack(raw);
 }
 
@@ -403,7 +490,10 @@ template <int G>
 Ops make_ops() {
     using L = Lay<G>;
     Ops o;
-    o.cells = L::CELLS; o.cols = L::COLS; o.block = L::BLOCK; o.nw = L::NW;
+    o.cells = L::CELLS; o.cols = L::COLS; o.block = L::BLOCK; o.nw = L::NW; o.max_steps_limit = L::MAX_STEPS_LIMIT;
+    o.rewind = [](uint4 *st, int64_t n, hipStream_t s) {
+        hipLaunchKernelGGL(rewind_kernel<G>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st, n);
+    };
     o.step = [](const Params &p, hipStream_t s) {
         hipLaunchKernelGGL(step_kernel<G>, dim3((unsigned)((p.n + L::BLOCK - 1) / L::BLOCK)), dim3(L::BLOCK), 0, s, p);
     };
@@ -473,6 +563,7 @@ int cge_snake_create(const cge_snake_config *cfg, int64_t n_envs, int device, in
     cge_snake *h = new cge_snake();
     h->cfg = *cfg;
     if (h->cfg.max_steps == 0) h->cfg.max_steps = 1000;   // snake_env.py:47
+    if (h->cfg.max_steps > ops.max_steps_limit) { delete h; return CGE_ERR_UNSUPPORTED; }
     h->ops = ops;
     h->n = n_envs; h->env0 = env_index0; h->device = device;
     DeviceGuard g(device);
@@ -521,6 +612,8 @@ int cge_snake_seed(cge_snake *h, const uint64_t *seeds, uint64_t base_seed, void
     if (!h) return CGE_ERR_INVALID_ARG;
     DeviceGuard g(h->device);
     CGE_TRY(h, launch_mt_seed(h->mt, MT_STRIDE, h->n, seeds, base_seed, h->env0, 0, as_stream(stream)));
+    h->ops.rewind(h->state, h->n, as_stream(stream));   // stream cursors back to word 0
+    CGE_TRY(h, hipGetLastError());
     return CGE_OK;
 }
 
@@ -538,8 +631,8 @@ int cge_snake_reset(cge_snake *h, const uint8_t *mask, int8_t *obs_out, void *st
 int cge_snake_step(cge_snake *h, const int32_t *actions, int8_t *obs_out, float *reward_out, uint8_t *terminated_out,
                    uint8_t *truncated_out, int8_t *final_obs_out, void *stream) {
     if (!h) return CGE_ERR_INVALID_ARG;
-    if (!actions || !obs_out || !reward_out || !terminated_out || !truncated_out)
-        return h->fail(CGE_ERR_INVALID_ARG, "cge_snake_step: null actions/obs/reward/terminated/truncated pointer");
+    if (!actions || !obs_out || !reward_out || !terminated_out)
+        return h->fail(CGE_ERR_INVALID_ARG, "cge_snake_step: null actions/obs/reward/terminated pointer");
     DeviceGuard g(h->device);
     snake::Params p = h->params();
     p.actions = actions; p.obs = obs_out; p.reward = reward_out;
@@ -603,10 +696,10 @@ int cge_snake_get_state(cge_snake *h, void *host_buf, void *stream) {
         int32_t *hdr = (int32_t *)p;
         uint32_t *omt = (uint32_t *)(p + 32);
         uint16_t *body = (uint16_t *)(p + 32 + MT_N * 4);
-        h->ops.decode(raw.data(), hdr, body);
+        uint32_t pos = 0, pretw = 0;
+        h->ops.decode(raw.data(), hdr, body, &pos, &pretw);
         // incremental-twist stream -> CPython layout (words >= idx generated but unconsumed)
         const uint32_t *w = &mt[(size_t)i * MT_STRIDE];
-        uint32_t pos = w[MT_POS], pretw = w[MT_PRETW];
         memcpy(omt, w, MT_N * 4);
         if (pretw >= (uint32_t)MT_N) {
             hdr[7] = (int32_t)pos;
@@ -646,8 +739,6 @@ int cge_snake_set_state(cge_snake *h, const void *host_buf, void *stream) {
         for (int c = 0; c < cols; ++c) st[(size_t)c * n + i] = make_uint4(raw[4 * c], raw[4 * c + 1], raw[4 * c + 2], raw[4 * c + 3]);
         uint32_t *w = &mt[(size_t)i * MT_STRIDE];
         memcpy(w, p + 32, MT_N * 4);
-        if (hdr[7] >= MT_N) { w[MT_POS] = 0; w[MT_PRETW] = 0; }
-        else { w[MT_POS] = (uint32_t)hdr[7]; w[MT_PRETW] = MT_N; }
     }
     CGE_TRY(h, hipStreamSynchronize(as_stream(stream)));
     CGE_TRY(h, hipMemcpy(h->state, st.data(), st.size() * sizeof(uint4), hipMemcpyHostToDevice));

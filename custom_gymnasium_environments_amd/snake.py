@@ -71,17 +71,24 @@ class SnakeVectorEnv(DeviceVectorEnv):
         obs = self._out("obs", self._obs_shape, torch.int8)
         rew = self._out("reward", (self.num_envs,), torch.float32)
         term = self._out("terminated", (self.num_envs,), torch.bool)
-        trunc = self._out("truncated", (self.num_envs,), torch.bool)
+        # the reference never truncates (snake_env.py:119): one shared all-False tensor, never rewritten
+        trunc = self._never_truncated()
         same = self._mode_code == _native.AUTORESET_SAME_STEP
         fin = self._out("final_obs", self._obs_shape, torch.int8) if same else None
         self._check(self._lib.cge_snake_step(self._h, a.data_ptr(), obs.data_ptr(), rew.data_ptr(), term.data_ptr(),
-                                             trunc.data_ptr(), fin.data_ptr() if same else None, self._stream()), "step")
+                                             None, fin.data_ptr() if same else None, self._stream()), "step")
         infos = self._infos()
         if same:
             # rows of final_obs are valid where _final_obs is True (gymnasium's SAME_STEP convention)
             infos["final_obs"] = fin
             infos["_final_obs"] = term
         return obs, rew, term, trunc, infos
+
+    def _never_truncated(self):
+        t = self._bufs.get("_truncated")
+        if t is None:
+            t = self._bufs["_truncated"] = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
+        return t
 
     # ------------------------------------------------------------------ extras
     def rollout(self, k_steps, actions=None, action_seed=0, t0=0, trajectory=False, want_obs=True):

@@ -69,7 +69,7 @@ typedef struct cge_snake cge_snake;
 
 typedef struct {
     int32_t grid_size;      /* reference default 20 (snake_env.py:19); BASELINE configs use 10 */
-    int32_t max_steps;      /* reference: 1000 (snake_env.py:47); 0 -> 1000; must be < 65536 */
+    int32_t max_steps;      /* reference: 1000 (snake_env.py:47); 0 -> 1000; <= 4095 for grid 10, <= 65535 otherwise */
     int32_t autoreset_mode; /* CGE_AUTORESET_* */
     int32_t reserved;
 } cge_snake_config;
@@ -100,8 +100,8 @@ int cge_snake_reset(cge_snake *h, const uint8_t *mask, int8_t *obs_out, void *st
  * (snake_env.py:69-70); here the env is left untouched, its row reports (current obs, 0, 0, 0) and a
  * device-side counter is bumped: read it with cge_snake_error_count (which synchronises). */
 int cge_snake_step(cge_snake *h, const int32_t *actions, int8_t *obs_out, float *reward_out,
-                   uint8_t *terminated_out, uint8_t *truncated_out, int8_t *final_obs_out /*nullable*/,
-                   void *stream);
+                   uint8_t *terminated_out, uint8_t *truncated_out /*nullable: always 0, snake_env.py:119*/,
+                   int8_t *final_obs_out /*nullable*/, void *stream);
 /* k_steps fused step()s in ONE launch.  actions: [k_steps, n_envs] int32 or NULL -> cge_hash_action(
  * action_seed, env_index0+i, t0+t, 4, 0).  obs_out: one [n_envs,G,G] buffer rewritten every step
  * (obs_step_stride = 0) or a trajectory buffer [k_steps, n_envs, G, G] (obs_step_stride = n_envs*G*G);

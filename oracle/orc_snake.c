@@ -120,9 +120,8 @@ void orc_snake_seed(orc_snake *h, const uint64_t *seeds) {
 void orc_snake_reset(orc_snake *h, const uint8_t *mask, int8_t *obs) {
     int cells = h->G * h->G;
     for (int64_t i = 0; i < h->n; ++i) {
-        if (mask && !mask[i]) continue;
-        env_reset(h, &h->e[i]);
-        if (obs) write_obs(h, &h->e[i], obs + i * cells);
+        if (!mask || mask[i]) env_reset(h, &h->e[i]);
+        if (obs) write_obs(h, &h->e[i], obs + i * cells);   /* every row is written, like the device ABI */
     }
 }
 
