@@ -38,7 +38,11 @@ def cpu_baseline_snake(grid, budget_s=12.0):
     """Times the oracle (C port of snake_env.py, single-threaded per handle) on all host cores:
     one handle per thread, ctypes releases the GIL.  Bounded sample of the same workload."""
     import oracle
-    cores = max(1, min(os.cpu_count() or 1, 64))
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))        # a 1-GPU box's CPU share is 16 cores
     n_each, k = 8192, 250
     # calibrate on one core, then size the sample to roughly budget_s of wall time
     o = oracle.SnakeOracle(n_each, grid, oracle.SAME_STEP)
@@ -46,7 +50,7 @@ def cpu_baseline_snake(grid, budget_s=12.0):
     t = time.perf_counter()
     o.rollout(k, 123, 0, 0)
     one = time.perf_counter() - t
-    reps = max(1, int(budget_s / max(one, 1e-3)))
+    reps = max(1, min(int(budget_s / max(one, 1e-3)), 2000))
     handles = []
     for c in range(cores):
         h = oracle.SnakeOracle(n_each, grid, oracle.SAME_STEP)
@@ -71,6 +75,17 @@ def cpu_baseline_snake(grid, budget_s=12.0):
                        f"oracle/orc_snake.c; single-core rate {n_each * k / one:.3e}",
                 reference_python_note="reference Python measured in the build container (8-core Xeon 2.6 GHz): "
                                       "3.4e5-4.2e5 steps/s/process, 1.81e6 over 8 processes (BASELINE.md section 2)")
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
+    tools_profile_summary.py: 2*FETCH_SIZE + WRITE_SIZE, the gfx950 read-side correction of
+    MI355X_MICROARCH.md section HBM).  None when no profile of this kernel has been committed."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f).get(kernel)
+    except (OSError, ValueError):
+        return None
 
 
 def main():
@@ -130,7 +145,7 @@ def main():
         barrier()
         wall = time.perf_counter() - t0
         launches = K
-        kernel = "cge::snake::step_kernel<10>"
+        kernel = "cge::snake::step_kernel<10, 256, 1, 8>"
     else:
         env.rollout(max(W, 1), action_seed=123, t0=0)
         barrier()
@@ -141,10 +156,27 @@ def main():
         barrier()
         wall = time.perf_counter() - t0
         launches = 1
-        kernel = "cge::snake::rollout_kernel<10>"
+        kernel = "cge::snake::rollout_kernel<10, 256, 1, 8>"
     gpu_ms = ev0.elapsed_time(ev1)
     bad = env.invalid_action_count()
     assert bad == 0
+    fused = None
+    if args.path == "step":
+        # reported beside the headline, outside its timed region: the same K steps fused in one launch
+        # (state stays in registers; obs still written to HBM every step; device-side action hash)
+        env.rollout(max(W, 1), action_seed=123, t0=0)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        env.rollout(K, action_seed=123, t0=W)
+        e1.record()
+        torch.cuda.synchronize()
+        f_ms = e0.elapsed_time(e1)
+        f_ach = ALGO_BYTES[wl["env"]] * n * K / (f_ms * 1e-3) / 1e9
+        fused = {"path": "rollout (one launch, K fused steps)", "kernel": "cge::snake::rollout_kernel<10, 256, 1, 8>",
+                 "env_steps_per_s_per_gpu": n * K / (f_ms * 1e-3), "us_per_step": f_ms * 1e3 / K,
+                 "roofline": {"bound": "hbm", "achieved": f_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": f_ach / HBM_PEAK_GBS}}
 
     wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -166,10 +198,12 @@ def main():
             "config": {"workload": f"{args.workload}: {wl['desc']}", "envs_per_gpu": n, "path": args.path,
                        "autoreset": "SameStep", "parallelism": f"env-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kernel),
                          "algorithmic_bytes_per_env_step": algo, "env_steps_per_launch": units_per_launch,
                          "avg_launch_us": launch_s * 1e6, "timing": "HIP events on the launch stream over the timed region"},
         }
+        if fused is not None:
+            out["fused_rollout"] = fused
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_snake(wl["grid"])
         print(json.dumps(out), flush=True)

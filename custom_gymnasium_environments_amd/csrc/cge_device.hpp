@@ -155,6 +155,11 @@ __device__ __forceinline__ void andnot_word(uint32_t (&a)[W], uint32_t idx, uint
     for (int k = 0; k < W; ++k) a[k] &= (idx == (uint32_t)k) ? ~m : 0xffffffffu;
 }
 
+// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() also emits s_waitcnt vmcnt(0),
+// which would stall every wave until its global stores (the previous obs tile) are acknowledged and
+// until prefetched global loads land — exactly the latency the fused rollout is built to hide.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ------------------------------------------------------------------ obs tile -> HBM
 // Streams `bytes_valid` bytes (multiple of 4) of an LDS tile to `dst` with the widest stores the
 // destination alignment allows.  Must be called by every thread of the block after a barrier.

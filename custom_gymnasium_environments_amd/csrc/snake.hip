@@ -17,6 +17,7 @@
 // issued before the observation is staged so its latency hides behind that work.
 // The (N,G,G) int8 observation is built in LDS (one row per lane, dword stride G*G/4 — odd for
 // G=10, so conflict-free) and streamed out as 16-byte-per-lane stores.
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -33,7 +34,7 @@ constexpr int bitlen(int n) {
 }
 
 enum : uint32_t { F_NEEDS_RESET = 1u, F_BOARD_FULL = 2u, F_FOOD_VALID = 4u };
-constexpr int FOOD_WINDOW = 8;   // MT words fetched per round trip by _place_food (mean use: 3.2 for G=10)
+constexpr int FOOD_WINDOW = 8;   // default MT words fetched per round trip by _place_food (mean use: 3.2 for G=10)
 
 template <int G>
 struct Lay {
@@ -138,13 +139,14 @@ struct Env {
     // _randbelow(G): r = next_u32 >> (32-k), redrawn while r >= G; the pair is redrawn while it lies
     // on the snake.  `win` was loaded at the current cursor; a reload happens only if 8 words were
     // not enough (0.6 % of placements for G=10).
-    __device__ __forceinline__ void place_food(uint32_t *__restrict__ blk, MtWindow<FOOD_WINDOW> &win) {
+    template <int FW>
+    __device__ __forceinline__ void place_food(uint32_t *__restrict__ blk, MtWindow<FW> &win) {
         uint32_t phase = 0, row = 0;
         for (;;) {
             uint32_t used = 0;
             bool done = false;
 #pragma unroll
-            for (int j = 0; j < FOOD_WINDOW; ++j) {
+            for (int j = 0; j < FW; ++j) {
                 if (!done) {
                     const uint32_t r = win.draw(j, mt_pos, mt_pretw) >> (32 - L::KBITS);
                     used = j + 1;
@@ -251,7 +253,7 @@ struct Params {
 
 // One env transition with fused auto-reset.  Everything except the food draw happens first; the RNG
 // window load is issued, the obs body is staged while it is in flight, then the food is placed.
-template <int G>
+template <int G, int FW = FOOD_WINDOW>
 __device__ __forceinline__ void transition(Env<G> &e, const Params &p, int64_t i, uint32_t action, bool valid_action,
                                            uint32_t *__restrict__ obs_row, float &reward, bool &term) {
     using L = Lay<G>;
@@ -282,19 +284,19 @@ __device__ __forceinline__ void transition(Env<G> &e, const Params &p, int64_t i
         }
     }
     if (need_food) need_food = e.can_place_food();
-    MtWindow<FOOD_WINDOW> win;
+    MtWindow<FW> win;
     if (need_food) win.load(blk, e.mt_pos);
     if (obs_row) e.write_obs_body(obs_row);
     if (need_food) e.place_food(blk, win);
     if (obs_row) e.write_obs_food(obs_row);
 }
 
-template <int G>
-__global__ __launch_bounds__(Lay<G>::BLOCK) void step_kernel(Params p) {
+template <int G, int BLOCK, int MINW, int FW>
+__global__ __launch_bounds__(BLOCK, MINW) void step_kernel(Params p) {
     using L = Lay<G>;
-    __shared__ uint4 tile4[L::BLOCK * L::OBS_DW / 4];
+    __shared__ uint4 tile4[BLOCK * L::OBS_DW / 4];
     uint32_t *tile = reinterpret_cast<uint32_t *>(tile4);
-    const int64_t first = (int64_t)blockIdx.x * L::BLOCK;
+    const int64_t first = (int64_t)blockIdx.x * BLOCK;
     const int64_t i = first + threadIdx.x;
     if (i < p.n) {
         Env<G> e;
@@ -302,27 +304,27 @@ __global__ __launch_bounds__(Lay<G>::BLOCK) void step_kernel(Params p) {
         const int32_t a = p.actions[i];
         float r;
         bool term;
-        transition<G>(e, p, i, (uint32_t)a, (uint32_t)a <= 3u, tile + threadIdx.x * L::OBS_DW, r, term);
+        transition<G, FW>(e, p, i, (uint32_t)a, (uint32_t)a <= 3u, tile + threadIdx.x * L::OBS_DW, r, term);
         e.store(p.state, p.n, i);
         p.reward[i] = r;
         p.terminated[i] = term ? 1 : 0;
         if (p.truncated) p.truncated[i] = 0;   // reference never truncates (snake_env.py:119)
     }
-    __syncthreads();
-    const int64_t live = p.n - first < L::BLOCK ? p.n - first : L::BLOCK;
-    store_tile<L::BLOCK>(tile, p.obs + first * L::CELLS, (uint32_t)(live * L::CELLS));
+    lds_barrier();
+    const int64_t live = p.n - first < BLOCK ? p.n - first : BLOCK;
+    store_tile<BLOCK>(tile, p.obs + first * L::CELLS, (uint32_t)(live * L::CELLS));
 }
 
 // k fused steps per launch: state stays in VGPRs, only obs (+ optional explicit actions) touch HBM per step
-template <int G>
-__global__ __launch_bounds__(Lay<G>::BLOCK) void rollout_kernel(Params p) {
+template <int G, int BLOCK, int MINW, int FW>
+__global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
     using L = Lay<G>;
-    __shared__ uint4 tile4[L::BLOCK * L::OBS_DW / 4];
+    __shared__ uint4 tile4[BLOCK * L::OBS_DW / 4];
     uint32_t *tile = reinterpret_cast<uint32_t *>(tile4);
-    const int64_t first = (int64_t)blockIdx.x * L::BLOCK;
+    const int64_t first = (int64_t)blockIdx.x * BLOCK;
     const int64_t i = first + threadIdx.x;
     const bool live_lane = i < p.n;
-    const int64_t live = p.n - first < L::BLOCK ? p.n - first : L::BLOCK;
+    const int64_t live = p.n - first < BLOCK ? p.n - first : BLOCK;
     Env<G> e;
     uint64_t key = 0;
     float rsum = 0.0f;
@@ -332,20 +334,29 @@ __global__ __launch_bounds__(Lay<G>::BLOCK) void rollout_kernel(Params p) {
         key = hash_env_key(p.a_seed, (uint64_t)(p.env0 + i));
     }
     uint32_t *row = p.obs ? tile + threadIdx.x * L::OBS_DW : nullptr;
+    // explicit actions are fetched one step ahead so the load's latency hides behind the previous step
+    uint32_t a_next = (live_lane && p.actions && p.k_steps > 0) ? (uint32_t)p.actions[i] : 0u;
     for (int t = 0; t < p.k_steps; ++t) {
         if (live_lane) {
-            const uint32_t a = p.actions ? (uint32_t)p.actions[(int64_t)t * p.n + i]
-                                         : hash_action_from_key(key, (uint64_t)(p.t0 + t), 4u, 0u);
+            uint32_t a;
+            if (p.actions) {
+                a = a_next;
+                if (t + 1 < p.k_steps) a_next = (uint32_t)p.actions[(int64_t)(t + 1) * p.n + i];
+            } else {
+                a = hash_action_from_key(key, (uint64_t)(p.t0 + t), 4u, 0u);
+            }
             float r;
             bool term;
-            transition<G>(e, p, i, a, a <= 3u, row, r, term);
+            transition<G, FW>(e, p, i, a, a <= 3u, row, r, term);
             rsum += r;
             dcount += term ? 1 : 0;
+            if (p.reward) p.reward[(int64_t)t * p.n + i] = r;                   // optional [k, n] trajectories
+            if (p.terminated) p.terminated[(int64_t)t * p.n + i] = term ? 1 : 0;
         }
         if (p.obs) {
-            __syncthreads();
-            store_tile<L::BLOCK>(tile, p.obs + (int64_t)t * p.obs_step_stride + first * L::CELLS, (uint32_t)(live * L::CELLS));
-            __syncthreads();
+            lds_barrier();
+            store_tile<BLOCK>(tile, p.obs + (int64_t)t * p.obs_step_stride + first * L::CELLS, (uint32_t)(live * L::CELLS));
+            lds_barrier();
         }
     }
     if (live_lane) {
@@ -381,7 +392,7 @@ __global__ __launch_bounds__(Lay<G>::BLOCK) void reset_kernel(Params p) {
         if (doit) e.store(p.state, p.n, i);
     }
     if (p.obs) {
-        __syncthreads();
+        lds_barrier();
         const int64_t live = p.n - first < L::BLOCK ? p.n - first : L::BLOCK;
         store_tile<L::BLOCK>(tile, p.obs + first * L::CELLS, (uint32_t)(live * L::CELLS));
     }
@@ -486,6 +497,17 @@ void encode_env(const int32_t *hdr, const uint16_t *body, uint32_t *raw) {
     e.pack(raw);
 }
 
+template <int G, int BLOCK, int MINW, int FW>
+void set_variant(Ops &o) {
+    o.block = BLOCK;
+    o.step = [](const Params &p, hipStream_t s) {
+        hipLaunchKernelGGL((step_kernel<G, BLOCK, MINW, FW>), dim3((unsigned)((p.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, p);
+    };
+    o.rollout = [](const Params &p, hipStream_t s) {
+        hipLaunchKernelGGL((rollout_kernel<G, BLOCK, MINW, FW>), dim3((unsigned)((p.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, p);
+    };
+}
+
 template <int G>
 Ops make_ops() {
     using L = Lay<G>;
@@ -494,12 +516,7 @@ Ops make_ops() {
     o.rewind = [](uint4 *st, int64_t n, hipStream_t s) {
         hipLaunchKernelGGL(rewind_kernel<G>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st, n);
     };
-    o.step = [](const Params &p, hipStream_t s) {
-        hipLaunchKernelGGL(step_kernel<G>, dim3((unsigned)((p.n + L::BLOCK - 1) / L::BLOCK)), dim3(L::BLOCK), 0, s, p);
-    };
-    o.rollout = [](const Params &p, hipStream_t s) {
-        hipLaunchKernelGGL(rollout_kernel<G>, dim3((unsigned)((p.n + L::BLOCK - 1) / L::BLOCK)), dim3(L::BLOCK), 0, s, p);
-    };
+    set_variant<G, L::BLOCK, 1, FOOD_WINDOW>(o);
     o.reset = [](const Params &p, hipStream_t s) {
         hipLaunchKernelGGL(reset_kernel<G>, dim3((unsigned)((p.n + L::BLOCK - 1) / L::BLOCK)), dim3(L::BLOCK), 0, s, p);
     };
@@ -515,7 +532,19 @@ static bool ops_for(int grid, Ops &o) {
     switch (grid) {
         case 6: o = make_ops<6>(); return true;
         case 8: o = make_ops<8>(); return true;
-        case 10: o = make_ops<10>(); return true;
+        case 10: {
+            o = make_ops<10>();
+            // tuning variants of the benchmark grid, selectable for A/B runs (default = best measured)
+            const char *v = getenv("CGE_SNAKE_VARIANT");
+            const int k = v ? atoi(v) : 0;
+            if (k == 1) set_variant<10, 256, 6, 8>(o);
+            else if (k == 2) set_variant<10, 128, 1, 8>(o);
+            else if (k == 3) set_variant<10, 64, 1, 8>(o);
+            else if (k == 4) set_variant<10, 256, 6, 6>(o);
+            else if (k == 5) set_variant<10, 128, 6, 6>(o);
+            else if (k == 6) set_variant<10, 64, 6, 6>(o);
+            return true;
+        }
         case 12: o = make_ops<12>(); return true;
         case 16: o = make_ops<16>(); return true;
         case 20: o = make_ops<20>(); return true;
@@ -643,7 +672,8 @@ int cge_snake_step(cge_snake *h, const int32_t *actions, int8_t *obs_out, float 
 }
 
 int cge_snake_rollout(cge_snake *h, int32_t k_steps, const int32_t *actions, uint64_t action_seed, int64_t t0,
-                      int8_t *obs_out, int64_t obs_step_stride, float *reward_sum_out, int32_t *done_count_out, void *stream) {
+                      int8_t *obs_out, int64_t obs_step_stride, float *reward_traj_out, uint8_t *terminated_traj_out,
+                      float *reward_sum_out, int32_t *done_count_out, void *stream) {
     if (!h) return CGE_ERR_INVALID_ARG;
     if (k_steps < 0 || obs_step_stride < 0 || (obs_step_stride != 0 && obs_step_stride < h->n * h->ops.cells) ||
         (obs_step_stride & 3))
@@ -653,6 +683,7 @@ int cge_snake_rollout(cge_snake *h, int32_t k_steps, const int32_t *actions, uin
     snake::Params p = h->params();
     p.k_steps = k_steps; p.actions = actions; p.a_seed = action_seed; p.t0 = t0;
     p.obs = obs_out; p.obs_step_stride = obs_step_stride;
+    p.reward = reward_traj_out; p.terminated = terminated_traj_out;
     p.reward_sum = reward_sum_out; p.done_count = done_count_out;
     h->ops.rollout(p, as_stream(stream));
     CGE_TRY(h, hipGetLastError());

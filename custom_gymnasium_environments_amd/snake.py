@@ -91,10 +91,11 @@ class SnakeVectorEnv(DeviceVectorEnv):
         return t
 
     # ------------------------------------------------------------------ extras
-    def rollout(self, k_steps, actions=None, action_seed=0, t0=0, trajectory=False, want_obs=True):
+    def rollout(self, k_steps, actions=None, action_seed=0, t0=0, trajectory=False, want_obs=True, per_step=False):
         """k fused step()s in one launch (state stays in registers).  actions: None -> counter-hash
         random actions (cge_hash_action) or an int32 [k, N] tensor.  Returns (obs, reward_sum, done_count)
-        with obs of shape [k, N, G, G] if trajectory else the last step's [N, G, G]."""
+        with obs of shape [k, N, G, G] if trajectory else the last step's [N, G, G]; with per_step=True
+        returns (obs, reward[k, N], terminated[k, N], reward_sum, done_count) — the outputs of k step() calls."""
         k = int(k_steps)
         a = None if actions is None else self._as_device(actions, torch.int32, (k, self.num_envs), "actions")
         obs = None
@@ -107,9 +108,16 @@ class SnakeVectorEnv(DeviceVectorEnv):
                 obs = self._out("obs", self._obs_shape, torch.int8)
         rs = self._out("reward_sum", (self.num_envs,), torch.float32)
         dc = self._out("done_count", (self.num_envs,), torch.int32)
+        rt = tt = None
+        if per_step:
+            rt = self._out("reward_traj", (k, self.num_envs), torch.float32)
+            tt = self._out("terminated_traj", (k, self.num_envs), torch.bool)
         self._check(self._lib.cge_snake_rollout(self._h, k, a.data_ptr() if a is not None else None, int(action_seed),
                                                 int(t0), obs.data_ptr() if obs is not None else None, stride,
+                                                rt.data_ptr() if per_step else None, tt.data_ptr() if per_step else None,
                                                 rs.data_ptr(), dc.data_ptr(), self._stream()), "rollout")
+        if per_step:
+            return obs, rt, tt, rs, dc
         return obs, rs, dc
 
     def info(self, field):

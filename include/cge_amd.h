@@ -102,13 +102,16 @@ int cge_snake_reset(cge_snake *h, const uint8_t *mask, int8_t *obs_out, void *st
 int cge_snake_step(cge_snake *h, const int32_t *actions, int8_t *obs_out, float *reward_out,
                    uint8_t *terminated_out, uint8_t *truncated_out /*nullable: always 0, snake_env.py:119*/,
                    int8_t *final_obs_out /*nullable*/, void *stream);
-/* k_steps fused step()s in ONE launch.  actions: [k_steps, n_envs] int32 or NULL -> cge_hash_action(
- * action_seed, env_index0+i, t0+t, 4, 0).  obs_out: one [n_envs,G,G] buffer rewritten every step
- * (obs_step_stride = 0) or a trajectory buffer [k_steps, n_envs, G, G] (obs_step_stride = n_envs*G*G);
+/* k_steps fused step()s in ONE launch (env state stays in registers between steps).  actions:
+ * [k_steps, n_envs] int32 or NULL -> cge_hash_action(action_seed, env_index0+i, t0+t, 4, 0).  obs_out
+ * (nullable): one [n_envs,G,G] buffer rewritten every step (obs_step_stride = 0) or a trajectory buffer
+ * [k_steps, n_envs, G, G] (obs_step_stride = n_envs*G*G).  reward_traj_out / terminated_traj_out
+ * (nullable): per-step [k_steps, n_envs] outputs, i.e. exactly what k step() calls would return;
  * reward_sum_out / done_count_out (nullable) accumulate per env over the k steps. */
 int cge_snake_rollout(cge_snake *h, int32_t k_steps, const int32_t *actions, uint64_t action_seed, int64_t t0,
-                      int8_t *obs_out, int64_t obs_step_stride, float *reward_sum_out,
-                      int32_t *done_count_out, void *stream);
+                      int8_t *obs_out, int64_t obs_step_stride, float *reward_traj_out,
+                      uint8_t *terminated_traj_out, float *reward_sum_out, int32_t *done_count_out,
+                      void *stream);
 int cge_snake_info(cge_snake *h, int32_t field_id, int32_t *out, void *stream);
 /* canonical per-env state record (host memory), identical to the oracle's: 8 int32 {len, dir, food_r,
  * food_c, score, steps, needs_reset, mt_idx}, uint32 mt[624] (CPython layout: words >= mt_idx are

@@ -106,11 +106,12 @@ def test_rollout_matches_oracle_and_step_path(cge, oracle):
     twin = cge.SnakeVectorEnv(n, grid_size=grid, autoreset_mode="SameStep", env_index0=1000)
     twin.set_state(env.get_state())
     acts = torch.randint(0, 4, (50, n), dtype=torch.int32, device="cuda")
-    traj, rs, dc = env.rollout(50, actions=acts, trajectory=True)
+    traj, rt, tt, rs, dc = env.rollout(50, actions=acts, trajectory=True, per_step=True)
     rsum = torch.zeros(n, device="cuda")
     for t in range(50):
         ob, r, te, tr, _ = twin.step(acts[t])
         assert torch.equal(ob, traj[t]), t
+        assert torch.equal(r, rt[t]) and torch.equal(te, tt[t]), t
         rsum += r
     assert torch.equal(rsum, rs)
     env.close(); twin.close()

@@ -1,0 +1,67 @@
+"""A/B timing of snake kernel variants in ONE process (interleaved rounds, HIP-event timed).
+usage: python tools_ab.py [variant ids ...]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import custom_gymnasium_environments_amd as cge
+
+N = 1 << 20
+variants = [int(v) for v in sys.argv[1:]] or [0, 1, 2, 3, 4, 5, 6]
+envs = {}
+for v in variants:
+    os.environ["CGE_SNAKE_VARIANT"] = str(v)
+    e = cge.SnakeVectorEnv(N, grid_size=10, autoreset_mode=os.environ.get("AB_MODE", "SameStep"), reuse_buffers=True)
+    e.reset(seed=0)
+    e.rollout(30, action_seed=1)          # decorrelate episode phases
+    envs[v] = e
+K = 100
+acts = torch.randint(0, 4, (K, N), dtype=torch.int32, device="cuda")
+CH = 25
+res = {v: {"step": [], "roll": [], "roll_traj": []} for v in variants}
+for rnd in range(4):
+    for v in variants:
+        e = envs[v]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        for t in range(5):
+            e.step(acts[t])
+        ev[0].record()
+        import time as _t
+        h0 = _t.perf_counter()
+        for t in range(K):
+            e.step(acts[t])
+        host_us = (_t.perf_counter() - h0) / K * 1e6
+        ev[1].record()
+        res[v].setdefault("host_step", []).append(host_us)
+        e.rollout(5, action_seed=3)
+        ev[2].record()
+        e.rollout(K, action_seed=3, t0=5)
+        ev[3].record()
+        ev6, ev7, ev8 = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev6.record()
+        for c in range(K // CH):
+            e.rollout(CH, action_seed=9, t0=c * CH, trajectory=True)          # hash actions + trajectory obs
+        ev7.record()
+        for c in range(K // CH):
+            e.rollout(CH, actions=acts[c * CH:(c + 1) * CH])                   # explicit actions, single obs buffer
+        ev8.record()
+        e.rollout(CH, actions=acts[:CH], trajectory=True, per_step=True)
+        ev[4].record()
+        for c in range(K // CH):
+            e.rollout(CH, actions=acts[c * CH:(c + 1) * CH], trajectory=True, per_step=True)
+        ev[5].record()
+        torch.cuda.synchronize()
+        res[v]["step"].append(ev[0].elapsed_time(ev[1]) / K * 1e3)
+        res[v]["roll"].append(ev[2].elapsed_time(ev[3]) / K * 1e3)
+        res[v]["roll_traj"].append(ev[4].elapsed_time(ev[5]) / K * 1e3)
+        res[v].setdefault("roll_hash_traj", []).append(ev6.elapsed_time(ev7) / K * 1e3)
+        res[v].setdefault("roll_acts_1buf", []).append(ev7.elapsed_time(ev8) / K * 1e3)
+print("variant: us per 1M-env step (min / median over rounds)")
+for v in variants:
+    out = []
+    for k in ["step", "host_step", "roll", "roll_hash_traj", "roll_acts_1buf", "roll_traj"]:
+        x = sorted(res[v][k])
+        out.append(f"{k} {x[0]:.1f}/{x[len(x)//2]:.1f}")
+    print(v, "  ".join(out))
