@@ -76,6 +76,17 @@ def _declare(L):
     L.orc_snake_get_state.argtypes = [vp, vp]
     L.orc_snake_set_state.argtypes = [vp, vp]
 
+    L.orc_crypto_create.argtypes = [i64, i32, i32]; L.orc_crypto_create.restype = vp
+    L.orc_crypto_destroy.argtypes = [vp]
+    L.orc_crypto_seed.argtypes = [vp, vp]
+    L.orc_crypto_reset.argtypes = [vp, vp, vp]
+    L.orc_crypto_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]; L.orc_crypto_step.restype = i32
+    L.orc_crypto_rollout.argtypes = [vp, i32, u64, i64, i64, vp, vp, vp]
+    L.orc_crypto_info.argtypes = [vp, i32, vp]
+    L.orc_crypto_state_bytes.argtypes = []; L.orc_crypto_state_bytes.restype = C.c_size_t
+    L.orc_crypto_get_state.argtypes = [vp, vp]
+    L.orc_crypto_set_state.argtypes = [vp, vp]
+
 
 NEXT_STEP, SAME_STEP, DISABLED = 0, 1, 2
 
@@ -170,3 +181,76 @@ class SnakeOracle:
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
         assert buf.shape == (self.n, lib().orc_snake_state_bytes(self.h))
         lib().orc_snake_set_state(self.h, _p(buf))
+
+
+CRYPTO_OBS = 261
+CRYPTO_INFO = {"portfolio_value": 0, "cash": 1, "holdings": 2, "current_price": 3, "market_psychology": 4,
+               "regime": 5, "step": 6, "trend_strength": 7, "episodes": 8, "needs_reset": 9, "cash_kind": 10}
+
+
+class CryptoOracle:
+    """Batch of independent CryptoTradingEnv restatements (oracle/orc_crypto.c)."""
+
+    def __init__(self, n, action_type="discrete", mode=SAME_STEP):
+        self.n, self.mode = int(n), int(mode)
+        self.continuous = action_type == "continuous"
+        self.h = lib().orc_crypto_create(self.n, int(self.continuous), self.mode)
+        if not self.h:
+            raise ValueError("orc_crypto_create failed")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_crypto_destroy(self.h)
+            self.h = None
+
+    def seed(self, seeds):
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        assert seeds.shape == (self.n,)
+        lib().orc_crypto_seed(self.h, _p(seeds))
+
+    def reset(self, mask=None):
+        obs = np.zeros((self.n, CRYPTO_OBS), np.float32)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        lib().orc_crypto_reset(self.h, _p(m), _p(obs))
+        return obs
+
+    def step(self, actions, want_final=False):
+        if self.continuous:
+            a = np.ascontiguousarray(actions, dtype=np.float32)
+            assert a.shape == (self.n, 2)
+        else:
+            a = np.ascontiguousarray(actions, dtype=np.int32)
+            assert a.shape == (self.n,)
+        obs = np.zeros((self.n, CRYPTO_OBS), np.float32)
+        rew = np.zeros(self.n, np.float32)
+        rew64 = np.zeros(self.n, np.float64)
+        te = np.zeros(self.n, np.uint8)
+        tr = np.zeros(self.n, np.uint8)
+        fin = np.zeros_like(obs) if want_final else None
+        bad = lib().orc_crypto_step(self.h, _p(a), _p(obs), _p(rew), _p(rew64), _p(te), _p(tr), _p(fin))
+        if bad:
+            raise ValueError(f"Invalid action in {bad} env(s)")
+        self.last_reward64 = rew64
+        return (obs, rew, te, tr, fin) if want_final else (obs, rew, te, tr)
+
+    def rollout(self, k, a_seed, t0=0, env0=0, want_obs=True):
+        obs = np.zeros((self.n, CRYPTO_OBS), np.float32) if want_obs else None
+        rs = np.zeros(self.n, np.float64)
+        dc = np.zeros(self.n, np.int32)
+        lib().orc_crypto_rollout(self.h, k, a_seed, t0, env0, _p(obs), _p(rs), _p(dc))
+        return obs, rs, dc
+
+    def info(self, field):
+        out = np.zeros(self.n, np.float64)
+        lib().orc_crypto_info(self.h, CRYPTO_INFO[field] if isinstance(field, str) else field, _p(out))
+        return out
+
+    def get_state(self):
+        buf = np.zeros((self.n, lib().orc_crypto_state_bytes()), np.uint8)
+        lib().orc_crypto_get_state(self.h, _p(buf))
+        return buf
+
+    def set_state(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        assert buf.shape == (self.n, lib().orc_crypto_state_bytes())
+        lib().orc_crypto_set_state(self.h, _p(buf))
