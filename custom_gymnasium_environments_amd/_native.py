@@ -24,6 +24,13 @@ class SnakeConfig(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class CryptoConfig(C.Structure):
+    _fields_ = [("initial_balance", C.c_double), ("trading_fee_rate", C.c_double), ("slippage_rate", C.c_double),
+                ("min_price", C.c_double), ("max_price", C.c_double), ("volatility_base", C.c_double),
+                ("market_psychology_factor", C.c_double), ("max_steps", C.c_int32), ("action_type", C.c_int32),
+                ("autoreset_mode", C.c_int32), ("reserved", C.c_int32)]
+
+
 # name -> (restype, argtypes); also the list tests check against include/cge_amd.h
 _vp, _i32, _i64, _u32, _u64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_size_t
 SIGNATURES = {
@@ -42,6 +49,19 @@ SIGNATURES = {
     "cge_snake_error_count": (_i64, [_vp, _vp]),
     "cge_snake_device_bytes": (_sz, [_vp]),
     "cge_snake_last_error": (C.c_char_p, [_vp]),
+    "cge_crypto_default_config": (None, [C.POINTER(CryptoConfig)]),
+    "cge_crypto_create": (C.c_int, [C.POINTER(CryptoConfig), _i64, C.c_int, _i64, C.POINTER(_vp)]),
+    "cge_crypto_destroy": (C.c_int, [_vp]),
+    "cge_crypto_seed": (C.c_int, [_vp, _vp, _u64, _vp]),
+    "cge_crypto_reset": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "cge_crypto_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cge_crypto_rollout": (C.c_int, [_vp, _i32, _vp, _u64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "cge_crypto_info": (C.c_int, [_vp, _i32, _vp, _vp]),
+    "cge_crypto_state_bytes": (_sz, [_vp]),
+    "cge_crypto_get_state": (C.c_int, [_vp, _vp, _vp]),
+    "cge_crypto_set_state": (C.c_int, [_vp, _vp, _vp]),
+    "cge_crypto_device_bytes": (_sz, [_vp]),
+    "cge_crypto_last_error": (C.c_char_p, [_vp]),
 }
 
 _lib = None

@@ -1,0 +1,854 @@
+// crypto.hip — batched CryptoTradingEnv for MI355X (gfx950): kernels + C ABI (include/cge_amd.h).
+//
+// Re-expresses /root/reference/crypto_trading_env/crypto_trading_env.py for N independent instances,
+// one lane per env:  MarketSimulator.generate_next_price :132-164, _update_market_regime :166-186,
+// reset :301-340, step :342-398, _execute_action/_buy/_sell :400-503, _get_observation :505-561 with
+// TechnicalIndicators rsi :45-61, bollinger_bands :64-76, macd/_ema :79-119.
+//
+// Numerics: every state quantity the reference keeps in float64 is float64 here, evaluated in the
+// reference's operation order with contraction off, so trajectories track the CPU bit for bit except
+// where a libm result differs in its last place (device log in the polar-method gauss).  NumPy's
+// pairwise summation order is reproduced for np.mean / np.std.  The observation is cast to float32 at
+// the end, as np.array(obs, dtype=np.float32) does; the 250 history ratios are computed as
+// x * (1/close) in float64 (differs from x/close by < 1e-16 relative, i.e. at most one float32 ulp
+// once in ~5e8 values) and O/H/L/V history is stored in float32.
+//
+// HBM layout (per env): 64 B of scalars in four uint4 columns (SoA), 50 closes as float64
+// `closes[slot][env]` and 50 {open,high,low,volume} float4 `ohlv[slot][env]`, two MT19937 blocks.
+// The 50-candle window is a ring whose phase is the SAME for every env of a handle (each step()
+// appends exactly one candle; a reset rewrites all 50 slots and adopts the batch phase), so slot
+// indices are wave-uniform and every history access is a coalesced 8- or 16-byte-per-lane stream.
+// Dominant traffic per env-step: 1200 B history read + 1044 B obs write (+ 24 B new candle, 128 B
+// scalars, RNG windows) — HBM-bound, no reuse, no MFMA-shaped work.
+//
+// The (N,261) float32 obs is a per-env scaled transpose of the SoA history: each wave stages 10
+// candles x 64 envs in LDS (row stride 51 dwords -> conflict-free) and streams the 200-byte row
+// segments out with fully used 256-byte store instructions.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "cge_device.hpp"
+#include "cge_host.hpp"
+
+namespace cge {
+namespace crypto {
+
+constexpr int HLEN = 50;
+constexpr int OBS = 261;
+constexpr int CH = 10;            // candles per staged chunk
+constexpr int ROW = CH * 5 + 1;   // LDS row stride (dwords), odd
+constexpr int WP = 10;            // P window: trade slippage + volume + regime test + high + low = 5 doubles
+constexpr int WL = 8;             // L window: two polar-method attempts
+constexpr int BLOCK = 64;
+enum { BULL = 0, BEAR = 1, SIDEWAYS = 2, CRASH = 3, RECOVERY = 4 };
+
+struct Cfg {
+    double initial_balance, fee, slip, minp, maxp, volb, psyf;
+    int32_t max_steps, continuous;
+};
+
+struct Params {
+    uint4 *scal;          // [4][n]
+    double *closes;       // [50][n]
+    float4 *ohlv;         // [50][n]
+    uint32_t *mtP, *mtL;  // [n][MT_STRIDE]
+    int64_t n, env0;
+    Cfg cfg;
+    int32_t mode, phase;  // phase: slot of the OLDEST candle (= where the next one is written)
+    const void *actions;
+    const uint8_t *mask;
+    float *obs, *final_obs;
+    float *reward;
+    uint8_t *terminated, *truncated;
+    int32_t k_steps;
+    uint64_t a_seed;
+    int64_t t0, obs_step_stride;
+    double *reward_sum;
+    int32_t *done_count;
+};
+
+__device__ __forceinline__ double mk_double(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
+__device__ __forceinline__ double u53(uint32_t a, uint32_t b) { return ((a >> 5) * 67108864.0 + (b >> 6)) / 9007199254740992.0; }
+__device__ __forceinline__ double clipd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+struct Env {
+    double cash, holdings, close, psych, trend, gauss;
+    uint32_t step, regime, has_gauss, cash_kind, needs_reset, episodes;
+    uint32_t ppos, ppretw, lpos, lpretw;
+
+    __device__ __forceinline__ void load(const uint4 *__restrict__ s, int64_t n, int64_t i) {
+        const uint4 a = s[i], b = s[n + i], c = s[2 * n + i], d = s[3 * n + i];
+        cash = mk_double(a.x, a.y); holdings = mk_double(a.z, a.w);
+        close = mk_double(b.x, b.y); psych = mk_double(b.z, b.w);
+        trend = mk_double(c.x, c.y); gauss = mk_double(c.z, c.w);
+        step = d.x & 0xffffu; regime = (d.x >> 16) & 7u; has_gauss = (d.x >> 19) & 1u;
+        cash_kind = (d.x >> 20) & 3u; needs_reset = (d.x >> 22) & 1u;
+        ppos = d.y & 1023u; ppretw = (d.y & 1024u) ? (uint32_t)MT_N : 0u;
+        lpos = (d.y >> 11) & 1023u; lpretw = (d.y & (1u << 21)) ? (uint32_t)MT_N : 0u;
+        episodes = d.z;
+    }
+    __device__ __forceinline__ void store(uint4 *__restrict__ s, int64_t n, int64_t i) const {
+        s[i] = make_uint4((uint32_t)__double2loint(cash), (uint32_t)__double2hiint(cash),
+                          (uint32_t)__double2loint(holdings), (uint32_t)__double2hiint(holdings));
+        s[n + i] = make_uint4((uint32_t)__double2loint(close), (uint32_t)__double2hiint(close),
+                              (uint32_t)__double2loint(psych), (uint32_t)__double2hiint(psych));
+        s[2 * n + i] = make_uint4((uint32_t)__double2loint(trend), (uint32_t)__double2hiint(trend),
+                                  (uint32_t)__double2loint(gauss), (uint32_t)__double2hiint(gauss));
+        s[3 * n + i] = make_uint4(step | (regime << 16) | (has_gauss << 19) | (cash_kind << 20) | (needs_reset << 22),
+                                  ppos | (ppretw ? 1024u : 0u) | (lpos << 11) | (lpretw ? (1u << 21) : 0u), episodes, 0u);
+    }
+};
+
+__device__ __forceinline__ double vol_mult(uint32_t r) { return r == BULL ? 1.2 : r == BEAR ? 1.5 : r == SIDEWAYS ? 0.8 : r == CRASH ? 3.0 : 2.0; }       // :190-196
+__device__ __forceinline__ double base_trend(uint32_t r) { return r == BULL ? 0.001 : r == BEAR ? -0.001 : r == SIDEWAYS ? 0.0 : r == CRASH ? -0.005 : 0.002; }   // :202-208
+
+// _update_market_regime :166-186, draws from the serial P stream (1 % of steps)
+__device__ __forceinline__ void update_regime(Env &e, MtStream &sp) {
+    const uint32_t pick = sp.randbelow(2u, 2);   // random.choice of the two successors
+    const uint32_t r = e.regime;
+    const uint32_t nx0 = r == BULL ? SIDEWAYS : r == BEAR ? SIDEWAYS : r == SIDEWAYS ? BULL : r == CRASH ? RECOVERY : BULL;
+    const uint32_t nx1 = r == BULL ? CRASH : r == BEAR ? RECOVERY : r == SIDEWAYS ? BEAR : r == CRASH ? BEAR : SIDEWAYS;
+    e.regime = pick ? nx1 : nx0;
+    const double u = sp.random53();
+    if (e.regime == BULL || e.regime == RECOVERY) e.trend = 0.5 + (1.0 - 0.5) * u;
+    else if (e.regime == BEAR || e.regime == CRASH) e.trend = -1.0 + (-0.5 - -1.0) * u;
+    else e.trend = -0.2 + (0.2 - -0.2) * u;
+}
+
+// legacy_gauss (polar method) from the serial L stream
+__device__ __forceinline__ double gauss_serial(Env &e, MtStream &sl) {
+    if (e.has_gauss) {
+        e.has_gauss = 0;
+        const double g = e.gauss;
+        e.gauss = 0.0;
+        return g;
+    }
+    double x1, x2, r2;
+    do {
+        x1 = 2.0 * sl.random53() - 1.0;
+        x2 = 2.0 * sl.random53() - 1.0;
+        r2 = x1 * x1 + x2 * x2;
+    } while (r2 >= 1.0 || r2 == 0.0);
+    const double f = sqrt(-2.0 * log(r2) / r2);
+    e.gauss = f * x1;
+    e.has_gauss = 1;
+    return f * x2;
+}
+
+// generate_next_price :132-164 after the regime test, given this step's gaussian
+__device__ __forceinline__ double price_update(Env &e, const Cfg &c, double current, double volume, double g) {
+    const double volatility = c.volb * vol_mult(e.regime);
+    const double drift = (e.psych - 0.5) * c.psyf;
+    const double trend = base_trend(e.regime) * e.trend;
+    const double rc = 0.0 + volatility * g;                       // np.random.normal(0, volatility)
+    const double vf = 1.0 / (1.0 + volume * 0.1);
+    const double pct = (trend + drift + rc) * vf;
+    const double np_ = clipd(current * (1.0 + pct), c.minp, c.maxp);
+    e.psych += pct * 10.0;                                        // :213-221
+    e.psych = clipd(e.psych, 0.0, 1.0);
+    e.psych += (0.5 - e.psych) * 0.01;
+    return np_;
+}
+
+// reset :301-340 — rare (once per episode), every draw through the serial streams.  Candle k of the
+// fresh history goes to slot (phase + k) % 50: the env adopts the batch-wide ring phase.
+__device__ __forceinline__ void do_reset(Env &e, const Params &p, int64_t i, int phase) {
+    MtStream sp(p.mtP + i * MT_STRIDE, e.ppos, e.ppretw), sl(p.mtL + i * MT_STRIDE, e.lpos, e.lpretw);
+    e.cash = p.cfg.initial_balance;
+    e.cash_kind = 0;
+    e.holdings = 0.0;
+    e.step = 0;
+    e.needs_reset = 0;
+    double price = 50000.0;
+    int slot = phase;
+#pragma unroll 1
+    for (int k = 0; k < HLEN; ++k) {
+        const double volume = 0.5 + (2.0 - 0.5) * sp.random53();
+        if (sp.random53() < 0.01) update_regime(e, sp);
+        const double g = gauss_serial(e, sl);
+        price = price_update(e, p.cfg, price, volume, g);
+        const double hi = price * (1.0 + (1.02 - 1.0) * sp.random53());
+        const double lo = price * (0.98 + (1.0 - 0.98) * sp.random53());
+        const double op = price * (0.99 + (1.01 - 0.99) * sp.random53());
+        p.closes[(int64_t)slot * p.n + i] = price;
+        p.ohlv[(int64_t)slot * p.n + i] = make_float4((float)op, (float)hi, (float)lo, (float)volume);
+        slot = slot + 1 == HLEN ? 0 : slot + 1;
+    }
+    e.close = price;
+    e.ppos = sp.pos; e.ppretw = sp.pretw; e.lpos = sl.pos; e.lpretw = sl.pretw;
+}
+
+// _execute_buy :449-476.  amount_f32: NumPy>=2 keeps np.float32 amounts in continuous mode (NEP 50)
+__device__ __forceinline__ bool buy_guard(const Env &e, double amount, bool amount_f32) {
+    if (amount_f32) return !((float)amount <= 0.0f || (float)e.cash < (float)amount);
+    return !(amount <= 0.0 || e.cash < amount);
+}
+__device__ __forceinline__ void buy_apply(Env &e, const Cfg &c, double amount, bool amount_f32, double price, double u) {
+    const double slippage = price * c.slip * (0.5 + (1.5 - 0.5) * u);
+    const double eff = price + slippage;
+    if (amount_f32) {
+        const float a = (float)amount;
+        const float fee = a * (float)c.fee;
+        const float net = a - fee;
+        const double bought = (double)net / eff;
+        e.cash = (double)((float)e.cash - a);
+        e.cash_kind = 1;
+        e.holdings += bought;
+    } else {
+        const double fee = amount * c.fee;
+        const double net = amount - fee;
+        e.cash -= amount;
+        e.holdings += net / eff;
+    }
+}
+__device__ __forceinline__ void sell_apply(Env &e, const Cfg &c, double qty, double price, double u) {   // :478-503
+    const double slippage = price * c.slip * (0.5 + (1.5 - 0.5) * u);
+    const double eff = price - slippage;
+    const double received = qty * eff;
+    const double fee = received * c.fee;
+    e.holdings -= qty;
+    e.cash += received - fee;
+    if (c.continuous) e.cash_kind = 2;
+}
+
+// One reference step() (:342-398) for one env; writes the new candle into slot `phase`.
+// Returns terminated; reward in float64.
+__device__ __forceinline__ bool env_step(Env &e, const Params &p, int64_t i, int phase, int32_t a_disc, float a_buy, float a_sell,
+                                         double &reward) {
+    const Cfg &c = p.cfg;
+    uint32_t *__restrict__ blkP = p.mtP + i * MT_STRIDE;
+    uint32_t *__restrict__ blkL = p.mtL + i * MT_STRIDE;
+    MtWindow<WP> wp;
+    wp.load(blkP, e.ppos);
+    MtWindow<WL> wl;
+    const bool need_l = !e.has_gauss;
+    if (need_l) wl.load(blkL, e.lpos);
+
+    // ---- _execute_action :400-447
+    const double price = e.close;
+    const double pv0 = e.cash + e.holdings * price;
+    int kind = 0;   // 0 none, 1 buy, 2 sell
+    double amount = 0.0;
+    bool amount_f32 = false;
+    if (c.continuous) {
+        const float b = a_buy < 0.0f ? 0.0f : (a_buy > 1.0f ? 1.0f : a_buy);
+        const float s = a_sell < 0.0f ? 0.0f : (a_sell > 1.0f ? 1.0f : a_sell);
+        double buy;
+        bool bf = true;
+        if (e.cash_kind == 0) buy = (double)(b * (float)(e.cash * 0.1));
+        else if (e.cash_kind == 1) buy = (double)(b * ((float)e.cash * 0.1f));
+        else { buy = (double)b * (e.cash * 0.1); bf = false; }
+        const double sell = (double)s * (e.holdings * 0.1);
+        if (buy > sell && buy > 0.0) { kind = 1; amount = buy; amount_f32 = bf; }
+        else if (sell > 0.0) { kind = 2; amount = sell; }
+    } else {
+        if (a_disc == 1) { kind = 1; amount = e.cash * 0.05; }
+        else if (a_disc == 2) { kind = 1; amount = e.cash * 0.2; }
+        else if (a_disc == 3) { kind = 2; amount = e.holdings * 0.05; }
+        else if (a_disc == 4) { kind = 2; amount = e.holdings * 0.2; }
+    }
+    bool traded = false;
+    if (kind == 1) traded = buy_guard(e, amount, amount_f32);
+    else if (kind == 2) traded = !(amount <= 0.0 || e.holdings < amount);
+
+    // ---- P draws of the common path, all from the window: [slippage] volume regime-test high low
+    double U[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) U[q] = u53(wp.draw(2 * q, e.ppos, e.ppretw), wp.draw(2 * q + 1, e.ppos, e.ppretw));
+    if (traded) {
+        if (kind == 1) buy_apply(e, c, amount, amount_f32, price, U[0]);
+        else sell_apply(e, c, amount, price, U[0]);
+    }
+    const double pv1 = e.cash + e.holdings * price;
+    reward = pv1 - pv0;                                           // :440-441
+    if (!traded) reward -= 1.0;                                   // :444-445
+    const double volume = 0.5 + (2.0 - 0.5) * (traded ? U[1] : U[0]);     // :349
+    const double ureg = traded ? U[2] : U[1];
+    const uint32_t tq = traded ? 1u : 0u;
+    const bool regime_switch = ureg < 0.01;                       // :135
+    double u_hi = traded ? U[3] : U[2], u_lo = traded ? U[4] : U[3];
+    if (regime_switch) {
+        // rare: persist the window up to the regime test, continue on the serial stream
+        wp.commit(blkP, e.ppos, e.ppretw, 2u * (tq + 2u));
+        MtStream sp(blkP, e.ppos, e.ppretw);
+        update_regime(e, sp);
+        u_hi = sp.random53();
+        u_lo = sp.random53();
+        e.ppos = sp.pos; e.ppretw = sp.pretw;
+    } else {
+        wp.commit(blkP, e.ppos, e.ppretw, 2u * (tq + 4u));
+    }
+    // ---- gaussian (family L): cached half, or up to two polar attempts from the window, else serial
+    double g;
+    if (e.has_gauss) {
+        e.has_gauss = 0;
+        g = e.gauss;
+        e.gauss = 0.0;
+    } else {
+        double x1 = 2.0 * u53(wl.draw(0, e.lpos, e.lpretw), wl.draw(1, e.lpos, e.lpretw)) - 1.0;
+        double x2 = 2.0 * u53(wl.draw(2, e.lpos, e.lpretw), wl.draw(3, e.lpos, e.lpretw)) - 1.0;
+        double r2 = x1 * x1 + x2 * x2;
+        uint32_t used = 4;
+        bool ok = !(r2 >= 1.0 || r2 == 0.0);
+        if (!ok) {
+            x1 = 2.0 * u53(wl.draw(4, e.lpos, e.lpretw), wl.draw(5, e.lpos, e.lpretw)) - 1.0;
+            x2 = 2.0 * u53(wl.draw(6, e.lpos, e.lpretw), wl.draw(7, e.lpos, e.lpretw)) - 1.0;
+            r2 = x1 * x1 + x2 * x2;
+            used = 8;
+            ok = !(r2 >= 1.0 || r2 == 0.0);
+        }
+        wl.commit(blkL, e.lpos, e.lpretw, used);
+        if (!ok) {
+            MtStream sl(blkL, e.lpos, e.lpretw);
+            do {
+                x1 = 2.0 * sl.random53() - 1.0;
+                x2 = 2.0 * sl.random53() - 1.0;
+                r2 = x1 * x1 + x2 * x2;
+            } while (r2 >= 1.0 || r2 == 0.0);
+            e.lpos = sl.pos; e.lpretw = sl.pretw;
+        }
+        const double f = sqrt(-2.0 * log(r2) / r2);
+        e.gauss = f * x1;
+        e.has_gauss = 1;
+        g = f * x2;
+    }
+    const double np_ = price_update(e, c, price, volume, g);
+    const double hi = np_ * (1.0 + (1.02 - 1.0) * u_hi);          // :353
+    const double lo = np_ * (0.98 + (1.0 - 0.98) * u_lo);         // :354
+    p.closes[(int64_t)phase * p.n + i] = np_;                     // append + pop(0), :359-365; open = previous close :355
+    p.ohlv[(int64_t)phase * p.n + i] = make_float4((float)price, (float)hi, (float)lo, (float)volume);
+    e.close = np_;
+    const double pv = e.cash + e.holdings * np_;
+    e.step += 1;
+    return e.step >= (uint32_t)c.max_steps || pv <= 0.0 || pv >= c.initial_balance * 10.0;   // :382-386
+}
+
+// NumPy pairwise sum of 14 / 20 float64 values (loops_utils.h.src): 8 running partials, a balanced
+// tree, then the tail added sequentially.
+struct Pairwise {
+    double r[8], res;
+    template <int P, int N>
+    __device__ __forceinline__ void add(double v) {
+        constexpr int BODY = N - (N % 8);
+        if constexpr (P < 8) r[P] = v;
+        else if constexpr (P < BODY) r[P % 8] += v;
+        if constexpr (P == BODY - 1) res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        if constexpr (P >= BODY) res += v;
+    }
+};
+
+// _get_observation :505-561 for the wave's 64 envs.  `oldest` = slot of logical candle 0.  Rows of
+// lanes whose bit is set in `rowmask` are written to dst (+ row*261 floats).
+__device__ __forceinline__ void observe(const Env &e, const Params &p, int64_t i0, int64_t i, bool live, int oldest,
+                                        float *__restrict__ dst, unsigned long long rowmask, uint32_t *__restrict__ tile) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const int64_t nrows = p.n - i0 < 64 ? p.n - i0 : 64;
+    const int64_t li = live ? i : i0;            // dead lanes of a partial last wave read a valid column, write nothing
+    const double cur = e.close;
+    const double inv = 1.0 / cur;
+    const double mf = 2.0 / (12 + 1), ms = 2.0 / (26 + 1), mg = 2.0 / (9 + 1);
+    double ef = 0, es = 0, sig = 0, macd = 0, mx = 0, mn = 0, prev = 0;
+    double bb[20];
+    Pairwise pg, pl, pm;
+    pg.res = pl.res = pm.res = 0.0;
+#pragma unroll
+    for (int c = 0; c < HLEN / CH; ++c) {
+        double cl[CH];
+        float4 oh[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            int slot = oldest + c * CH + j;
+            slot -= slot >= HLEN ? HLEN : 0;
+            cl[j] = p.closes[(int64_t)slot * p.n + li];
+            oh[j] = p.ohlv[(int64_t)slot * p.n + li];
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int k = c * CH + j;
+            const double x = cl[j];
+            float *row = reinterpret_cast<float *>(tile) + lane * ROW + j * 5;   // :513-515, [O,H,L,C,V] / current close
+            row[0] = (float)((double)oh[j].x * inv);
+            row[1] = (float)((double)oh[j].y * inv);
+            row[2] = (float)((double)oh[j].z * inv);
+            row[3] = (float)(x * inv);
+            row[4] = (float)((double)oh[j].w * inv);
+            if (k == 0) { ef = es = x; mx = mn = x; }
+            else {
+                ef = (x * mf) + (ef * (1.0 - mf));                 // _ema :113-117
+                es = (x * ms) + (es * (1.0 - ms));
+                mx = x > mx ? x : mx;
+                mn = x < mn ? x : mn;
+            }
+            if (k >= 25) {                                          // macd_values for prefixes 26..50, :94-100
+                macd = ef - es;
+                sig = k == 25 ? macd : (macd * mg) + (sig * (1.0 - mg));
+            }
+            if (k >= 36) {                                          // last 14 deltas, :50-55
+                const double d = x - prev;
+                const double gain = d > 0.0 ? d : 0.0, loss = d < 0.0 ? -d : 0.0;
+                switch (k) {
+#define CGE_CASE(K) case K: pg.add<K - 36, 14>(gain); pl.add<K - 36, 14>(loss); break;
+                    CGE_CASE(36) CGE_CASE(37) CGE_CASE(38) CGE_CASE(39) CGE_CASE(40) CGE_CASE(41) CGE_CASE(42)
+                    CGE_CASE(43) CGE_CASE(44) CGE_CASE(45) CGE_CASE(46) CGE_CASE(47) CGE_CASE(48) CGE_CASE(49)
+#undef CGE_CASE
+                }
+            }
+            if (k >= 30) {
+                bb[k >= 30 ? k - 30 : 0] = x;
+                switch (k) {
+#define CGE_CASE(K) case K: pm.add<K - 30, 20>(x); break;
+                    CGE_CASE(30) CGE_CASE(31) CGE_CASE(32) CGE_CASE(33) CGE_CASE(34) CGE_CASE(35) CGE_CASE(36) CGE_CASE(37)
+                    CGE_CASE(38) CGE_CASE(39) CGE_CASE(40) CGE_CASE(41) CGE_CASE(42) CGE_CASE(43) CGE_CASE(44) CGE_CASE(45)
+                    CGE_CASE(46) CGE_CASE(47) CGE_CASE(48) CGE_CASE(49)
+#undef CGE_CASE
+                }
+            }
+            prev = x;
+        }
+        // stream the chunk: element idx = m*64 + lane of the [64 rows][50 cols] tile -> row idx/50, col idx%50
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        {
+            uint32_t row = lane >= 50u ? 1u : 0u, col = lane >= 50u ? lane - 50u : lane;
+#pragma unroll 5
+            for (int m = 0; m < CH * 5; ++m) {
+                if ((int64_t)row < nrows && ((rowmask >> row) & 1ull))
+                    reinterpret_cast<uint32_t *>(dst)[(int64_t)row * OBS + c * (CH * 5) + col] = tile[row * ROW + col];
+                col += 14u; row += 1u;
+                if (col >= 50u) { col -= 50u; row += 1u; }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    // ---- the 11 scalar features, staged [64][11]
+    float tail[11];
+    const double pv = e.cash + e.holdings * cur;
+    tail[0] = e.cash_kind == 1 ? (float)e.cash / (float)p.cfg.initial_balance : (float)(e.cash / p.cfg.initial_balance);   // :524
+    tail[1] = (float)(e.holdings * cur / p.cfg.initial_balance);
+    tail[2] = (float)(pv / p.cfg.initial_balance);
+    {
+        const double ag = pg.res / 14, al = pl.res / 14;
+        double rsi;
+        if (al == 0.0) rsi = 100.0;
+        else { const double rs = ag / al; rsi = 100.0 - (100.0 / (1.0 + rs)); }
+        tail[3] = (float)(rsi / 100.0);
+    }
+    {
+        const double hist = macd - sig, range = mx - mn;
+        const bool ok = range > 0.0;
+        tail[4] = ok ? (float)(macd / range) : 0.0f;
+        tail[5] = ok ? (float)(sig / range) : 0.0f;
+        tail[6] = ok ? (float)(hist / range) : 0.0f;
+    }
+    {
+        const double sma = pm.res / 20;
+        Pairwise pd;
+        pd.res = 0.0;
+#define CGE_DEV(P) { const double x = bb[P] - sma; pd.add<P, 20>(x * x); }
+        CGE_DEV(0) CGE_DEV(1) CGE_DEV(2) CGE_DEV(3) CGE_DEV(4) CGE_DEV(5) CGE_DEV(6) CGE_DEV(7) CGE_DEV(8) CGE_DEV(9)
+        CGE_DEV(10) CGE_DEV(11) CGE_DEV(12) CGE_DEV(13) CGE_DEV(14) CGE_DEV(15) CGE_DEV(16) CGE_DEV(17) CGE_DEV(18) CGE_DEV(19)
+#undef CGE_DEV
+        const double sd = sqrt(pd.res / 20);
+        const double upper = sma + (2.0 * sd), lower = sma - (2.0 * sd);
+        tail[7] = (float)(upper > lower ? (cur - lower) / (upper - lower) : 0.5);
+        tail[8] = (float)(sma > 0.0 ? (upper - lower) / sma : 0.0);
+        tail[9] = (float)(sma > 0.0 ? (cur - sma) / sma : 0.0);
+    }
+    tail[10] = (float)e.psych;
+#pragma unroll
+    for (int j = 0; j < 11; ++j) reinterpret_cast<float *>(tile)[lane * 11 + j] = tail[j];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+        uint32_t row = lane / 11u, col = lane - row * 11u;       // 64 = 5*11 + 9
+#pragma unroll
+        for (int m = 0; m < 11; ++m) {
+            if ((int64_t)row < nrows && ((rowmask >> row) & 1ull))
+                reinterpret_cast<uint32_t *>(dst)[(int64_t)row * OBS + 250 + col] = tile[row * 11 + col];
+            col += 9u; row += 5u;
+            if (col >= 11u) { col -= 11u; row += 1u; }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+__device__ __forceinline__ void hash_cont(uint64_t key, uint64_t t, float &b, float &s) {
+    const uint64_t u0 = mix64(key + t * 0xD1342543DE82EF95ull + 0) >> 40, u1 = mix64(key + t * 0xD1342543DE82EF95ull + 1) >> 40;
+    b = (float)((double)u0 / 8388608.0 - 1.0);
+    s = (float)((double)u1 / 8388608.0 - 1.0);
+}
+
+// step (k_steps == 1, explicit actions, per-step outputs) and rollout (k fused steps) share one body
+template <bool ROLLOUT>
+__global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
+    __shared__ uint32_t tile[64 * ROW];
+    const int64_t i0 = (int64_t)blockIdx.x * BLOCK;
+    const int64_t i = i0 + threadIdx.x;
+    const bool live = i < p.n;
+    const int64_t li = live ? i : i0;
+    Env e;
+    e.load(p.scal, p.n, li);
+    uint64_t key = ROLLOUT ? hash_env_key(p.a_seed, (uint64_t)(p.env0 + li)) : 0;
+    double rsum = 0.0;
+    int32_t dcount = 0;
+    int phase = p.phase;
+    const int ksteps = ROLLOUT ? p.k_steps : 1;
+#pragma unroll 1
+    for (int t = 0; t < ksteps; ++t) {
+        double reward = 0.0;
+        bool term = false, reset_now = false;
+        const int next_phase = phase + 1 == HLEN ? 0 : phase + 1;
+        if (live) {
+            if (p.mode == CGE_AUTORESET_NEXT_STEP && e.needs_reset) {
+                reset_now = true;
+            } else {
+                int32_t a = 0;
+                float ab = 0.0f, as = 0.0f;
+                if (p.cfg.continuous) {
+                    if (p.actions) { const float2 v = reinterpret_cast<const float2 *>(p.actions)[(int64_t)t * p.n + i]; ab = v.x; as = v.y; }
+                    else hash_cont(key, (uint64_t)(p.t0 + t), ab, as);
+                } else {
+                    a = p.actions ? reinterpret_cast<const int32_t *>(p.actions)[(int64_t)t * p.n + i]
+                                  : (int32_t)hash_action_from_key(key, (uint64_t)(p.t0 + t), 5u, 0u);
+                }
+                term = env_step(e, p, i, phase, a, ab, as, reward);
+                if (term) {
+                    e.episodes += 1;
+                    if (p.mode == CGE_AUTORESET_SAME_STEP) reset_now = true;
+                    else if (p.mode == CGE_AUTORESET_NEXT_STEP) e.needs_reset = 1;
+                }
+            }
+        }
+        // SAME_STEP: the terminal observation of the lanes that just finished goes to final_obs first
+        const unsigned long long fin_mask = __ballot(live && term && reset_now);
+        float *obs_t = p.obs ? p.obs + (int64_t)t * p.obs_step_stride + i0 * OBS : nullptr;
+#pragma unroll 1
+        for (int pass = (fin_mask && p.final_obs) ? 0 : 1; pass < 2; ++pass) {
+            if (pass == 1 && reset_now) do_reset(e, p, i, next_phase);
+            float *dst = pass == 0 ? p.final_obs + i0 * OBS : obs_t;
+            if (dst) observe(e, p, i0, i, live, next_phase, dst, pass == 0 ? fin_mask : ~0ull, tile);
+        }
+        if (live) {
+            if (ROLLOUT) {
+                rsum += reward;
+                dcount += term ? 1 : 0;
+                if (p.reward) p.reward[(int64_t)t * p.n + i] = (float)reward;
+                if (p.terminated) p.terminated[(int64_t)t * p.n + i] = term ? 1 : 0;
+            } else {
+                p.reward[i] = (float)reward;
+                p.terminated[i] = term ? 1 : 0;
+                if (p.truncated) p.truncated[i] = 0;
+            }
+        }
+        phase = next_phase;
+    }
+    if (live) {
+        e.store(p.scal, p.n, i);
+        if (ROLLOUT) {
+            if (p.reward_sum) p.reward_sum[i] = rsum;
+            if (p.done_count) p.done_count[i] = dcount;
+        }
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void reset_kernel(Params p) {
+    __shared__ uint32_t tile[64 * ROW];
+    const int64_t i0 = (int64_t)blockIdx.x * BLOCK;
+    const int64_t i = i0 + threadIdx.x;
+    const bool live = i < p.n;
+    Env e;
+    e.load(p.scal, p.n, live ? i : i0);
+    if (live && (!p.mask || p.mask[i])) {
+        do_reset(e, p, i, p.phase);
+        e.store(p.scal, p.n, i);
+    }
+    if (p.obs) observe(e, p, i0, i, live, p.phase, p.obs + i0 * OBS, ~0ull, tile);
+}
+
+// initial MarketSimulator state (:125-130) and balances; also rewinds the stream cursors after (re)seeding
+__global__ __launch_bounds__(256) void init_kernel(uint4 *scal, int64_t n, double initial_balance, int rewind_only) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    Env e;
+    e.load(scal, n, i);
+    if (!rewind_only) {
+        e.cash = initial_balance; e.holdings = 0.0; e.close = 50000.0; e.psych = 0.5; e.trend = 0.0; e.gauss = 0.0;
+        e.step = 0; e.regime = SIDEWAYS; e.cash_kind = 0; e.needs_reset = 0; e.episodes = 0;
+    }
+    e.has_gauss = 0;            // np.random.seed() drops the cached gaussian
+    e.gauss = 0.0;
+    e.ppos = e.lpos = 0;
+    e.ppretw = e.lpretw = 0;
+    e.store(scal, n, i);
+}
+
+__global__ __launch_bounds__(256) void info_kernel(const uint4 *__restrict__ scal, int64_t n, int field, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    Env e;
+    e.load(scal, n, i);
+    double v = 0.0;
+    switch (field) {
+        case CGE_CRYPTO_INFO_PORTFOLIO_VALUE: v = e.cash + e.holdings * e.close; break;
+        case CGE_CRYPTO_INFO_CASH: v = e.cash; break;
+        case CGE_CRYPTO_INFO_HOLDINGS: v = e.holdings; break;
+        case CGE_CRYPTO_INFO_CURRENT_PRICE: v = e.close; break;
+        case CGE_CRYPTO_INFO_MARKET_PSYCHOLOGY: v = e.psych; break;
+        case CGE_CRYPTO_INFO_REGIME: v = e.regime; break;
+        case CGE_CRYPTO_INFO_STEP: v = e.step; break;
+        case CGE_CRYPTO_INFO_TREND_STRENGTH: v = e.trend; break;
+        case CGE_CRYPTO_INFO_EPISODES: v = e.episodes; break;
+        case CGE_CRYPTO_INFO_NEEDS_RESET: v = e.needs_reset; break;
+        case CGE_CRYPTO_INFO_CASH_KIND: v = e.cash_kind; break;
+    }
+    out[i] = v;
+}
+
+}  // namespace crypto
+}  // namespace cge
+
+using namespace cge;
+
+struct cge_crypto : HandleBase {
+    cge_crypto_config cfg{};
+    uint4 *scal = nullptr;
+    double *closes = nullptr;
+    float4 *ohlv = nullptr;
+    uint32_t *mtP = nullptr, *mtL = nullptr;
+    int phase = 0;
+
+    crypto::Params params() const {
+        crypto::Params p{};
+        p.scal = scal; p.closes = closes; p.ohlv = ohlv; p.mtP = mtP; p.mtL = mtL; p.n = n; p.env0 = env0;
+        p.cfg = crypto::Cfg{cfg.initial_balance, cfg.trading_fee_rate, cfg.slippage_rate, cfg.min_price, cfg.max_price,
+                            cfg.volatility_base, cfg.market_psychology_factor, cfg.max_steps, cfg.action_type};
+        p.mode = cfg.autoreset_mode; p.phase = phase;
+        return p;
+    }
+    unsigned blocks() const { return (unsigned)((n + crypto::BLOCK - 1) / crypto::BLOCK); }
+    void free_all() {
+        (void)hipFree(scal); (void)hipFree(closes); (void)hipFree(ohlv); (void)hipFree(mtP); (void)hipFree(mtL);
+    }
+};
+
+extern "C" {
+
+void cge_crypto_default_config(cge_crypto_config *c) {
+    if (!c) return;
+    *c = cge_crypto_config{10000.0, 0.001, 0.0005, 100.0, 100000.0, 0.02, 0.1, 1000, 0, CGE_AUTORESET_NEXT_STEP, 0};
+}
+
+int cge_crypto_create(const cge_crypto_config *cfg, int64_t n_envs, int device, int64_t env_index0, cge_crypto **out) {
+    if (!cfg || !out || n_envs <= 0 || env_index0 < 0) return CGE_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (cfg->autoreset_mode < 0 || cfg->autoreset_mode > 2 || cfg->max_steps <= 0 || cfg->max_steps > 65535 ||
+        cfg->action_type < 0 || cfg->action_type > 1 || !(cfg->min_price > 0) || !(cfg->max_price >= cfg->min_price))
+        return CGE_ERR_INVALID_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return CGE_ERR_NO_DEVICE;
+    cge_crypto *h = new cge_crypto();
+    h->cfg = *cfg; h->n = n_envs; h->env0 = env_index0; h->device = device;
+    DeviceGuard g(device);
+    const size_t sb = (size_t)4 * n_envs * sizeof(uint4), cb = (size_t)crypto::HLEN * n_envs * sizeof(double),
+                 ob = (size_t)crypto::HLEN * n_envs * sizeof(float4), mb = (size_t)n_envs * MT_STRIDE * sizeof(uint32_t);
+    hipError_t e;
+    if ((e = hipMalloc(&h->scal, sb)) != hipSuccess || (e = hipMalloc(&h->closes, cb)) != hipSuccess ||
+        (e = hipMalloc(&h->ohlv, ob)) != hipSuccess || (e = hipMalloc(&h->mtP, mb)) != hipSuccess ||
+        (e = hipMalloc(&h->mtL, mb)) != hipSuccess || (e = hipMemset(h->scal, 0, sb)) != hipSuccess ||
+        (e = hipMemset(h->closes, 0, cb)) != hipSuccess || (e = hipMemset(h->ohlv, 0, ob)) != hipSuccess) {
+        h->free_all();
+        delete h;
+        return CGE_ERR_HIP;
+    }
+    h->device_bytes = sb + cb + ob + 2 * mb;
+    e = launch_mt_seed(h->mtP, MT_STRIDE, n_envs, nullptr, 0, env_index0, 0, nullptr);
+    if (e == hipSuccess) e = launch_mt_seed(h->mtL, MT_STRIDE, n_envs, nullptr, 0, env_index0, 1, nullptr);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(crypto::init_kernel, dim3((unsigned)((n_envs + 255) / 256)), dim3(256), 0, nullptr, h->scal, n_envs,
+                           cfg->initial_balance, 0);
+        // no reset here: a fresh handle is a freshly constructed env (:244-278) — the MarketSimulator state a
+        // reset leaves behind would otherwise leak into the first real reset(seed=...)
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) {
+        h->free_all();
+        delete h;
+        return CGE_ERR_HIP;
+    }
+    *out = h;
+    return CGE_OK;
+}
+
+int cge_crypto_destroy(cge_crypto *h) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    DeviceGuard g(h->device);
+    (void)hipDeviceSynchronize();
+    h->free_all();
+    delete h;
+    return CGE_OK;
+}
+
+int cge_crypto_seed(cge_crypto *h, const uint64_t *seeds, uint64_t base_seed, void *stream) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    DeviceGuard g(h->device);
+    if (!seeds && base_seed + (uint64_t)(h->env0 + h->n) > 0x100000000ull)
+        return h->fail(CGE_ERR_INVALID_ARG, "cge_crypto_seed: np.random.seed needs seeds < 2**32");
+    CGE_TRY(h, launch_mt_seed(h->mtP, MT_STRIDE, h->n, seeds, base_seed, h->env0, 0, as_stream(stream)));
+    CGE_TRY(h, launch_mt_seed(h->mtL, MT_STRIDE, h->n, seeds, base_seed, h->env0, 1, as_stream(stream)));
+    hipLaunchKernelGGL(crypto::init_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, as_stream(stream), h->scal, h->n,
+                       h->cfg.initial_balance, 1);
+    CGE_TRY(h, hipGetLastError());
+    return CGE_OK;
+}
+
+int cge_crypto_reset(cge_crypto *h, const uint8_t *mask, float *obs_out, void *stream) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    DeviceGuard g(h->device);
+    crypto::Params p = h->params();
+    p.mask = mask; p.obs = obs_out;
+    hipLaunchKernelGGL(crypto::reset_kernel, dim3(h->blocks()), dim3(crypto::BLOCK), 0, as_stream(stream), p);
+    CGE_TRY(h, hipGetLastError());
+    return CGE_OK;
+}
+
+int cge_crypto_step(cge_crypto *h, const void *actions, float *obs_out, float *reward_out, uint8_t *terminated_out,
+                    uint8_t *truncated_out, float *final_obs_out, void *stream) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    if (!actions || !obs_out || !reward_out || !terminated_out)
+        return h->fail(CGE_ERR_INVALID_ARG, "cge_crypto_step: null actions/obs/reward/terminated pointer");
+    DeviceGuard g(h->device);
+    crypto::Params p = h->params();
+    p.actions = actions; p.obs = obs_out; p.reward = reward_out; p.terminated = terminated_out; p.truncated = truncated_out;
+    p.final_obs = final_obs_out; p.k_steps = 1;
+    hipLaunchKernelGGL(crypto::step_kernel<false>, dim3(h->blocks()), dim3(crypto::BLOCK), 0, as_stream(stream), p);
+    CGE_TRY(h, hipGetLastError());
+    h->phase = (h->phase + 1) % crypto::HLEN;
+    return CGE_OK;
+}
+
+int cge_crypto_rollout(cge_crypto *h, int32_t k_steps, const void *actions, uint64_t action_seed, int64_t t0, float *obs_out,
+                       int64_t obs_step_stride, float *reward_traj_out, uint8_t *terminated_traj_out, double *reward_sum_out,
+                       int32_t *done_count_out, void *stream) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    if (k_steps < 0 || obs_step_stride < 0 || (obs_step_stride != 0 && obs_step_stride < h->n * crypto::OBS))
+        return h->fail(CGE_ERR_INVALID_ARG, "cge_crypto_rollout: bad k_steps / obs_step_stride");
+    if (k_steps == 0) return CGE_OK;
+    DeviceGuard g(h->device);
+    crypto::Params p = h->params();
+    p.k_steps = k_steps; p.actions = actions; p.a_seed = action_seed; p.t0 = t0; p.obs = obs_out; p.obs_step_stride = obs_step_stride;
+    p.reward = reward_traj_out; p.terminated = terminated_traj_out; p.reward_sum = reward_sum_out; p.done_count = done_count_out;
+    hipLaunchKernelGGL(crypto::step_kernel<true>, dim3(h->blocks()), dim3(crypto::BLOCK), 0, as_stream(stream), p);
+    CGE_TRY(h, hipGetLastError());
+    h->phase = (h->phase + k_steps) % crypto::HLEN;
+    return CGE_OK;
+}
+
+int cge_crypto_info(cge_crypto *h, int32_t field_id, double *out, void *stream) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    if (!out || field_id < 0 || field_id > CGE_CRYPTO_INFO_CASH_KIND) return h->fail(CGE_ERR_INVALID_ARG, "cge_crypto_info: bad field / null out");
+    DeviceGuard g(h->device);
+    hipLaunchKernelGGL(crypto::info_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, as_stream(stream), h->scal, h->n, field_id, out);
+    CGE_TRY(h, hipGetLastError());
+    return CGE_OK;
+}
+
+size_t cge_crypto_state_bytes(const cge_crypto *h) { return h ? 12 * 4 + 6 * 8 + 2 * MT_N * 4 + crypto::HLEN * 5 * 8 : 0; }
+
+static void export_mt(const uint32_t *w, uint32_t pos, uint32_t pretw, uint32_t *omt, int32_t *idx) {
+    memcpy(omt, w, MT_N * 4);
+    if (pretw >= (uint32_t)MT_N) { *idx = (int32_t)pos; return; }
+    if (pos == 0) { *idx = MT_N; return; }
+    for (uint32_t k = pos; k < (uint32_t)MT_N; ++k) {
+        const uint32_t k1 = k + 1 == (uint32_t)MT_N ? 0 : k + 1, km = k + MT_M >= (uint32_t)MT_N ? k + MT_M - MT_N : k + MT_M;
+        const uint32_t t = (omt[k] & 0x80000000u) | (omt[k1] & 0x7fffffffu);
+        omt[k] = omt[km] ^ (t >> 1) ^ ((t & 1u) ? 0x9908b0dfu : 0u);
+    }
+    *idx = (int32_t)pos;
+}
+
+int cge_crypto_get_state(cge_crypto *h, void *host_buf, void *stream) {
+    if (!h || !host_buf) return CGE_ERR_INVALID_ARG;
+    DeviceGuard g(h->device);
+    const int64_t n = h->n;
+    std::vector<uint4> sc((size_t)4 * n);
+    std::vector<double> cl((size_t)crypto::HLEN * n);
+    std::vector<float4> oh((size_t)crypto::HLEN * n);
+    std::vector<uint32_t> mp((size_t)n * MT_STRIDE), ml((size_t)n * MT_STRIDE);
+    CGE_TRY(h, hipStreamSynchronize(as_stream(stream)));
+    CGE_TRY(h, hipMemcpy(sc.data(), h->scal, sc.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+    CGE_TRY(h, hipMemcpy(cl.data(), h->closes, cl.size() * sizeof(double), hipMemcpyDeviceToHost));
+    CGE_TRY(h, hipMemcpy(oh.data(), h->ohlv, oh.size() * sizeof(float4), hipMemcpyDeviceToHost));
+    CGE_TRY(h, hipMemcpy(mp.data(), h->mtP, mp.size() * 4, hipMemcpyDeviceToHost));
+    CGE_TRY(h, hipMemcpy(ml.data(), h->mtL, ml.size() * 4, hipMemcpyDeviceToHost));
+    const size_t rec = cge_crypto_state_bytes(h);
+    for (int64_t i = 0; i < n; ++i) {
+        uint8_t *p = (uint8_t *)host_buf + (size_t)i * rec;
+        const uint4 a = sc[i], b = sc[n + i], c = sc[2 * n + i], d = sc[3 * n + i];
+        auto dbl = [](uint32_t lo, uint32_t hi) { uint64_t u = ((uint64_t)hi << 32) | lo; double x; memcpy(&x, &u, 8); return x; };
+        int32_t hd[12] = {(int32_t)((d.x >> 16) & 7u), (int32_t)(d.x & 0xffffu), (int32_t)((d.x >> 22) & 1u), (int32_t)((d.x >> 20) & 3u),
+                          0, 0, (int32_t)((d.x >> 19) & 1u), (int32_t)d.z, 0, 0, 0, 0};
+        double scv[6] = {dbl(a.x, a.y), dbl(a.z, a.w), dbl(b.z, b.w), dbl(c.x, c.y), dbl(c.z, c.w), 0.0};
+        export_mt(&mp[(size_t)i * MT_STRIDE], d.y & 1023u, (d.y & 1024u) ? MT_N : 0, (uint32_t *)(p + 96), &hd[4]);
+        export_mt(&ml[(size_t)i * MT_STRIDE], (d.y >> 11) & 1023u, (d.y & (1u << 21)) ? MT_N : 0, (uint32_t *)(p + 96 + MT_N * 4), &hd[5]);
+        memcpy(p, hd, 48);
+        memcpy(p + 48, scv, 48);
+        double *hh = (double *)(p + 96 + 2 * MT_N * 4);
+        for (int k = 0; k < crypto::HLEN; ++k) {
+            const int slot = (h->phase + k) % crypto::HLEN;
+            const float4 v = oh[(size_t)slot * n + i];
+            hh[5 * k] = v.x; hh[5 * k + 1] = v.y; hh[5 * k + 2] = v.z; hh[5 * k + 3] = cl[(size_t)slot * n + i]; hh[5 * k + 4] = v.w;
+        }
+    }
+    return CGE_OK;
+}
+
+int cge_crypto_set_state(cge_crypto *h, const void *host_buf, void *stream) {
+    if (!h || !host_buf) return CGE_ERR_INVALID_ARG;
+    DeviceGuard g(h->device);
+    const int64_t n = h->n;
+    std::vector<uint4> sc((size_t)4 * n);
+    std::vector<double> cl((size_t)crypto::HLEN * n);
+    std::vector<float4> oh((size_t)crypto::HLEN * n);
+    std::vector<uint32_t> mp((size_t)n * MT_STRIDE, 0u), ml((size_t)n * MT_STRIDE, 0u);
+    const size_t rec = cge_crypto_state_bytes(h);
+    for (int64_t i = 0; i < n; ++i) {
+        const uint8_t *p = (const uint8_t *)host_buf + (size_t)i * rec;
+        int32_t hd[12];
+        double scv[6];
+        memcpy(hd, p, 48);
+        memcpy(scv, p + 48, 48);
+        if (hd[0] < 0 || hd[0] > 4 || hd[1] < 0 || hd[1] > 65535 || hd[4] < 0 || hd[4] > MT_N || hd[5] < 0 || hd[5] > MT_N)
+            return h->fail(CGE_ERR_INVALID_ARG, "cge_crypto_set_state: malformed record");
+        const double *hh = (const double *)(p + 96 + 2 * MT_N * 4);
+        auto lo = [](double x) { uint64_t u; memcpy(&u, &x, 8); return (uint32_t)u; };
+        auto hi = [](double x) { uint64_t u; memcpy(&u, &x, 8); return (uint32_t)(u >> 32); };
+        const double close = hh[5 * (crypto::HLEN - 1) + 3];
+        const uint32_t ppos = hd[4] >= MT_N ? 0u : (uint32_t)hd[4], ppre = hd[4] >= MT_N ? 0u : 1024u;
+        const uint32_t lpos = hd[5] >= MT_N ? 0u : (uint32_t)hd[5], lpre = hd[5] >= MT_N ? 0u : (1u << 21);
+        sc[i] = make_uint4(lo(scv[0]), hi(scv[0]), lo(scv[1]), hi(scv[1]));
+        sc[n + i] = make_uint4(lo(close), hi(close), lo(scv[2]), hi(scv[2]));
+        sc[2 * n + i] = make_uint4(lo(scv[3]), hi(scv[3]), lo(scv[4]), hi(scv[4]));
+        sc[3 * n + i] = make_uint4((uint32_t)hd[1] | ((uint32_t)hd[0] << 16) | ((uint32_t)(hd[6] & 1) << 19) | ((uint32_t)(hd[3] & 3) << 20) |
+                                       ((uint32_t)(hd[2] & 1) << 22),
+                                   ppos | ppre | (lpos << 11) | lpre, (uint32_t)hd[7], 0u);
+        memcpy(&mp[(size_t)i * MT_STRIDE], p + 96, MT_N * 4);
+        memcpy(&ml[(size_t)i * MT_STRIDE], p + 96 + MT_N * 4, MT_N * 4);
+        for (int k = 0; k < crypto::HLEN; ++k) {
+            const int slot = (h->phase + k) % crypto::HLEN;
+            cl[(size_t)slot * n + i] = hh[5 * k + 3];
+            oh[(size_t)slot * n + i] = make_float4((float)hh[5 * k], (float)hh[5 * k + 1], (float)hh[5 * k + 2], (float)hh[5 * k + 4]);
+        }
+    }
+    CGE_TRY(h, hipStreamSynchronize(as_stream(stream)));
+    CGE_TRY(h, hipMemcpy(h->scal, sc.data(), sc.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    CGE_TRY(h, hipMemcpy(h->closes, cl.data(), cl.size() * sizeof(double), hipMemcpyHostToDevice));
+    CGE_TRY(h, hipMemcpy(h->ohlv, oh.data(), oh.size() * sizeof(float4), hipMemcpyHostToDevice));
+    CGE_TRY(h, hipMemcpy(h->mtP, mp.data(), mp.size() * 4, hipMemcpyHostToDevice));
+    CGE_TRY(h, hipMemcpy(h->mtL, ml.data(), ml.size() * 4, hipMemcpyHostToDevice));
+    return CGE_OK;
+}
+
+size_t cge_crypto_device_bytes(const cge_crypto *h) { return h ? h->device_bytes : 0; }
+const char *cge_crypto_last_error(const cge_crypto *h) { return h ? h->last_error.c_str() : "null handle"; }
+
+}  // extern "C"

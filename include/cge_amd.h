@@ -125,6 +125,75 @@ int64_t cge_snake_error_count(cge_snake *h, void *stream);
 size_t cge_snake_device_bytes(const cge_snake *h);
 const char *cge_snake_last_error(const cge_snake *h);
 
+/* ------------------------------------------------------------------------------------------ */
+/* Crypto  (crypto_trading_env/crypto_trading_env.py: CryptoTradingEnv)                        */
+/*   obs float32 (261,) (:505-561; the declared space says 260, :286)                          */
+/*   action: int32 in {0 hold,1 buy 5%,2 buy 20%,3 sell 5%,4 sell 20%} (discrete) or float32[2] */
+/*   (continuous: [buy, sell], :407-422).  All state arithmetic is float64 as in the reference; */
+/*   O/H/L/V history is stored as float32 (it only feeds the float32 obs), closes as float64.   */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct cge_crypto cge_crypto;
+
+typedef struct {                 /* TradingConfig, crypto_trading_env.py:28-38 (history_length is fixed at 50) */
+    double initial_balance;          /* 10000.0 */
+    double trading_fee_rate;         /* 0.001 */
+    double slippage_rate;            /* 0.0005 */
+    double min_price;                /* 100.0 */
+    double max_price;                /* 100000.0 */
+    double volatility_base;          /* 0.02 */
+    double market_psychology_factor; /* 0.1 */
+    int32_t max_steps;               /* 1000 (:278); <= 65535 */
+    int32_t action_type;             /* 0 discrete, 1 continuous (:247) */
+    int32_t autoreset_mode;          /* CGE_AUTORESET_* */
+    int32_t reserved;
+} cge_crypto_config;
+
+enum { /* cge_crypto_info field ids (float64 per env), the keys of step()'s info dict (:390-398) */
+    CGE_CRYPTO_INFO_PORTFOLIO_VALUE = 0,
+    CGE_CRYPTO_INFO_CASH = 1,
+    CGE_CRYPTO_INFO_HOLDINGS = 2,
+    CGE_CRYPTO_INFO_CURRENT_PRICE = 3,
+    CGE_CRYPTO_INFO_MARKET_PSYCHOLOGY = 4,
+    CGE_CRYPTO_INFO_REGIME = 5,       /* 0 bull_run 1 bear_market 2 sideways 3 crash 4 recovery (:20-25) */
+    CGE_CRYPTO_INFO_STEP = 6,
+    CGE_CRYPTO_INFO_TREND_STRENGTH = 7,
+    CGE_CRYPTO_INFO_EPISODES = 8,
+    CGE_CRYPTO_INFO_NEEDS_RESET = 9,
+    CGE_CRYPTO_INFO_CASH_KIND = 10    /* dtype of self.cash under NumPy>=2: 0 Python float, 1 float32, 2 float64 */
+};
+
+void cge_crypto_default_config(cge_crypto_config *cfg);
+int cge_crypto_create(const cge_crypto_config *cfg, int64_t n_envs, int device, int64_t env_index0,
+                      cge_crypto **out);
+int cge_crypto_destroy(cge_crypto *h);
+/* reset(seed=s) seeding (:305-307): random.seed(s_i) AND np.random.seed(s_i); s_i as for snake; s_i must
+ * be < 2**32 (np.random.seed raises otherwise).  Does not reset the envs; the MarketSimulator state
+ * (regime, trend, psychology) is never reset, as in the reference (:257). */
+int cge_crypto_seed(cge_crypto *h, const uint64_t *seeds, uint64_t base_seed, void *stream);
+int cge_crypto_reset(cge_crypto *h, const uint8_t *mask, float *obs_out, void *stream);
+/* actions: int32[n_envs] (discrete; any value outside 1..4 is a hold, as in the reference) or
+ * float32[n_envs,2] (continuous).  reward_out is float32(reward); terminated = step>=max_steps or
+ * portfolio<=0 or portfolio>=10*initial (:382-386); truncated always 0 (nullable). */
+int cge_crypto_step(cge_crypto *h, const void *actions, float *obs_out, float *reward_out,
+                    uint8_t *terminated_out, uint8_t *truncated_out, float *final_obs_out, void *stream);
+/* k fused step()s.  actions NULL -> hash actions (discrete: cge_hash_action(seed,env,t,5,0); continuous:
+ * (cge_hash(..,j) >> 40) / 2^23 - 1 for j = 0,1); else [k, n_envs(,2)].  obs_out / obs_step_stride
+ * (in floats) as for snake; reward_sum_out is float64. */
+int cge_crypto_rollout(cge_crypto *h, int32_t k_steps, const void *actions, uint64_t action_seed, int64_t t0,
+                       float *obs_out, int64_t obs_step_stride, float *reward_traj_out,
+                       uint8_t *terminated_traj_out, double *reward_sum_out, int32_t *done_count_out,
+                       void *stream);
+int cge_crypto_info(cge_crypto *h, int32_t field_id, double *out, void *stream);
+/* canonical record (host), identical to the oracle's: int32[12] {regime, step, needs_reset, cash_kind,
+ * P_idx, L_idx, has_gauss, episodes, 0,0,0,0}; double[6] {cash, holdings, psych, trend_strength, gauss, 0};
+ * uint32 P[624]; uint32 L[624]; double hist[50][5] (O,H,L,C,V, oldest first; O/H/L/V round-trip
+ * through float32 on the device). */
+size_t cge_crypto_state_bytes(const cge_crypto *h);
+int cge_crypto_get_state(cge_crypto *h, void *host_buf, void *stream);
+int cge_crypto_set_state(cge_crypto *h, const void *host_buf, void *stream);
+size_t cge_crypto_device_bytes(const cge_crypto *h);
+const char *cge_crypto_last_error(const cge_crypto *h);
+
 #ifdef __cplusplus
 }
 #endif

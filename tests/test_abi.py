@@ -17,10 +17,11 @@ def _declared():
 
 def test_header_declares_the_full_per_env_surface():
     names = _declared()
-    for env in ["snake"]:
+    for env in ["snake", "crypto"]:
         for fn in ["create", "destroy", "seed", "reset", "step", "rollout", "info", "state_bytes", "get_state",
-                   "set_state", "last_error", "error_count", "device_bytes"]:
+                   "set_state", "last_error", "device_bytes"]:
             assert f"cge_{env}_{fn}" in names, (env, fn)
+    assert "cge_snake_error_count" in names
 
 
 def test_library_exports_every_declared_symbol():
