@@ -26,12 +26,18 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 # algorithmic bytes per env-step, SURVEY.md section 8d
-ALGO_BYTES = {"snake": 145}
+ALGO_BYTES = {"snake": 145, "crypto": 2346}
 WORKLOADS = {
     "snake_1m": dict(env="snake", n_per_gpu=1 << 20, grid=10,
                      desc="SnakeEnv 10x10, 1,048,576 parallel envs per GPU, random actions, fused auto-reset"),
     "snake_64k": dict(env="snake", n_per_gpu=1 << 16, grid=10, desc="SnakeEnv 10x10, 65,536 envs per GPU (quick check)"),
+    "crypto_1m": dict(env="crypto", n_per_gpu=1 << 20,
+                      desc="crypto_trading_env discrete, 1,048,576 parallel envs per GPU, random actions, fused auto-reset"),
 }
+KERNELS = {("snake", "step"): "cge::snake::step_kernel<10, 256, 1, 8>", ("snake", "rollout"): "cge::snake::rollout_kernel<10, 256, 1, 8>",
+           ("crypto", "step"): "cge::crypto::step_kernel<false>", ("crypto", "rollout"): "cge::crypto::step_kernel<true>"}
+N_ACTIONS = {"snake": 4, "crypto": 5}
+DTYPE = {"snake": "i8", "crypto": "f64"}
 
 
 def cpu_baseline_snake(grid, budget_s=12.0):
@@ -77,6 +83,44 @@ def cpu_baseline_snake(grid, budget_s=12.0):
                                       "3.4e5-4.2e5 steps/s/process, 1.81e6 over 8 processes (BASELINE.md section 2)")
 
 
+def cpu_baseline_crypto(budget_s=12.0):
+    import oracle
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
+    n_each, k = 256, 100
+    o = oracle.CryptoOracle(n_each, "discrete", oracle.SAME_STEP)
+    o.reset()
+    t = time.perf_counter()
+    o.rollout(k, 123, 0, 0)
+    one = time.perf_counter() - t
+    reps = max(1, min(int(budget_s / max(one, 1e-3)), 2000))
+    handles = []
+    for c in range(cores):
+        h = oracle.CryptoOracle(n_each, "discrete", oracle.SAME_STEP)
+        h.seed(np.arange(c * n_each, (c + 1) * n_each, dtype=np.uint64))
+        h.reset()
+        handles.append(h)
+
+    def work(c):
+        for r in range(reps):
+            handles[c].rollout(k, 123, r * k, c * n_each)
+
+    th = [threading.Thread(target=work, args=(c,)) for c in range(cores)]
+    t = time.perf_counter()
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    dt = time.perf_counter() - t
+    return dict(value=cores * reps * n_each * k / dt, unit="env-steps/s", cores=cores, kind="port",
+                sample=f"{cores} threads x {n_each} envs x {reps * k} steps (hash actions, auto-reset, obs assembled every step), "
+                       f"oracle/orc_crypto.c; single-core rate {n_each * k / one:.3e}",
+                reference_python_note="reference Python in the build container: 1.64e3-1.68e3 steps/s/process (BASELINE.md section 2)")
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
     tools_profile_summary.py: 2*FETCH_SIZE + WRITE_SIZE, the gfx950 read-side correction of
@@ -120,11 +164,15 @@ def main():
     n = wl["n_per_gpu"]
     K, W = args.steps, args.warmup
     dev = torch.device("cuda", local_rank)
-    env = cge.SnakeVectorEnv(n, grid_size=wl["grid"], device=dev, autoreset_mode="SameStep", env_index0=rank * n,
-                             reuse_buffers=True)
+    if wl["env"] == "snake":
+        env = cge.SnakeVectorEnv(n, grid_size=wl["grid"], device=dev, autoreset_mode="SameStep", env_index0=rank * n,
+                                 reuse_buffers=True)
+    else:
+        env = cge.CryptoVectorEnv(n, action_type="discrete", device=dev, autoreset_mode="SameStep", env_index0=rank * n,
+                                  reuse_buffers=True)
     env.reset(seed=0)
-    # synthetic action stream, resident in HBM before timing: counter-hash actions for K+W steps
-    actions = torch.randint(0, 4, (K + W, n), dtype=torch.int32, device=dev)
+    # synthetic action stream, resident in HBM before timing
+    actions = torch.randint(0, N_ACTIONS[wl["env"]], (K + W, n), dtype=torch.int32, device=dev)
 
     def barrier():
         torch.cuda.synchronize()
@@ -145,7 +193,7 @@ def main():
         barrier()
         wall = time.perf_counter() - t0
         launches = K
-        kernel = "cge::snake::step_kernel<10, 256, 1, 8>"
+        kernel = KERNELS[(wl["env"], "step")]
     else:
         env.rollout(max(W, 1), action_seed=123, t0=0)
         barrier()
@@ -156,10 +204,10 @@ def main():
         barrier()
         wall = time.perf_counter() - t0
         launches = 1
-        kernel = "cge::snake::rollout_kernel<10, 256, 1, 8>"
+        kernel = KERNELS[(wl["env"], "rollout")]
     gpu_ms = ev0.elapsed_time(ev1)
-    bad = env.invalid_action_count()
-    assert bad == 0
+    if wl["env"] == "snake":
+        assert env.invalid_action_count() == 0
     fused = None
     if args.path == "step":
         # reported beside the headline, outside its timed region: the same K steps fused in one launch
@@ -173,7 +221,7 @@ def main():
         torch.cuda.synchronize()
         f_ms = e0.elapsed_time(e1)
         f_ach = ALGO_BYTES[wl["env"]] * n * K / (f_ms * 1e-3) / 1e9
-        fused = {"path": "rollout (one launch, K fused steps)", "kernel": "cge::snake::rollout_kernel<10, 256, 1, 8>",
+        fused = {"path": "rollout (one launch, K fused steps)", "kernel": KERNELS[(wl["env"], "rollout")],
                  "env_steps_per_s_per_gpu": n * K / (f_ms * 1e-3), "us_per_step": f_ms * 1e3 / K,
                  "roofline": {"bound": "hbm", "achieved": f_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": f_ach / HBM_PEAK_GBS}}
@@ -194,7 +242,7 @@ def main():
             "metric": "env steps/sec (whole node) at 1M parallel envs; achieved HBM GB/s vs peak",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": wall_max * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "i8", "data": "synthetic",
+            "dtype": DTYPE[wl["env"]], "data": "synthetic",
             "config": {"workload": f"{args.workload}: {wl['desc']}", "envs_per_gpu": n, "path": args.path,
                        "autoreset": "SameStep", "parallelism": f"env-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -205,7 +253,7 @@ def main():
         if fused is not None:
             out["fused_rollout"] = fused
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_snake(wl["grid"])
+            out["cpu_baseline"] = cpu_baseline_snake(wl["grid"]) if wl["env"] == "snake" else cpu_baseline_crypto()
         print(json.dumps(out), flush=True)
     env.close()
     if dist is not None:
