@@ -87,6 +87,18 @@ def _declare(L):
     L.orc_crypto_get_state.argtypes = [vp, vp]
     L.orc_crypto_set_state.argtypes = [vp, vp]
 
+    L.orc_traffic_create.argtypes = [i64, i32]; L.orc_traffic_create.restype = vp
+    L.orc_traffic_destroy.argtypes = [vp]
+    L.orc_traffic_seed.argtypes = [vp, vp]
+    L.orc_traffic_reset.argtypes = [vp, vp, vp]
+    L.orc_traffic_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.orc_traffic_rollout.argtypes = [vp, i32, u64, i64, i64, vp, vp, vp]
+    L.orc_traffic_info.argtypes = [vp, i32, i32, vp]
+    L.orc_traffic_total_reward.argtypes = [vp, vp]
+    L.orc_traffic_state_bytes.argtypes = []; L.orc_traffic_state_bytes.restype = C.c_size_t
+    L.orc_traffic_get_state.argtypes = [vp, vp]
+    L.orc_traffic_set_state.argtypes = [vp, vp]
+
 
 NEXT_STEP, SAME_STEP, DISABLED = 0, 1, 2
 
@@ -254,3 +266,74 @@ class CryptoOracle:
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
         assert buf.shape == (self.n, lib().orc_crypto_state_bytes())
         lib().orc_crypto_set_state(self.h, _p(buf))
+
+
+TRAFFIC_OBS = 130
+TRAFFIC_INFO = {"timestep": 0, "num_vehicles": 1, "light_phase": 2, "light_timer": 3, "vehicles_passed": 4,
+                "total_waiting_time": 5, "queue_len": 6, "queue_dest": 7, "queue_wait": 8, "episodes": 9, "needs_reset": 10}
+
+
+class TrafficOracle:
+    """Batch of independent TrafficManagementEnv restatements (oracle/orc_traffic.c)."""
+
+    def __init__(self, n, mode=SAME_STEP):
+        self.n, self.mode = int(n), int(mode)
+        self.h = lib().orc_traffic_create(self.n, self.mode)
+        if not self.h:
+            raise ValueError("orc_traffic_create failed")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_traffic_destroy(self.h)
+            self.h = None
+
+    def seed(self, seeds):
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        assert seeds.shape == (self.n,)
+        lib().orc_traffic_seed(self.h, _p(seeds))
+
+    def reset(self, mask=None):
+        obs = np.zeros((self.n, TRAFFIC_OBS), np.float32)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        lib().orc_traffic_reset(self.h, _p(m), _p(obs))
+        return obs
+
+    def step(self, actions, want_final=False):
+        a = np.ascontiguousarray(actions, dtype=np.int32)
+        assert a.shape == (self.n, 9)
+        obs = np.zeros((self.n, TRAFFIC_OBS), np.float32)
+        rew = np.zeros(self.n, np.float32)
+        rew64 = np.zeros(self.n, np.float64)
+        te = np.zeros(self.n, np.uint8)
+        tr = np.zeros(self.n, np.uint8)
+        fin = np.zeros_like(obs) if want_final else None
+        lib().orc_traffic_step(self.h, _p(a), _p(obs), _p(rew), _p(rew64), _p(te), _p(tr), _p(fin))
+        self.last_reward64 = rew64
+        return (obs, rew, te, tr, fin) if want_final else (obs, rew, te, tr)
+
+    def rollout(self, k, a_seed, t0=0, env0=0, want_obs=True):
+        obs = np.zeros((self.n, TRAFFIC_OBS), np.float32) if want_obs else None
+        rs = np.zeros(self.n, np.float64)
+        dc = np.zeros(self.n, np.int32)
+        lib().orc_traffic_rollout(self.h, k, a_seed, t0, env0, _p(obs), _p(rs), _p(dc))
+        return obs, rs, dc
+
+    def info(self, field, idx=0):
+        out = np.zeros(self.n, np.int32)
+        lib().orc_traffic_info(self.h, TRAFFIC_INFO[field] if isinstance(field, str) else field, idx, _p(out))
+        return out
+
+    def total_reward(self):
+        out = np.zeros(self.n, np.float64)
+        lib().orc_traffic_total_reward(self.h, _p(out))
+        return out
+
+    def get_state(self):
+        buf = np.zeros((self.n, lib().orc_traffic_state_bytes()), np.uint8)
+        lib().orc_traffic_get_state(self.h, _p(buf))
+        return buf
+
+    def set_state(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        assert buf.shape == (self.n, lib().orc_traffic_state_bytes())
+        lib().orc_traffic_set_state(self.h, _p(buf))
