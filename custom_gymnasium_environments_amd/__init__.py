@@ -5,6 +5,7 @@ from ._native import NativeLibraryError, lib as native_lib  # noqa: F401
 from .vector_env import AutoresetMode, DeviceVectorEnv  # noqa: F401
 from .snake import SnakeVectorEnv  # noqa: F401
 from .crypto import CryptoVectorEnv  # noqa: F401
+from .traffic import TrafficVectorEnv  # noqa: F401
 
-__all__ = ["SnakeVectorEnv", "CryptoVectorEnv", "AutoresetMode", "DeviceVectorEnv", "NativeLibraryError", "native_lib"]
+__all__ = ["SnakeVectorEnv", "CryptoVectorEnv", "TrafficVectorEnv", "AutoresetMode", "DeviceVectorEnv", "NativeLibraryError", "native_lib"]
 __version__ = "0.1.0"

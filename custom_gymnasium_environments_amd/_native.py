@@ -31,6 +31,12 @@ class CryptoConfig(C.Structure):
                 ("autoreset_mode", C.c_int32), ("reserved", C.c_int32)]
 
 
+class TrafficConfig(C.Structure):
+    _fields_ = [("grid_rows", C.c_int32), ("grid_cols", C.c_int32), ("num_intersections", C.c_int32),
+                ("max_vehicles", C.c_int32), ("spawn_rate", C.c_double), ("max_steps", C.c_int32),
+                ("autoreset_mode", C.c_int32)]
+
+
 # name -> (restype, argtypes); also the list tests check against include/cge_amd.h
 _vp, _i32, _i64, _u32, _u64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_size_t
 SIGNATURES = {
@@ -62,6 +68,20 @@ SIGNATURES = {
     "cge_crypto_set_state": (C.c_int, [_vp, _vp, _vp]),
     "cge_crypto_device_bytes": (_sz, [_vp]),
     "cge_crypto_last_error": (C.c_char_p, [_vp]),
+    "cge_traffic_default_config": (None, [C.POINTER(TrafficConfig)]),
+    "cge_traffic_create": (C.c_int, [C.POINTER(TrafficConfig), _i64, C.c_int, _i64, C.POINTER(_vp)]),
+    "cge_traffic_destroy": (C.c_int, [_vp]),
+    "cge_traffic_seed": (C.c_int, [_vp, _vp, _u64, _vp]),
+    "cge_traffic_reset": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "cge_traffic_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cge_traffic_rollout": (C.c_int, [_vp, _i32, _vp, _u64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "cge_traffic_info": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    "cge_traffic_total_reward": (C.c_int, [_vp, _vp, _vp]),
+    "cge_traffic_state_bytes": (_sz, [_vp]),
+    "cge_traffic_get_state": (C.c_int, [_vp, _vp, _vp]),
+    "cge_traffic_set_state": (C.c_int, [_vp, _vp, _vp]),
+    "cge_traffic_device_bytes": (_sz, [_vp]),
+    "cge_traffic_last_error": (C.c_char_p, [_vp]),
 }
 
 _lib = None

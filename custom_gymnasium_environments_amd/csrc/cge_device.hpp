@@ -132,6 +132,58 @@ struct MtWindow {
     }
 };
 
+// Draw queue for envs whose draw COUNT per step is data dependent (traffic: lights, spawn, routes): the
+// window's twisted words are parked in the lane's own LDS row, where a per-lane cursor can index them
+// natively (a runtime-indexed register array would go to scratch).  `row` must hold W dwords; give rows an
+// odd stride so the 64 lanes' rows start in different banks.  flush() writes back only consumed words.
+template <int W>
+struct LdsDraws {
+    uint32_t *row;
+    uint32_t *blk;
+    uint32_t pos, pretw, cur;
+    bool filled;
+
+    __device__ __forceinline__ LdsDraws(uint32_t *lds_row, uint32_t *block, uint32_t pos_, uint32_t pretw_)
+        : row(lds_row), blk(block), pos(pos_), pretw(pretw_), cur(0), filled(false) {}
+    __device__ __forceinline__ void fill() {
+        MtWindow<W> w;
+        w.load(blk, pos);
+#pragma unroll
+        for (int j = 0; j < W; ++j) row[j] = w.twisted(j, pos, pretw);
+        cur = 0;
+        filled = true;
+    }
+    __device__ __forceinline__ void flush() {
+        if (!filled) return;
+        for (uint32_t j = 0; j < cur; ++j) {
+            uint32_t k = pos + j;
+            if (k >= pretw) {
+                k -= k >= (uint32_t)MT_N ? MT_N : 0;
+                blk[k] = row[j];
+            }
+        }
+        uint32_t p = pos + cur;
+        if (p >= (uint32_t)MT_N) { p -= MT_N; pretw = 0; }
+        pos = p;
+        cur = 0;
+        filled = false;
+    }
+    __device__ __forceinline__ uint32_t next() {
+        if (!filled) fill();
+        else if (cur == (uint32_t)W) { flush(); fill(); }
+        return mt_temper(row[cur++]);
+    }
+    __device__ __forceinline__ uint32_t randbelow(uint32_t n, int kbits) {   // CPython _randbelow_with_getrandbits
+        uint32_t r = next() >> (32 - kbits);
+        while (r >= n) r = next() >> (32 - kbits);
+        return r;
+    }
+    __device__ __forceinline__ double random53() {
+        const uint32_t a = next() >> 5, b = next() >> 6;
+        return (a * 67108864.0 + b) / 9007199254740992.0;
+    }
+};
+
 // ------------------------------------------------------------------ small register arrays
 // Runtime-indexed register arrays go to scratch on hipcc; these helpers keep every index static
 // (fully unrolled select chains) so the env state stays in VGPRs.

@@ -1,0 +1,128 @@
+"""TrafficVectorEnv — batched drop-in for TrafficManagementEnv (traffic_management_env/environment.py:31-384)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native
+from ._spaces import Box, MultiDiscrete, batch_space
+from .vector_env import DeviceVectorEnv
+
+INFO_FIELDS = {"timestep": 0, "num_vehicles": 1, "light_phase": 2, "light_timer": 3, "vehicles_passed": 4,
+               "total_waiting_time": 5, "queue_len": 6, "queue_dest": 7, "queue_wait": 8, "episodes": 9, "needs_reset": 10}
+LIGHT_PHASES = ("NS_GREEN", "NS_YELLOW", "EW_GREEN", "EW_YELLOW")   # config.py:17
+OBS_DIM = 130
+
+
+class TrafficVectorEnv(DeviceVectorEnv):
+    """N independent TrafficManagementEnv instances (default 5x5 grid, 9 controlled intersections) stepped by
+    one HIP kernel launch.
+
+    Spaces as the reference (environment.py:111-130): actions `MultiDiscrete([3]*9)` (0 maintain, 1 switch to
+    NS_GREEN, 2 switch to EW_GREEN), obs `Box(0, inf, (130,), float32)`; reward is the reference's cumulative
+    expression (:287-311) returned as float32; terminated when timestep >= 1000; truncated always False.
+    Bit-exact with the reference (integer state, float64 reward, float32 obs).  `reset(seed=s)` gives env i
+    the private stream `random.seed(s + env_index0 + i)` (:145-146).
+    """
+
+    _abi = "cge_traffic"
+    metadata = {"render_modes": []}
+
+    def __init__(self, num_envs, device="cuda:0", autoreset_mode="NextStep", env_index0=0, grid_size=(5, 5),
+                 num_intersections=9, max_vehicles=50, spawn_rate=0.3, max_steps=1000, reuse_buffers=False, info_fields=()):
+        self._init_common(num_envs, device, autoreset_mode, env_index0, reuse_buffers)
+        cfg = _native.TrafficConfig()
+        self._lib.cge_traffic_default_config(C.byref(cfg))
+        cfg.grid_rows, cfg.grid_cols = int(grid_size[0]), int(grid_size[1])
+        cfg.num_intersections = int(num_intersections)
+        cfg.max_vehicles, cfg.spawn_rate, cfg.max_steps = int(max_vehicles), float(spawn_rate), int(max_steps)
+        cfg.autoreset_mode = self._mode_code
+        self.single_action_space = MultiDiscrete([3] * 9)
+        self.single_observation_space = Box(0.0, np.inf, (OBS_DIM,), np.float32)
+        self.action_space = batch_space(self.single_action_space, self.num_envs)
+        self.observation_space = batch_space(self.single_observation_space, self.num_envs)
+        self.info_fields = tuple(info_fields)
+        h = C.c_void_p()
+        st = self._lib.cge_traffic_create(C.byref(cfg), self.num_envs, self._dev_index, self.env_index0, C.byref(h))
+        if st == -3:
+            raise ValueError("only the reference's default layout (grid_size=(5,5), num_intersections=9) is compiled in")
+        _native.check(st, what="cge_traffic_create")
+        self._h = h
+        self._obs_shape = (self.num_envs, OBS_DIM)
+
+    def reset(self, *, seed=None, options=None):
+        self._seed_native(seed)
+        mask = None
+        if options and options.get("reset_mask") is not None:
+            mask = self._as_device(options["reset_mask"], torch.uint8, (self.num_envs,), "reset_mask")
+        obs = self._out("obs", self._obs_shape, torch.float32)
+        self._check(self._lib.cge_traffic_reset(self._h, mask.data_ptr() if mask is not None else None, obs.data_ptr(),
+                                                self._stream()), "reset")
+        return obs, self._infos()
+
+    def step(self, actions):
+        a = self._as_device(actions, torch.int32, (self.num_envs, 9), "actions")
+        obs = self._out("obs", self._obs_shape, torch.float32)
+        rew = self._out("reward", (self.num_envs,), torch.float32)
+        term = self._out("terminated", (self.num_envs,), torch.bool)
+        trunc = self._bufs.get("_truncated")
+        if trunc is None:
+            trunc = self._bufs["_truncated"] = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
+        same = self._mode_code == _native.AUTORESET_SAME_STEP
+        fin = self._out("final_obs", self._obs_shape, torch.float32) if same else None
+        self._check(self._lib.cge_traffic_step(self._h, a.data_ptr(), obs.data_ptr(), rew.data_ptr(), term.data_ptr(), None,
+                                               fin.data_ptr() if same else None, self._stream()), "step")
+        infos = self._infos()
+        if same:
+            infos["final_obs"] = fin
+            infos["_final_obs"] = term
+        return obs, rew, term, trunc, infos
+
+    def rollout(self, k_steps, actions=None, action_seed=0, t0=0, trajectory=False, want_obs=True, per_step=False):
+        """k fused step()s in one launch; see SnakeVectorEnv.rollout.  reward_sum is float64."""
+        k = int(k_steps)
+        a = None if actions is None else self._as_device(actions, torch.int32, (k, self.num_envs, 9), "actions")
+        obs, stride = None, 0
+        if want_obs:
+            if trajectory:
+                obs = self._out("traj", (k,) + self._obs_shape, torch.float32)
+                stride = self.num_envs * OBS_DIM
+            else:
+                obs = self._out("obs", self._obs_shape, torch.float32)
+        rs = self._out("reward_sum", (self.num_envs,), torch.float64)
+        dc = self._out("done_count", (self.num_envs,), torch.int32)
+        rt = tt = None
+        if per_step:
+            rt = self._out("reward_traj", (k, self.num_envs), torch.float32)
+            tt = self._out("terminated_traj", (k, self.num_envs), torch.bool)
+        self._check(self._lib.cge_traffic_rollout(self._h, k, a.data_ptr() if a is not None else None, int(action_seed), int(t0),
+                                                  obs.data_ptr() if obs is not None else None, stride,
+                                                  rt.data_ptr() if per_step else None, tt.data_ptr() if per_step else None,
+                                                  rs.data_ptr(), dc.data_ptr(), self._stream()), "rollout")
+        return (obs, rt, tt, rs, dc) if per_step else (obs, rs, dc)
+
+    def info(self, field, index=0):
+        out = torch.empty(self.num_envs, dtype=torch.int32, device=self.device)
+        self._check(self._lib.cge_traffic_info(self._h, INFO_FIELDS[field], int(index), out.data_ptr(), self._stream()), "info")
+        return out
+
+    def total_reward(self):
+        out = torch.empty(self.num_envs, dtype=torch.float64, device=self.device)
+        self._check(self._lib.cge_traffic_total_reward(self._h, out.data_ptr(), self._stream()), "total_reward")
+        return out
+
+    def _infos(self):
+        return {f: self.info(f) for f in self.info_fields}
+
+    def get_state(self):
+        rec = int(self._lib.cge_traffic_state_bytes(self._h))
+        buf = np.zeros((self.num_envs, rec), np.uint8)
+        self._check(self._lib.cge_traffic_get_state(self._h, buf.ctypes.data, self._stream()), "get_state")
+        return buf
+
+    def set_state(self, buf):
+        rec = int(self._lib.cge_traffic_state_bytes(self._h))
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        if buf.shape != (self.num_envs, rec):
+            raise ValueError(f"state buffer must be uint8 {(self.num_envs, rec)}")
+        self._check(self._lib.cge_traffic_set_state(self._h, buf.ctypes.data, self._stream()), "set_state")

@@ -194,6 +194,67 @@ int cge_crypto_set_state(cge_crypto *h, const void *host_buf, void *stream);
 size_t cge_crypto_device_bytes(const cge_crypto *h);
 const char *cge_crypto_last_error(const cge_crypto *h);
 
+/* ------------------------------------------------------------------------------------------ */
+/* Traffic  (traffic_management_env/environment.py: TrafficManagementEnv, utils.py, config.py)  */
+/*   obs float32 (130,) (:313-363)   action int32[9] in {0 maintain,1 NS_GREEN,2 EW_GREEN}       */
+/*   State is the collapsed form of SURVEY.md 8a (queue length / waiting sum / arrivals-at-      */
+/*   destination per queue, counters per intersection, vehicle count): _update_vehicles          */
+/*   (:251-269) never moves a vehicle, so nothing else is observable.  Bit-exact: integer state,  */
+/*   float64 reward arithmetic in the reference's order, float32 obs from float64 quotients.     */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct cge_traffic cge_traffic;
+
+typedef struct {                 /* TrafficManagementEnv.__init__ kwargs (:61-66) + config.py */
+    int32_t grid_rows, grid_cols;    /* (5, 5) — the only grid compiled in */
+    int32_t num_intersections;       /* 9 */
+    int32_t max_vehicles;            /* 50; <= 63 and max_vehicles*max_steps <= 65535 */
+    double spawn_rate;               /* 0.3 */
+    int32_t max_steps;               /* MAX_TIMESTEPS = 1000 */
+    int32_t autoreset_mode;          /* CGE_AUTORESET_* */
+} cge_traffic_config;
+
+enum { /* cge_traffic_info field ids (int32 per env; `index` selects the intersection 0..8 or queue 0..35 = 4*i+dir) */
+    CGE_TRAFFIC_INFO_TIMESTEP = 0,
+    CGE_TRAFFIC_INFO_NUM_VEHICLES = 1,
+    CGE_TRAFFIC_INFO_LIGHT_PHASE = 2,       /* 0 NS_GREEN 1 NS_YELLOW 2 EW_GREEN 3 EW_YELLOW */
+    CGE_TRAFFIC_INFO_LIGHT_TIMER = 3,
+    CGE_TRAFFIC_INFO_VEHICLES_PASSED = 4,
+    CGE_TRAFFIC_INFO_TOTAL_WAITING_TIME = 5,
+    CGE_TRAFFIC_INFO_QUEUE_LEN = 6,         /* dir order NORTH, EAST, SOUTH, WEST (utils.py:17-22) */
+    CGE_TRAFFIC_INFO_QUEUE_DEST = 7,
+    CGE_TRAFFIC_INFO_QUEUE_WAIT = 8,
+    CGE_TRAFFIC_INFO_EPISODES = 9,
+    CGE_TRAFFIC_INFO_NEEDS_RESET = 10
+};
+
+void cge_traffic_default_config(cge_traffic_config *cfg);
+int cge_traffic_create(const cge_traffic_config *cfg, int64_t n_envs, int device, int64_t env_index0,
+                       cge_traffic **out);
+int cge_traffic_destroy(cge_traffic *h);
+/* reset(seed=s) seeding (:145-147): random.seed(s_i); the NumPy generator it also seeds is never drawn from */
+int cge_traffic_seed(cge_traffic *h, const uint64_t *seeds, uint64_t base_seed, void *stream);
+int cge_traffic_reset(cge_traffic *h, const uint8_t *mask, float *obs_out, void *stream);
+/* actions: int32 [n_envs, 9]; values other than 1/2 maintain the phase, as in the reference (:214-220) */
+int cge_traffic_step(cge_traffic *h, const int32_t *actions, float *obs_out, float *reward_out,
+                     uint8_t *terminated_out, uint8_t *truncated_out /*nullable*/, float *final_obs_out,
+                     void *stream);
+/* k fused steps; actions [k, n_envs, 9] or NULL -> cge_hash_action(seed, env, t, 3, j) for intersection j */
+int cge_traffic_rollout(cge_traffic *h, int32_t k_steps, const int32_t *actions, uint64_t action_seed, int64_t t0,
+                        float *obs_out, int64_t obs_step_stride, float *reward_traj_out,
+                        uint8_t *terminated_traj_out, double *reward_sum_out, int32_t *done_count_out,
+                        void *stream);
+int cge_traffic_info(cge_traffic *h, int32_t field_id, int32_t index, int32_t *out, void *stream);
+/* info['total_reward'] (:372): float64 running sum of the episode's rewards */
+int cge_traffic_total_reward(cge_traffic *h, double *out, void *stream);
+/* canonical record (host), identical to the oracle's: int32[6] {timestep, n_vehicles, needs_reset, mt_idx,
+ * episodes, 0}; double total_reward; int32 phase[9], timer[9], passed[9], total_wait[9], qlen[36], qdest[36],
+ * qwait[36]; uint32 mt[624]. */
+size_t cge_traffic_state_bytes(const cge_traffic *h);
+int cge_traffic_get_state(cge_traffic *h, void *host_buf, void *stream);
+int cge_traffic_set_state(cge_traffic *h, const void *host_buf, void *stream);
+size_t cge_traffic_device_bytes(const cge_traffic *h);
+const char *cge_traffic_last_error(const cge_traffic *h);
+
 #ifdef __cplusplus
 }
 #endif

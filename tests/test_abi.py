@@ -17,7 +17,7 @@ def _declared():
 
 def test_header_declares_the_full_per_env_surface():
     names = _declared()
-    for env in ["snake", "crypto"]:
+    for env in ["snake", "crypto", "traffic"]:
         for fn in ["create", "destroy", "seed", "reset", "step", "rollout", "info", "state_bytes", "get_state",
                    "set_state", "last_error", "device_bytes"]:
             assert f"cge_{env}_{fn}" in names, (env, fn)
