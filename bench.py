@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 # algorithmic bytes per env-step, SURVEY.md section 8d
-ALGO_BYTES = {"snake": 145, "crypto": 2346}
+ALGO_BYTES = {"snake": 145, "crypto": 2346, "traffic": 1134}
 WORKLOADS = {
     "snake_1m": dict(env="snake", n_per_gpu=1 << 20, grid=10,
                      desc="SnakeEnv 10x10, 1,048,576 parallel envs per GPU, random actions, fused auto-reset"),
@@ -34,10 +34,13 @@ WORKLOADS = {
     "crypto_1m": dict(env="crypto", n_per_gpu=1 << 20,
                       desc="crypto_trading_env discrete, 1,048,576 parallel envs per GPU, random actions, fused auto-reset"),
 }
+WORKLOADS["traffic_262k"] = dict(env="traffic", n_per_gpu=1 << 18,
+                                 desc="traffic_management_env (9 intersections), 262,144 parallel envs per GPU, random actions, fused auto-reset")
 KERNELS = {("snake", "step"): "cge::snake::step_kernel<10, 256, 1, 8>", ("snake", "rollout"): "cge::snake::rollout_kernel<10, 256, 1, 8>",
-           ("crypto", "step"): "cge::crypto::step_kernel<false>", ("crypto", "rollout"): "cge::crypto::step_kernel<true>"}
-N_ACTIONS = {"snake": 4, "crypto": 5}
-DTYPE = {"snake": "i8", "crypto": "f64"}
+           ("crypto", "step"): "cge::crypto::step_kernel<false>", ("crypto", "rollout"): "cge::crypto::step_kernel<true>",
+           ("traffic", "step"): "cge::traffic::step_kernel<false>", ("traffic", "rollout"): "cge::traffic::step_kernel<true>"}
+N_ACTIONS = {"snake": 4, "crypto": 5, "traffic": 3}
+DTYPE = {"snake": "i8", "crypto": "f64", "traffic": "int32"}
 
 
 def cpu_baseline_snake(grid, budget_s=12.0):
@@ -121,6 +124,44 @@ def cpu_baseline_crypto(budget_s=12.0):
                 reference_python_note="reference Python in the build container: 1.64e3-1.68e3 steps/s/process (BASELINE.md section 2)")
 
 
+def cpu_baseline_traffic(budget_s=12.0):
+    import oracle
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
+    n_each, k = 1024, 100
+    o = oracle.TrafficOracle(n_each, oracle.SAME_STEP)
+    o.reset()
+    t = time.perf_counter()
+    o.rollout(k, 123, 0, 0)
+    one = time.perf_counter() - t
+    reps = max(1, min(int(budget_s / max(one, 1e-3)), 2000))
+    handles = []
+    for c in range(cores):
+        h = oracle.TrafficOracle(n_each, oracle.SAME_STEP)
+        h.seed(np.arange(c * n_each, (c + 1) * n_each, dtype=np.uint64))
+        h.reset()
+        handles.append(h)
+
+    def work(c):
+        for r in range(reps):
+            handles[c].rollout(k, 123, r * k, c * n_each)
+
+    th = [threading.Thread(target=work, args=(c,)) for c in range(cores)]
+    t = time.perf_counter()
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    dt = time.perf_counter() - t
+    return dict(value=cores * reps * n_each * k / dt, unit="env-steps/s", cores=cores, kind="port",
+                sample=f"{cores} threads x {n_each} envs x {reps * k} steps (hash actions, auto-reset, obs assembled every step), "
+                       f"oracle/orc_traffic.c (collapsed state, no O(V*I) sqrt loop); single-core rate {n_each * k / one:.3e}",
+                reference_python_note="reference Python in the build container: 1.75e3-1.90e3 steps/s/process (BASELINE.md section 2)")
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
     tools_profile_summary.py: 2*FETCH_SIZE + WRITE_SIZE, the gfx950 read-side correction of
@@ -167,12 +208,15 @@ def main():
     if wl["env"] == "snake":
         env = cge.SnakeVectorEnv(n, grid_size=wl["grid"], device=dev, autoreset_mode="SameStep", env_index0=rank * n,
                                  reuse_buffers=True)
-    else:
+    elif wl["env"] == "crypto":
         env = cge.CryptoVectorEnv(n, action_type="discrete", device=dev, autoreset_mode="SameStep", env_index0=rank * n,
                                   reuse_buffers=True)
+    else:
+        env = cge.TrafficVectorEnv(n, device=dev, autoreset_mode="SameStep", env_index0=rank * n, reuse_buffers=True)
     env.reset(seed=0)
     # synthetic action stream, resident in HBM before timing
-    actions = torch.randint(0, N_ACTIONS[wl["env"]], (K + W, n), dtype=torch.int32, device=dev)
+    ashape = (K + W, n, 9) if wl["env"] == "traffic" else (K + W, n)
+    actions = torch.randint(0, N_ACTIONS[wl["env"]], ashape, dtype=torch.int32, device=dev)
 
     def barrier():
         torch.cuda.synchronize()
@@ -253,7 +297,8 @@ def main():
         if fused is not None:
             out["fused_rollout"] = fused
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_snake(wl["grid"]) if wl["env"] == "snake" else cpu_baseline_crypto()
+            out["cpu_baseline"] = (cpu_baseline_snake(wl["grid"]) if wl["env"] == "snake" else
+                                   cpu_baseline_crypto() if wl["env"] == "crypto" else cpu_baseline_traffic())
         print(json.dumps(out), flush=True)
     env.close()
     if dist is not None:
