@@ -99,6 +99,15 @@ def _declare(L):
     L.orc_traffic_get_state.argtypes = [vp, vp]
     L.orc_traffic_set_state.argtypes = [vp, vp]
 
+    L.orc_parking_create.argtypes = [i64, i32]; L.orc_parking_create.restype = vp
+    L.orc_parking_destroy.argtypes = [vp]
+    L.orc_parking_seed.argtypes = [vp, vp]
+    L.orc_parking_reset.argtypes = [vp, vp, vp]
+    L.orc_parking_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.orc_parking_rollout.argtypes = [vp, i32, u64, i64, i64, vp, vp, vp]
+    L.orc_parking_info.argtypes = [vp, i32, i32, vp]
+    L.orc_parking_info64.argtypes = [vp, i32, vp]
+
 
 NEXT_STEP, SAME_STEP, DISABLED = 0, 1, 2
 
@@ -337,3 +346,69 @@ class TrafficOracle:
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
         assert buf.shape == (self.n, lib().orc_traffic_state_bytes())
         lib().orc_traffic_set_state(self.h, _p(buf))
+
+
+PARKING_OBS = 13
+PARKING_INFO = {"timestep": 0, "total_customers": 1, "rejected": 2, "satisfied": 3, "total_wait_time": 4, "queue_length": 5,
+                "price_changes_this_hour": 6, "zone_occupied": 7, "price_level": 8, "episodes": 9, "needs_reset": 10}
+
+
+class _SimpleOracle:
+    """Shared ctypes plumbing for the small discrete-action envs (int32 action per env, float32 obs)."""
+    _name = None
+    _obs = None
+    _nact = None
+
+    def __init__(self, n, mode=SAME_STEP):
+        self.n, self.mode = int(n), int(mode)
+        self.h = getattr(lib(), f"orc_{self._name}_create")(self.n, self.mode)
+        if not self.h:
+            raise ValueError("create failed")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            getattr(lib(), f"orc_{self._name}_destroy")(self.h)
+            self.h = None
+
+    def seed(self, seeds):
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        assert seeds.shape == (self.n,)
+        getattr(lib(), f"orc_{self._name}_seed")(self.h, _p(seeds))
+
+    def reset(self, mask=None):
+        obs = np.zeros((self.n, self._obs), np.float32)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        getattr(lib(), f"orc_{self._name}_reset")(self.h, _p(m), _p(obs))
+        return obs
+
+    def step(self, actions, want_final=False):
+        a = np.ascontiguousarray(actions, dtype=np.int32)
+        assert a.shape == (self.n,)
+        obs = np.zeros((self.n, self._obs), np.float32)
+        rew = np.zeros(self.n, np.float32); rew64 = np.zeros(self.n, np.float64)
+        te = np.zeros(self.n, np.uint8); tr = np.zeros(self.n, np.uint8)
+        fin = np.zeros_like(obs) if want_final else None
+        getattr(lib(), f"orc_{self._name}_step")(self.h, _p(a), _p(obs), _p(rew), _p(rew64), _p(te), _p(tr), _p(fin))
+        self.last_reward64 = rew64
+        return (obs, rew, te, tr, fin) if want_final else (obs, rew, te, tr)
+
+    def rollout(self, k, a_seed, t0=0, env0=0, want_obs=True):
+        obs = np.zeros((self.n, self._obs), np.float32) if want_obs else None
+        rs = np.zeros(self.n, np.float64); dc = np.zeros(self.n, np.int32)
+        getattr(lib(), f"orc_{self._name}_rollout")(self.h, k, a_seed, t0, env0, _p(obs), _p(rs), _p(dc))
+        return obs, rs, dc
+
+
+class ParkingOracle(_SimpleOracle):
+    """Batch of independent SmartParkingEnv restatements (oracle/orc_parking.c)."""
+    _name, _obs, _nact = "parking", PARKING_OBS, 8
+
+    def info(self, field, idx=0):
+        out = np.zeros(self.n, np.int32)
+        lib().orc_parking_info(self.h, PARKING_INFO[field], idx, _p(out))
+        return out
+
+    def info64(self, field):
+        out = np.zeros(self.n, np.float64)
+        lib().orc_parking_info64(self.h, {"episode_revenue": 0, "episode_satisfaction": 1}[field], _p(out))
+        return out
