@@ -37,6 +37,10 @@ class TrafficConfig(C.Structure):
                 ("autoreset_mode", C.c_int32)]
 
 
+class ParkingConfig(C.Structure):
+    _fields_ = [("max_steps", C.c_int32), ("autoreset_mode", C.c_int32)]
+
+
 # name -> (restype, argtypes); also the list tests check against include/cge_amd.h
 _vp, _i32, _i64, _u32, _u64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_size_t
 SIGNATURES = {
@@ -82,6 +86,16 @@ SIGNATURES = {
     "cge_traffic_set_state": (C.c_int, [_vp, _vp, _vp]),
     "cge_traffic_device_bytes": (_sz, [_vp]),
     "cge_traffic_last_error": (C.c_char_p, [_vp]),
+    "cge_parking_create": (C.c_int, [C.POINTER(ParkingConfig), _i64, C.c_int, _i64, C.POINTER(_vp)]),
+    "cge_parking_destroy": (C.c_int, [_vp]),
+    "cge_parking_seed": (C.c_int, [_vp, _vp, _u64, _vp]),
+    "cge_parking_reset": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "cge_parking_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cge_parking_rollout": (C.c_int, [_vp, _i32, _vp, _u64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "cge_parking_info": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    "cge_parking_info64": (C.c_int, [_vp, _i32, _vp, _vp]),
+    "cge_parking_device_bytes": (_sz, [_vp]),
+    "cge_parking_last_error": (C.c_char_p, [_vp]),
 }
 
 _lib = None

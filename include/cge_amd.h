@@ -255,6 +255,52 @@ int cge_traffic_set_state(cge_traffic *h, const void *host_buf, void *stream);
 size_t cge_traffic_device_bytes(const cge_traffic *h);
 const char *cge_traffic_last_error(const cge_traffic *h);
 
+/* ------------------------------------------------------------------------------------------ */
+/* Smart parking  (smart_parking_env/core/parking_env.py: SmartParkingEnv + customer/parking_lot/pricing) */
+/*   obs float32 (13,) in [0,1] (:306-369)   action int32 in 0..7 (:161-195)   1440 one-minute steps     */
+/*   Bit-exact: integer state, float64 price/satisfaction/reward arithmetic in the reference's order.   */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct cge_parking cge_parking;
+
+typedef struct {
+    int32_t max_steps;        /* TIMESTEPS_PER_EPISODE = 1440 (config.py:15); <= 60000 */
+    int32_t autoreset_mode;   /* CGE_AUTORESET_* */
+} cge_parking_config;
+
+enum { /* cge_parking_info int32 fields (`index` = zone 0..2 where noted) — the counters behind _get_info (:371-399) */
+    CGE_PARKING_INFO_TIMESTEP = 0,
+    CGE_PARKING_INFO_TOTAL_CUSTOMERS = 1,
+    CGE_PARKING_INFO_REJECTED = 2,
+    CGE_PARKING_INFO_SATISFIED = 3,
+    CGE_PARKING_INFO_TOTAL_WAIT_TIME = 4,
+    CGE_PARKING_INFO_QUEUE_LENGTH = 5,
+    CGE_PARKING_INFO_PRICE_CHANGES_THIS_HOUR = 6,
+    CGE_PARKING_INFO_ZONE_OCCUPIED = 7,   /* index = zone */
+    CGE_PARKING_INFO_PRICE_LEVEL = 8,     /* index = zone */
+    CGE_PARKING_INFO_EPISODES = 9,
+    CGE_PARKING_INFO_NEEDS_RESET = 10
+};
+enum { CGE_PARKING_INFO64_EPISODE_REVENUE = 0, CGE_PARKING_INFO64_EPISODE_SATISFACTION = 1 };
+
+int cge_parking_create(const cge_parking_config *cfg, int64_t n_envs, int device, int64_t env_index0,
+                       cge_parking **out);
+int cge_parking_destroy(cge_parking *h);
+/* the env never seeds `random` (parking_env.py:81): env i's private stream := random.seed(s_i), as for snake */
+int cge_parking_seed(cge_parking *h, const uint64_t *seeds, uint64_t base_seed, void *stream);
+int cge_parking_reset(cge_parking *h, const uint8_t *mask, float *obs_out, void *stream);
+/* actions int32[n_envs]; values outside 0..7 are an idle step, as in the reference (no branch matches) */
+int cge_parking_step(cge_parking *h, const int32_t *actions, float *obs_out, float *reward_out,
+                     uint8_t *terminated_out, uint8_t *truncated_out /*nullable*/, float *final_obs_out,
+                     void *stream);
+int cge_parking_rollout(cge_parking *h, int32_t k_steps, const int32_t *actions, uint64_t action_seed, int64_t t0,
+                        float *obs_out, int64_t obs_step_stride, float *reward_traj_out,
+                        uint8_t *terminated_traj_out, double *reward_sum_out, int32_t *done_count_out,
+                        void *stream);
+int cge_parking_info(cge_parking *h, int32_t field_id, int32_t index, int32_t *out, void *stream);
+int cge_parking_info64(cge_parking *h, int32_t field_id, double *out, void *stream);
+size_t cge_parking_device_bytes(const cge_parking *h);
+const char *cge_parking_last_error(const cge_parking *h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,104 @@
+"""GPU parity tests for the smart-parking hot path (through the C ABI via ParkingVectorEnv): bit-exact obs,
+rewards, flags, counters and float64 accumulators against the reference's golden vectors and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cge():
+    import custom_gymnasium_environments_amd as m
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    m.native_lib()
+    return m
+
+
+def _np(t):
+    return t.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", ["parking_hash.npz", "parking_busy.npz"])
+def test_same_step_matches_reference_fixture(cge, name):
+    fx = golden(name)
+    A = fx["actions"]
+    n, T = A.shape
+    env = cge.ParkingVectorEnv(n, autoreset_mode="SameStep")
+    obs, _ = env.reset(seed=int(fx["seed0"]))
+    assert np.array_equal(_np(obs), fx["obs0"])
+    reset_at = {(int(i), int(t)): k for k, (i, t) in enumerate(fx["reset_index"])}
+    A_dev = torch.from_numpy(A).cuda()
+    for t in range(T):
+        obs, rew, te, tr, info = env.step(A_dev[:, t])
+        obs, rew, te, fin = _np(obs), _np(rew), _np(te), _np(info["final_obs"])
+        assert np.array_equal(te, fx["terminated"][:, t].astype(bool)), t
+        assert np.array_equal(rew, fx["reward"][:, t].astype(np.float32)), (t, rew, fx["reward"][:, t])
+        step_obs = np.where(te[:, None], fin, obs)
+        assert np.array_equal(step_obs.view(np.uint32), fx["obs"][:, t].view(np.uint32)), t
+        for i in np.nonzero(te)[0]:
+            assert np.array_equal(obs[i], fx["reset_obs"][reset_at[(int(i), t)]])
+        if t % 97 == 5:
+            S, live = fx["stats"][:, t], ~te
+            for col, f in enumerate(["total_customers", "rejected", "satisfied", "total_wait_time", "queue_length",
+                                     "price_changes_this_hour", "timestep"]):
+                assert np.array_equal(_np(env.info(f))[live], S[live, col]), (t, f)
+            for z in range(3):
+                assert np.array_equal(_np(env.info("zone_occupied", z))[live], S[live, 7 + z])
+                assert np.array_equal(_np(env.info("price_level", z))[live], S[live, 10 + z])
+            assert np.array_equal(_np(env.info("episode_revenue"))[live], fx["money"][live, t, 0])
+            assert np.array_equal(_np(env.info("episode_satisfaction"))[live], fx["money"][live, t, 1])
+    env.close()
+
+
+@pytest.mark.parametrize("mode", ["NextStep", "SameStep", "Disabled"])
+def test_step_matches_oracle_all_modes(cge, oracle, mode):
+    code = {"NextStep": oracle.NEXT_STEP, "SameStep": oracle.SAME_STEP, "Disabled": oracle.DISABLED}[mode]
+    n, T = 300, 1600
+    env = cge.ParkingVectorEnv(n, autoreset_mode=mode, env_index0=4)
+    o = oracle.ParkingOracle(n, code)
+    o.seed(np.arange(n, dtype=np.uint64) + np.uint64(4 + 60))
+    od, _ = env.reset(seed=60)
+    assert np.array_equal(_np(od), o.reset())
+    rng = np.random.default_rng(6)
+    for t in range(T):
+        a = rng.integers(0, 8, n).astype(np.int32)
+        a[rng.random(n) < 0.5] = rng.integers(1, 4)            # bias toward assignments so the lot fills up
+        od, rd, ted, trd, _ = env.step(a)
+        oo, ro, teo, tro = o.step(a)
+        assert np.array_equal(_np(od).view(np.uint32), oo.view(np.uint32)), t
+        assert np.array_equal(_np(rd), ro) and np.array_equal(_np(ted), teo.astype(bool)), t
+    for f in ["timestep", "total_customers", "rejected", "satisfied", "total_wait_time", "queue_length", "episodes", "needs_reset"]:
+        assert np.array_equal(_np(env.info(f)), o.info(f)), f
+    assert np.array_equal(_np(env.info("episode_revenue")), o.info64("episode_revenue"))
+    assert np.array_equal(_np(env.info("episode_satisfaction")), o.info64("episode_satisfaction"))
+    env.close()
+
+
+def test_rollout_and_config5_size(cge, oracle):
+    """BASELINE config 5 share: 131,072 envs; rollout bit-exact vs the oracle on slices, sharding invariant."""
+    n, T = 1 << 17, 400
+    env = cge.ParkingVectorEnv(n, autoreset_mode="SameStep", reuse_buffers=True)
+    obs, _ = env.reset(seed=0)
+    obs, rs, dc = env.rollout(T, action_seed=123)
+    assert bool(((obs >= 0) & (obs <= 1)).all())
+    for lo in [0, n - 2000]:
+        m = 2000
+        o = oracle.ParkingOracle(m, oracle.SAME_STEP)
+        o.seed(np.arange(lo, lo + m, dtype=np.uint64)); o.reset()
+        oo, ro, do = o.rollout(T, 123, env0=lo)
+        assert np.array_equal(_np(obs[lo:lo + m]), oo) and np.array_equal(_np(rs[lo:lo + m]), ro)
+    half = cge.ParkingVectorEnv(n // 2, autoreset_mode="SameStep", env_index0=n // 2)
+    half.reset(seed=0)
+    oh, rh, dh = half.rollout(T, action_seed=123)
+    assert torch.equal(oh, obs[n // 2:]) and torch.equal(rh, rs[n // 2:])
+    acts = torch.randint(0, 8, (25, n // 2), dtype=torch.int32, device="cuda")
+    twin = cge.ParkingVectorEnv(n // 2, autoreset_mode="SameStep", env_index0=n // 2)
+    twin.reset(seed=0); twin.rollout(T, action_seed=123)
+    traj, rt, tt, rs2, dc2 = half.rollout(25, actions=acts, trajectory=True, per_step=True)
+    for t in range(25):
+        ob, r, te, _, _ = twin.step(acts[t])
+        assert torch.equal(ob, traj[t]) and torch.equal(r, rt[t]) and torch.equal(te, tt[t]), t
+    env.close(); half.close(); twin.close()
