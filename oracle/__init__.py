@@ -63,6 +63,16 @@ def _declare(L):
     L.orc_mt_uniform.argtypes = [vp, dbl, dbl]; L.orc_mt_uniform.restype = dbl
     L.orc_mt_normal.argtypes = [vp, dbl, dbl]; L.orc_mt_normal.restype = dbl
     L.orc_mt_get.argtypes = [vp, vp, vp]
+    L.orc_pcg_new.restype = vp
+    L.orc_pcg_free.argtypes = [vp]
+    L.orc_pcg_seed_export.argtypes = [vp, u64]
+    L.orc_pcg_next64_export.argtypes = [vp]; L.orc_pcg_next64_export.restype = u64
+    L.orc_pcg_random_export.argtypes = [vp]; L.orc_pcg_random_export.restype = dbl
+    L.orc_pcg_uniform_export.argtypes = [vp, dbl, dbl]; L.orc_pcg_uniform_export.restype = dbl
+    L.orc_pcg_integers_export.argtypes = [vp, i64, i64]; L.orc_pcg_integers_export.restype = i64
+    L.orc_pcg_normal_export.argtypes = [vp, dbl, dbl]; L.orc_pcg_normal_export.restype = dbl
+    L.orc_pcg_choice4_export.argtypes = [vp, vp]; L.orc_pcg_choice4_export.restype = i32
+    L.orc_pcg_state_export.argtypes = [vp, vp]
     L.orc_hash_action_export.argtypes = [u64, u64, u64, u32, u32]; L.orc_hash_action_export.restype = u32
 
     L.orc_snake_create.argtypes = [i64, i32, i32]; L.orc_snake_create.restype = vp
@@ -108,6 +118,15 @@ def _declare(L):
     L.orc_parking_info.argtypes = [vp, i32, i32, vp]
     L.orc_parking_info64.argtypes = [vp, i32, vp]
 
+    L.orc_climate_create.argtypes = [i64, i32]; L.orc_climate_create.restype = vp
+    L.orc_climate_destroy.argtypes = [vp]
+    L.orc_climate_seed.argtypes = [vp, vp]
+    L.orc_climate_reset.argtypes = [vp, vp, vp]
+    L.orc_climate_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.orc_climate_rollout.argtypes = [vp, i32, u64, i64, i64, vp, vp, vp]
+    L.orc_climate_info.argtypes = [vp, i32, vp]
+    L.orc_climate_hash_action.argtypes = [u64, u64, u64, vp, vp]
+
 
 NEXT_STEP, SAME_STEP, DISABLED = 0, 1, 2
 
@@ -137,6 +156,34 @@ class MT:
         idx = C.c_int(0)
         lib().orc_mt_get(self.h, _p(mt), C.addressof(idx))
         return mt, idx.value
+
+
+class PCG:
+    """One NumPy-Generator-compatible PCG64 stream (for RNG known answers)."""
+
+    def __init__(self, seed):
+        self.h = lib().orc_pcg_new()
+        lib().orc_pcg_seed_export(self.h, seed)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_pcg_free(self.h)
+            self.h = None
+
+    def next64(self): return lib().orc_pcg_next64_export(self.h)
+    def random(self): return lib().orc_pcg_random_export(self.h)
+    def uniform(self, lo, hi): return lib().orc_pcg_uniform_export(self.h, lo, hi)
+    def integers(self, lo, hi): return lib().orc_pcg_integers_export(self.h, lo, hi)
+    def normal(self, loc, scale): return lib().orc_pcg_normal_export(self.h, loc, scale)
+
+    def choice4(self, p):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        return lib().orc_pcg_choice4_export(self.h, _p(p))
+
+    def state(self):
+        out = np.zeros(4, np.uint64)
+        lib().orc_pcg_state_export(self.h, _p(out))
+        return (int(out[0]) << 64) | int(out[1]), (int(out[2]) << 64) | int(out[3])
 
 
 def hash_action(a_seed, env, t, n, j=0):
@@ -412,3 +459,36 @@ class ParkingOracle(_SimpleOracle):
         out = np.zeros(self.n, np.float64)
         lib().orc_parking_info64(self.h, {"episode_revenue": 0, "episode_satisfaction": 1}[field], _p(out))
         return out
+
+
+CLIMATE_OBS = 9
+CLIMATE_INFO = {"room_temp": 0, "outside_temp": 1, "ac_setting": 2, "energy_usage": 3, "total_reward": 4, "num_people": 5,
+                "step": 6, "comfort_time": 7, "episodes": 8, "needs_reset": 9}
+
+
+class ClimateOracle(_SimpleOracle):
+    """Batch of independent SmartClimateEnv restatements (oracle/orc_climate.c)."""
+    _name, _obs = "climate", CLIMATE_OBS
+
+    def step(self, ac_temp, lights, want_final=False):
+        ac = np.ascontiguousarray(ac_temp, dtype=np.float32).reshape(self.n)
+        li = np.ascontiguousarray(lights, dtype=np.int8)
+        assert li.shape == (self.n, 4)
+        obs = np.zeros((self.n, self._obs), np.float32)
+        rew = np.zeros(self.n, np.float32); rew64 = np.zeros(self.n, np.float64)
+        te = np.zeros(self.n, np.uint8); tr = np.zeros(self.n, np.uint8)
+        fin = np.zeros_like(obs) if want_final else None
+        lib().orc_climate_step(self.h, _p(ac), _p(li), _p(obs), _p(rew), _p(rew64), _p(te), _p(tr), _p(fin))
+        self.last_reward64 = rew64
+        return (obs, rew, te, tr, fin) if want_final else (obs, rew, te, tr)
+
+    def info(self, field):
+        out = np.zeros(self.n, np.float64)
+        lib().orc_climate_info(self.h, CLIMATE_INFO[field], _p(out))
+        return out
+
+    @staticmethod
+    def hash_action(a_seed, env, t):
+        ac = np.zeros(1, np.float32); li = np.zeros(4, np.int8)
+        lib().orc_climate_hash_action(a_seed, env, t, _p(ac), _p(li))
+        return ac[0], li

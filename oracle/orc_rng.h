@@ -153,4 +153,121 @@ static inline uint32_t orc_hash_action(uint64_t a_seed, uint64_t env, uint64_t t
     return (uint32_t)(((u >> 32) * (uint64_t)n) >> 32);
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * Family D/G: NumPy Generator(PCG64(SeedSequence(seed))) — smartclimate/env.py:30,63-65 (default_rng) and
+ * smart_manufacturing_env (gymnasium's self.np_random).  Restated from NumPy's published sources
+ * (bit_generator.pyx SeedSequence, _pcg64.pyx / pcg64.h, distributions.c); pinned against NumPy executed
+ * here (tests/test_oracle_rng.py) and SURVEY 8c's known answers.
+ * ---------------------------------------------------------------------------------------------- */
+#include "orc_zig_tables.h"
+
+typedef unsigned __int128 orc_u128;
+
+typedef struct {
+    orc_u128 state, inc;
+    int has_uint32;
+    uint32_t uinteger;
+} orc_pcg;
+
+static inline uint32_t orc_ss_hashmix(uint32_t value, uint32_t *hash_const) {
+    value ^= *hash_const;
+    *hash_const *= 0x931e8875u;
+    value *= *hash_const;
+    value ^= value >> 16;
+    return value;
+}
+static inline uint32_t orc_ss_mix(uint32_t x, uint32_t y) {
+    uint32_t r = 0xca01f9ddu * x - 0x4973f715u * y;
+    return r ^ (r >> 16);
+}
+/* default_rng(seed): SeedSequence(seed).generate_state(4, uint64) -> pcg64_srandom_r */
+static inline void orc_pcg_seed(orc_pcg *g, uint64_t seed) {
+    uint32_t ent[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    int nent = ent[1] ? 2 : 1;
+    uint32_t pool[4], hc = 0x43b0d7e5u;
+    for (int i = 0; i < 4; ++i) pool[i] = orc_ss_hashmix(i < nent ? ent[i] : 0u, &hc);
+    for (int is = 0; is < 4; ++is)
+        for (int id = 0; id < 4; ++id)
+            if (is != id) pool[id] = orc_ss_mix(pool[id], orc_ss_hashmix(pool[is], &hc));
+    uint32_t w[8], hb = 0x8b51f9ddu;
+    for (int i = 0; i < 8; ++i) {
+        uint32_t v = pool[i % 4];
+        v ^= hb;
+        hb *= 0x58f38dedu;
+        v *= hb;
+        v ^= v >> 16;
+        w[i] = v;
+    }
+    uint64_t q[4];
+    for (int i = 0; i < 4; ++i) q[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+    const orc_u128 mult = ((orc_u128)0x2360ED051FC65DA4ull << 64) | 0x4385DF649FCCF645ull;
+    orc_u128 initstate = ((orc_u128)q[0] << 64) | q[1], initseq = ((orc_u128)q[2] << 64) | q[3];
+    g->inc = (initseq << 1) | 1;
+    g->state = g->inc;                       /* state = 0; step */
+    g->state += initstate;
+    g->state = g->state * mult + g->inc;
+    g->has_uint32 = 0;
+    g->uinteger = 0;
+}
+static inline uint64_t orc_pcg_next64(orc_pcg *g) {
+    const orc_u128 mult = ((orc_u128)0x2360ED051FC65DA4ull << 64) | 0x4385DF649FCCF645ull;
+    g->state = g->state * mult + g->inc;
+    uint64_t hi = (uint64_t)(g->state >> 64), lo = (uint64_t)g->state, x = hi ^ lo;
+    unsigned rot = (unsigned)(g->state >> 122);
+    return (x >> rot) | (x << ((64 - rot) & 63));
+}
+static inline uint32_t orc_pcg_next32(orc_pcg *g) {       /* low half first, the high half is buffered */
+    if (g->has_uint32) { g->has_uint32 = 0; return g->uinteger; }
+    uint64_t n = orc_pcg_next64(g);
+    g->has_uint32 = 1;
+    g->uinteger = (uint32_t)(n >> 32);
+    return (uint32_t)n;
+}
+static inline double orc_pcg_double(orc_pcg *g) { return (double)(orc_pcg_next64(g) >> 11) * (1.0 / 9007199254740992.0); }
+static inline double orc_pcg_uniform(orc_pcg *g, double lo, double hi) { return lo + (hi - lo) * orc_pcg_double(g); }
+/* Generator.integers(low, high), high-low-1 < 2**32-1: Lemire's method on buffered 32-bit draws */
+static inline int64_t orc_pcg_integers(orc_pcg *g, int64_t low, int64_t high) {
+    uint32_t rng = (uint32_t)(high - low - 1);
+    if (rng == 0) return low;
+    uint32_t rng_excl = rng + 1;
+    uint64_t m = (uint64_t)orc_pcg_next32(g) * rng_excl;
+    uint32_t leftover = (uint32_t)m;
+    if (leftover < rng_excl) {
+        uint32_t threshold = (0xFFFFFFFFu - rng) % rng_excl;
+        while (leftover < threshold) { m = (uint64_t)orc_pcg_next32(g) * rng_excl; leftover = (uint32_t)m; }
+    }
+    return low + (int64_t)(m >> 32);
+}
+/* random_standard_normal: 256-layer ziggurat (tables: tools/gen_ziggurat_tables.py) */
+static inline double orc_pcg_standard_normal(orc_pcg *g) {
+    for (;;) {
+        uint64_t r = orc_pcg_next64(g);
+        int idx = (int)(r & 0xff);
+        r >>= 8;
+        int sign = (int)(r & 1);
+        uint64_t rabs = (r >> 1) & 0x000fffffffffffffull;
+        double x = (double)rabs * zig_wi[idx];
+        if (sign) x = -x;
+        if (rabs < zig_ki[idx]) return x;
+        if (idx == 0) {
+            for (;;) {
+                double xx = -ZIG_NOR_INV_R * log1p(-orc_pcg_double(g));
+                double yy = -log1p(-orc_pcg_double(g));
+                if (yy + yy > xx * xx) return ((rabs >> 8) & 1) ? -(ZIG_NOR_R + xx) : ZIG_NOR_R + xx;
+            }
+        } else if (((zig_fi[idx - 1] - zig_fi[idx]) * orc_pcg_double(g) + zig_fi[idx]) < exp(-0.5 * x * x)) return x;
+    }
+}
+static inline double orc_pcg_normal(orc_pcg *g, double loc, double scale) { return loc + scale * orc_pcg_standard_normal(g); }
+/* Generator.choice(4 values, p=p): cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(cdf, random(), 'right') */
+static inline int orc_pcg_choice4(orc_pcg *g, const double *p) {
+    double c[4];
+    c[0] = p[0]; c[1] = c[0] + p[1]; c[2] = c[1] + p[2]; c[3] = c[2] + p[3];
+    for (int i = 0; i < 4; ++i) c[i] /= c[3];       /* in place: the last element divides itself last */
+    double u = orc_pcg_double(g);
+    int idx = 0;
+    while (idx < 4 && c[idx] <= u) ++idx;
+    return idx;
+}
+
 #endif

@@ -22,3 +22,16 @@ void orc_mt_get(const orc_mt *s, uint32_t *mt624, int *idx) {
 uint32_t orc_hash_action_export(uint64_t a_seed, uint64_t env, uint64_t t, uint32_t n, uint32_t j) {
     return orc_hash_action(a_seed, env, t, n, j);
 }
+
+orc_pcg *orc_pcg_new(void) { return (orc_pcg *)calloc(1, sizeof(orc_pcg)); }
+void orc_pcg_free(orc_pcg *g) { free(g); }
+void orc_pcg_seed_export(orc_pcg *g, uint64_t seed) { orc_pcg_seed(g, seed); }
+uint64_t orc_pcg_next64_export(orc_pcg *g) { return orc_pcg_next64(g); }
+double orc_pcg_random_export(orc_pcg *g) { return orc_pcg_double(g); }
+double orc_pcg_uniform_export(orc_pcg *g, double lo, double hi) { return orc_pcg_uniform(g, lo, hi); }
+int64_t orc_pcg_integers_export(orc_pcg *g, int64_t lo, int64_t hi) { return orc_pcg_integers(g, lo, hi); }
+double orc_pcg_normal_export(orc_pcg *g, double loc, double scale) { return orc_pcg_normal(g, loc, scale); }
+int orc_pcg_choice4_export(orc_pcg *g, const double *p) { return orc_pcg_choice4(g, p); }
+void orc_pcg_state_export(const orc_pcg *g, uint64_t *out4) {
+    out4[0] = (uint64_t)(g->state >> 64); out4[1] = (uint64_t)g->state; out4[2] = (uint64_t)(g->inc >> 64); out4[3] = (uint64_t)g->inc;
+}

@@ -64,3 +64,38 @@ def test_hash_action_matches_generator_definition(oracle):
     v = common.hash_actions_np(123, ids, 17, 4)
     assert all(int(v[i]) == common.hash_action(123, int(i), 17, 4) for i in range(0, 1000, 37))
     assert 0.2 < np.mean(v == 0) < 0.3
+
+
+def test_pcg64_seedsequence_and_draws_match_numpy(oracle):
+    for seed in [0, 1, 7, 42, 2**31, 2**32 + 5, 2**63 + 11]:
+        g = np.random.default_rng(seed)
+        st = g.bit_generator.state["state"]
+        p = oracle.PCG(seed)
+        assert p.state() == (st["state"], st["inc"]), seed
+        raw = np.random.PCG64(seed).random_raw(50)
+        q = oracle.PCG(seed)
+        assert [q.next64() for _ in range(50)] == [int(x) for x in raw]
+        # mixed call sequence exactly as SmartClimateEnv issues it (uniform, integers, normal, choice)
+        for _ in range(300):
+            assert p.uniform(22.0, 26.0) == g.uniform(22.0, 26.0)
+            assert p.integers(0, 9) == int(g.integers(0, 9))
+            assert p.normal(25, 5) == g.normal(25, 5)
+            assert [-1, 0, 1, 2][p.choice4([0.1, 0.3, 0.4, 0.2])] == int(g.choice([-1, 0, 1, 2], p=[0.1, 0.3, 0.4, 0.2]))
+            assert [-2, -1, 0, 1][p.choice4([0.2, 0.4, 0.3, 0.1])] == int(g.choice([-2, -1, 0, 1], p=[0.2, 0.4, 0.3, 0.1]))
+            assert p.random() == g.random()
+
+
+def test_pcg64_known_answers_literal(oracle):
+    p = oracle.PCG(0)                                   # default_rng(0)
+    assert p.uniform(22, 26) == 24.547846749285817
+    assert p.integers(0, 9) == 4
+    assert p.normal(25, 5) == 28.20211325221641
+    assert [-2, -1, 0, 1][p.choice4([.2, .4, .3, .1])] == -2
+
+
+def test_ziggurat_normal_bulk(oracle):
+    g = np.random.default_rng(99)
+    ref = g.standard_normal(200000)
+    p = oracle.PCG(99)
+    got = np.array([p.normal(0.0, 1.0) for _ in range(200000)])
+    assert np.array_equal(ref, got)
