@@ -301,6 +301,49 @@ int cge_parking_info64(cge_parking *h, int32_t field_id, double *out, void *stre
 size_t cge_parking_device_bytes(const cge_parking *h);
 const char *cge_parking_last_error(const cge_parking *h);
 
+/* ------------------------------------------------------------------------------------------ */
+/* SmartClimate  (smartclimate_rl-main/smartclimate/env.py: SmartClimateEnv, utils.py)          */
+/*   obs float32 (9,): room_temp, num_people, time_of_day, outside_temp, ac_setting, lights[4]  */
+/*   action Dict{ac_temp float32[1] (clipped to 16..32), lights MultiBinary(4)} (:39-47)        */
+/*   float64 dynamics; generator family D: a private default_rng(seed) (PCG64) per env —        */
+/*   uniform, Lemire integers on buffered 32-bit draws, ziggurat normal, choice(p).             */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct cge_climate cge_climate;
+
+typedef struct {
+    int32_t max_occupancy;    /* 8 (:19); <= 15 */
+    int32_t episode_minutes;  /* 1440 (:21); <= 65535 */
+    int32_t autoreset_mode;   /* CGE_AUTORESET_* */
+    int32_t reserved;
+} cge_climate_config;
+
+enum { /* cge_climate_info float64 fields */
+    CGE_CLIMATE_INFO_ROOM_TEMP = 0, CGE_CLIMATE_INFO_OUTSIDE_TEMP = 1, CGE_CLIMATE_INFO_AC_SETTING = 2,
+    CGE_CLIMATE_INFO_ENERGY_USAGE = 3, CGE_CLIMATE_INFO_TOTAL_REWARD = 4, CGE_CLIMATE_INFO_NUM_PEOPLE = 5,
+    CGE_CLIMATE_INFO_STEP = 6, CGE_CLIMATE_INFO_COMFORT_TIME = 7, CGE_CLIMATE_INFO_EPISODES = 8,
+    CGE_CLIMATE_INFO_NEEDS_RESET = 9
+};
+
+int cge_climate_create(const cge_climate_config *cfg, int64_t n_envs, int device, int64_t env_index0,
+                       cge_climate **out);
+int cge_climate_destroy(cge_climate *h);
+/* reset(seed=s) (:63-65): env i's generator := np.random.default_rng(s_i) (SeedSequence -> PCG64) */
+int cge_climate_seed(cge_climate *h, const uint64_t *seeds, uint64_t base_seed, void *stream);
+int cge_climate_reset(cge_climate *h, const uint8_t *mask, float *obs_out, void *stream);
+/* ac_temp float32[n_envs] (action['ac_temp'][0]), lights int8[n_envs,4] */
+int cge_climate_step(cge_climate *h, const float *ac_temp, const int8_t *lights, float *obs_out, float *reward_out,
+                     uint8_t *terminated_out, uint8_t *truncated_out /*nullable*/, float *final_obs_out,
+                     void *stream);
+/* k fused steps; ac_temp [k,n] / lights [k,n,4] or both NULL -> hash actions:
+ * ac = float32(16 + 16*(hash(seed,env,t,j=0) >> 40)/2^24), lights[j] = cge_hash_action(seed,env,t,2,1+j) */
+int cge_climate_rollout(cge_climate *h, int32_t k_steps, const float *ac_temp, const int8_t *lights,
+                        uint64_t action_seed, int64_t t0, float *obs_out, int64_t obs_step_stride,
+                        float *reward_traj_out, uint8_t *terminated_traj_out, double *reward_sum_out,
+                        int32_t *done_count_out, void *stream);
+int cge_climate_info(cge_climate *h, int32_t field_id, double *out, void *stream);
+size_t cge_climate_device_bytes(const cge_climate *h);
+const char *cge_climate_last_error(const cge_climate *h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,6 +24,8 @@ def test_header_declares_the_full_per_env_surface():
     assert "cge_snake_error_count" in names
     for fn in ["create", "destroy", "seed", "reset", "step", "rollout", "info", "info64", "last_error", "device_bytes"]:
         assert f"cge_parking_{fn}" in names, fn
+    for fn in ["create", "destroy", "seed", "reset", "step", "rollout", "info", "last_error", "device_bytes"]:
+        assert f"cge_climate_{fn}" in names, fn
 
 
 def test_library_exports_every_declared_symbol():

@@ -1,0 +1,98 @@
+"""GPU parity tests for the SmartClimate hot path (through the C ABI via ClimateVectorEnv).
+
+Float-state env (BASELINE north_star: "within a stated fp32 tolerance"): obs |d| <= 1e-6 + 1e-6|x|, reward
+|d| <= 1e-4 + 1e-6|x| — the device can differ from the CPU only in the last place of log1p/exp inside the
+ziggurat's wedge/tail (1.5 % of normals); the fraction of bit-identical obs values is reported and must stay
+> 0.9999.  Discrete quantities (people, lights, step, flags) are exact."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cge():
+    import custom_gymnasium_environments_amd as m
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    m.native_lib()
+    return m
+
+
+def _np(t):
+    return t.cpu().numpy()
+
+
+def _close(a, b, atol, rtol=1e-6):
+    return np.abs(a.astype(np.float64) - b.astype(np.float64)) <= atol + rtol * np.abs(b.astype(np.float64))
+
+
+def test_same_step_matches_reference_fixture(cge):
+    fx = golden("climate_hash.npz")
+    AC, LI = fx["ac_temp"], fx["lights"]
+    n, T = AC.shape
+    env = cge.ClimateVectorEnv(n, autoreset_mode="SameStep")
+    obs, _ = env.reset(seed=int(fx["seed0"]))
+    assert _close(_np(obs), fx["obs0"], 1e-6).all()
+    reset_at = {(int(i), int(t)): k for k, (i, t) in enumerate(fx["reset_index"])}
+    ac_d, li_d = torch.from_numpy(AC).cuda(), torch.from_numpy(LI).cuda()
+    exact = total = 0
+    for t in range(T):
+        obs, rew, te, tr, info = env.step({"ac_temp": ac_d[:, t:t + 1], "lights": li_d[:, t]})
+        obs, rew, te, fin = _np(obs), _np(rew), _np(te), _np(info["final_obs"])
+        assert np.array_equal(te, fx["terminated"][:, t].astype(bool)), t
+        assert _close(rew, fx["reward"][:, t], 1e-4).all(), t
+        step_obs = np.where(te[:, None], fin, obs)
+        assert _close(step_obs, fx["obs"][:, t], 1e-6).all(), t
+        assert np.array_equal(step_obs[:, [1, 2, 4, 5, 6, 7, 8]], fx["obs"][:, t][:, [1, 2, 4, 5, 6, 7, 8]]), t   # discrete/echo fields exact
+        exact += int((step_obs.view(np.uint32) == fx["obs"][:, t].view(np.uint32)).sum()); total += step_obs.size
+        for i in np.nonzero(te)[0]:
+            assert _close(obs[i], fx["reset_obs"][reset_at[(int(i), t)]], 1e-6).all()
+    print(f"climate fixture: {exact}/{total} obs values bit-identical ({exact / total:.6f})")
+    assert exact / total > 0.9999
+    env.close()
+
+
+@pytest.mark.parametrize("mode", ["NextStep", "SameStep", "Disabled"])
+def test_step_matches_oracle_all_modes(cge, oracle, mode):
+    code = {"NextStep": oracle.NEXT_STEP, "SameStep": oracle.SAME_STEP, "Disabled": oracle.DISABLED}[mode]
+    n, T = 500, 1500
+    env = cge.ClimateVectorEnv(n, autoreset_mode=mode, env_index0=6)
+    o = oracle.ClimateOracle(n, code)
+    o.seed(np.arange(n, dtype=np.uint64) + np.uint64(6 + 80))
+    od, _ = env.reset(seed=80)
+    assert _close(_np(od), o.reset(), 1e-6).all()
+    rng = np.random.default_rng(8)
+    for t in range(T):
+        ac = rng.uniform(10, 38, (n, 1)).astype(np.float32)
+        li = rng.integers(0, 2, (n, 4)).astype(np.int8)
+        od, rd, ted, trd, _ = env.step((ac, li))
+        oo, ro, teo, tro = o.step(ac, li)
+        assert _close(_np(od), oo, 1e-6).all(), t
+        assert _close(_np(rd), ro, 1e-4).all() and np.array_equal(_np(ted), teo.astype(bool)), t
+    for f in ["num_people", "step", "comfort_time", "episodes", "needs_reset"]:
+        assert np.array_equal(_np(env.info(f)), o.info(f)), f
+    for f in ["room_temp", "outside_temp", "energy_usage", "total_reward"]:
+        assert np.allclose(_np(env.info(f)), o.info(f), rtol=1e-10, atol=1e-9), f
+    env.close()
+
+
+def test_rollout_config5_size_and_sharding(cge, oracle):
+    n, T = 1 << 17, 300
+    env = cge.ClimateVectorEnv(n, autoreset_mode="SameStep", reuse_buffers=True)
+    env.reset(seed=0)
+    obs, rs, dc = env.rollout(T, action_seed=123)
+    assert torch.isfinite(obs).all() and bool(((obs[:, 0] >= 10) & (obs[:, 0] <= 50)).all())
+    for lo in [0, n - 3000]:
+        m = 3000
+        o = oracle.ClimateOracle(m, oracle.SAME_STEP)
+        o.seed(np.arange(lo, lo + m, dtype=np.uint64)); o.reset()
+        oo, ro, do = o.rollout(T, 123, env0=lo)
+        assert _close(_np(obs[lo:lo + m]), oo, 1e-6).all() and np.allclose(_np(rs[lo:lo + m]), ro, rtol=1e-9, atol=1e-6)
+    half = cge.ClimateVectorEnv(n // 2, autoreset_mode="SameStep", env_index0=n // 2)
+    half.reset(seed=0)
+    oh, rh, dh = half.rollout(T, action_seed=123)
+    assert torch.equal(oh, obs[n // 2:]) and torch.equal(rh, rs[n // 2:])
+    env.close(); half.close()
