@@ -127,6 +127,14 @@ def _declare(L):
     L.orc_climate_info.argtypes = [vp, i32, vp]
     L.orc_climate_hash_action.argtypes = [u64, u64, u64, vp, vp]
 
+    L.orc_fleet_create.argtypes = [i64, i32]; L.orc_fleet_create.restype = vp
+    L.orc_fleet_destroy.argtypes = [vp]
+    L.orc_fleet_seed.argtypes = [vp, vp]
+    L.orc_fleet_reset.argtypes = [vp, vp, vp]
+    L.orc_fleet_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.orc_fleet_rollout.argtypes = [vp, i32, u64, i64, i64, vp, vp, vp]
+    L.orc_fleet_info.argtypes = [vp, i32, vp]
+
 
 NEXT_STEP, SAME_STEP, DISABLED = 0, 1, 2
 
@@ -405,6 +413,7 @@ class _SimpleOracle:
     _name = None
     _obs = None
     _nact = None
+    _adim = 1
 
     def __init__(self, n, mode=SAME_STEP):
         self.n, self.mode = int(n), int(mode)
@@ -430,7 +439,7 @@ class _SimpleOracle:
 
     def step(self, actions, want_final=False):
         a = np.ascontiguousarray(actions, dtype=np.int32)
-        assert a.shape == (self.n,)
+        assert a.shape == ((self.n,) if self._adim == 1 else (self.n, self._adim))
         obs = np.zeros((self.n, self._obs), np.float32)
         rew = np.zeros(self.n, np.float32); rew64 = np.zeros(self.n, np.float64)
         te = np.zeros(self.n, np.uint8); tr = np.zeros(self.n, np.uint8)
@@ -492,3 +501,18 @@ class ClimateOracle(_SimpleOracle):
         ac = np.zeros(1, np.float32); li = np.zeros(4, np.int8)
         lib().orc_climate_hash_action(a_seed, env, t, _p(ac), _p(li))
         return ac[0], li
+
+
+FLEET_OBS = 76
+FLEET_INFO = {"timestep": 0, "missed_deadlines": 1, "completed_deliveries": 2, "num_requests": 3, "weather_effect": 4,
+              "total_reward": 5, "episodes": 6, "needs_reset": 7, "fuel0": 8, "fuel1": 9, "fuel2": 10}
+
+
+class FleetOracle(_SimpleOracle):
+    """Batch of independent FleetManagementEnv restatements (oracle/orc_fleet.c); actions int32 (n, 3)."""
+    _name, _obs, _nact, _adim = "fleet", FLEET_OBS, 8, 3
+
+    def info(self, field):
+        out = np.zeros(self.n, np.float64)
+        lib().orc_fleet_info(self.h, FLEET_INFO[field] if isinstance(field, str) else field, _p(out))
+        return out
