@@ -1,0 +1,576 @@
+// fleet.hip — batched FleetManagementEnv for MI355X (gfx950): kernels + C ABI (include/cge_amd.h).
+//
+// Re-expresses /root/reference/fleet_management_env/fleet_env.py for N independent instances, one lane per env:
+//   reset :185-234, step :236-276, _execute_vehicle_action :278-329, _get_new_position :331-342,
+//   _get_traffic_cost :349-361, _attempt_pickup :363-391, _attempt_dropoff :393-437, _attempt_refuel :439-448,
+//   _generate_delivery_requests :450-514, _update_traffic :516-522, _update_weather :524-528,
+//   _check_missed_deadlines :530-535, _is_terminated :537-553, _get_observation :555-593 (76 values).
+// State per env: 40 dwords in 10 uint4 columns — 3 vehicles (cell, cargo, assignment; float64 fuel), up to 12
+// deliveries in two dwords each (cells, urgency, vehicle requirement, window, deadline, pickup time), the 5x5
+// traffic map at 2 bits per cell, weather index, counters and both generators' cursors.  Rewards are sums of
+// small integers (exact); fuel is float64 in the reference's operation order -> obs and reward bit-identical.
+// RNG: draws are rare in step() (traffic every 50 steps, weather every 100) and heavy in reset() (~150 words
+// over two interleaved streams: NumPy-legacy masked randint / choice(p) / random and CPython random.choice over
+// 144 cells) -> both MT19937 windows are parked in LDS (LdsDraws), 16 words per round trip.
+// The (N,76) float32 obs is staged whole in LDS ([64][77] per wave) and written in one linear pass, so every
+// 128-byte line of the output is completed within a few instructions.
+#include <cstring>
+#include <vector>
+
+#include "cge_device.hpp"
+#include "cge_host.hpp"
+
+namespace cge {
+namespace fleet {
+
+constexpr int OBS = 76;
+constexpr int ROW = 77;
+constexpr int MAXD = 12;
+constexpr int COLS = 10;
+constexpr int DW = 16;
+constexpr int DROW = 17;
+constexpr int BLOCK = 64;
+
+struct Params {
+    uint4 *state;
+    uint32_t *mtP, *mtL;
+    int64_t n, env0;
+    int32_t mode, max_steps;
+    const int32_t *actions;
+    const uint8_t *mask;
+    float *obs, *final_obs, *reward;
+    uint8_t *terminated, *truncated;
+    int32_t k_steps;
+    uint64_t a_seed;
+    int64_t t0, obs_step_stride;
+    double *reward_sum;
+    int32_t *done_count;
+};
+
+__device__ __forceinline__ double vrange(int k) { return k == 0 ? 80.0 : k == 1 ? 120.0 : 60.0; }     // :128-132
+__device__ __forceinline__ double vcons(int k) { return k == 0 ? 1.0 : k == 1 ? 0.5 : 2.0; }
+__device__ __forceinline__ uint32_t vcap(int k) { return k == 0 ? 3u : k == 1 ? 1u : 5u; }
+
+struct Env {
+    uint32_t veh[3];        // x:5 | y:5 << 5 | cargo:3 << 10 | (assigned+1):4 << 13
+    double fuel[3];
+    uint32_t dA[MAXD];      // px:5 | py:5<<5 | dx:5<<10 | dy:5<<15 | urgency:2<<20 | required:2<<22 | completed<<24 | (assigned_vehicle+1):2<<25
+    uint32_t dB[MAXD];      // t0:8 | commercial<<8 | deadline:9<<9 | pickup_time:10<<18
+    uint32_t traffic[2];    // 25 cells x 2 bits, row-major
+    uint32_t timestep, nd, weather, needs_reset, missed, completed, episodes, ppos, ppretw, lpos, lpretw;
+    double total_reward;
+
+    __host__ __device__ __forceinline__ void unpack(const uint32_t *raw) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            veh[k] = raw[k];
+            const uint64_t u = ((uint64_t)raw[4 + 2 * k] << 32) | raw[3 + 2 * k];
+            memcpy(&fuel[k], &u, 8);
+        }
+#pragma unroll
+        for (int i = 0; i < MAXD; ++i) { dA[i] = raw[9 + i]; dB[i] = raw[21 + i]; }
+        traffic[0] = raw[33]; traffic[1] = raw[34];
+        const uint32_t m0 = raw[35], m1 = raw[36], m2 = raw[37];
+        timestep = m0 & 1023u; nd = (m0 >> 10) & 15u; weather = (m0 >> 14) & 3u; needs_reset = (m0 >> 16) & 1u; missed = m0 >> 17;
+        completed = m1 & 15u; episodes = (m1 >> 4) & 0xFFFFu; ppos = (m1 >> 20) & 1023u; ppretw = (m1 & (1u << 30)) ? (uint32_t)MT_N : 0u;
+        lpos = m2 & 1023u; lpretw = (m2 & 1024u) ? (uint32_t)MT_N : 0u;
+        const uint64_t u = ((uint64_t)raw[39] << 32) | raw[38];
+        memcpy(&total_reward, &u, 8);
+    }
+    __host__ __device__ __forceinline__ void pack(uint32_t *raw) const {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            raw[k] = veh[k];
+            uint64_t u;
+            memcpy(&u, &fuel[k], 8);
+            raw[3 + 2 * k] = (uint32_t)u; raw[4 + 2 * k] = (uint32_t)(u >> 32);
+        }
+#pragma unroll
+        for (int i = 0; i < MAXD; ++i) { raw[9 + i] = dA[i]; raw[21 + i] = dB[i]; }
+        raw[33] = traffic[0]; raw[34] = traffic[1];
+        raw[35] = timestep | (nd << 10) | (weather << 14) | (needs_reset << 16) | (missed << 17);
+        raw[36] = completed | ((episodes & 0xFFFFu) << 4) | (ppos << 20) | (ppretw ? (1u << 30) : 0u);
+        raw[37] = lpos | (lpretw ? 1024u : 0u);
+        uint64_t u;
+        memcpy(&u, &total_reward, 8);
+        raw[38] = (uint32_t)u; raw[39] = (uint32_t)(u >> 32);
+    }
+    __device__ __forceinline__ void load(const uint4 *__restrict__ s, int64_t n, int64_t i) {
+        uint32_t raw[COLS * 4];
+#pragma unroll
+        for (int c = 0; c < COLS; ++c) {
+            const uint4 v = s[(int64_t)c * n + i];
+            raw[4 * c] = v.x; raw[4 * c + 1] = v.y; raw[4 * c + 2] = v.z; raw[4 * c + 3] = v.w;
+        }
+        unpack(raw);
+    }
+    __device__ __forceinline__ void store(uint4 *__restrict__ s, int64_t n, int64_t i) const {
+        uint32_t raw[COLS * 4];
+        pack(raw);
+#pragma unroll
+        for (int c = 0; c < COLS; ++c) s[(int64_t)c * n + i] = make_uint4(raw[4 * c], raw[4 * c + 1], raw[4 * c + 2], raw[4 * c + 3]);
+    }
+    // traffic_grid[r, c], 2 bits per cell
+    __device__ __forceinline__ uint32_t traffic_at(uint32_t cell) const {
+        const uint32_t w = (traffic[0] & (0u - (uint32_t)(cell < 16u))) | (traffic[1] & (0u - (uint32_t)(cell >= 16u)));   // mask form: no select-of-loads
+        return (w >> ((cell & 15u) * 2u)) & 3u;
+    }
+};
+
+// NumPy legacy helpers on the L stream
+__device__ __forceinline__ uint32_t np_randint(LdsDraws<DW> &L, uint32_t lo, uint32_t hi) {   // masked rejection on 32-bit words
+    const uint32_t rng = hi - lo - 1u;
+    uint32_t mask = rng;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    uint32_t v = L.next() & mask;
+    while (v > rng) v = L.next() & mask;
+    return lo + v;
+}
+// choice(n, p): searchsorted(cumsum(p)/sum, random_sample(), 'right'); the normalised cdf values are passed in
+__device__ __forceinline__ uint32_t np_choice_cdf(LdsDraws<DW> &L, double c0, double c1, double c2, double c3) {
+    const double u = L.random53();
+    return (uint32_t)(c0 <= u) + (uint32_t)(c1 <= u) + (uint32_t)(c2 <= u) + (uint32_t)(c3 <= u);
+}
+
+__device__ __forceinline__ void update_traffic(Env &e, LdsDraws<DW> &L) {                      // :516-522
+    // cdf of p=[0.6,0.3,0.1]: cumsum then / last, evaluated in float64 exactly as NumPy does
+    const double a0 = 0.6, a1 = a0 + 0.3, a2 = a1 + 0.1;
+    const double c0 = a0 / a2, c1 = a1 / a2, c2 = a2 / a2;
+    uint32_t t0 = 0, t1 = 0;
+#pragma unroll 1
+    for (int cell = 0; cell < 25; ++cell) {
+        const double u = L.random53();
+        const uint32_t v = (uint32_t)(c0 <= u) + (uint32_t)(c1 <= u) + (uint32_t)(c2 <= u);
+        if (cell < 16) t0 |= v << (cell * 2); else t1 |= v << ((cell - 16) * 2);
+    }
+    const double b0 = 0.4, b1 = b0 + 0.6;
+    const double d0 = b0 / b1, d1 = b1 / b1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                          // traffic_grid[0:2, 3:5], row-major: cells 3, 4, 8, 9
+        const int cell = q == 0 ? 3 : q == 1 ? 4 : q == 2 ? 8 : 9;
+        const double u = L.random53();
+        const uint32_t v = 1u + (uint32_t)(d0 <= u) + (uint32_t)(d1 <= u);
+        t0 = (t0 & ~(3u << (cell * 2))) | (v << (cell * 2));
+    }
+    e.traffic[0] = t0; e.traffic[1] = t1;
+}
+
+__device__ __forceinline__ uint32_t zone_cell(uint32_t zone, uint32_t k) {                    // customer_zones :135-140 -> x | y << 5
+    const uint32_t i = k / 12u, j = k - i * 12u;
+    const uint32_t x = (zone == 1u || zone == 3u) ? 13u + i : i, y = (zone == 2u || zone == 3u) ? 13u + j : j;
+    return x | (y << 5);
+}
+
+__device__ __forceinline__ void do_reset(Env &e, int32_t max_steps, LdsDraws<DW> &P, LdsDraws<DW> &L) {   // :185-234
+    e.timestep = 0; e.total_reward = 0.0; e.completed = 0; e.missed = 0; e.weather = 1; e.needs_reset = 0;   // weather index 1 = 1.0
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { e.veh[k] = 12u | (12u << 5); e.fuel[k] = vrange(k); }
+    // _generate_delivery_requests :450-514
+    const double u0 = 0.3, u1 = u0 + 0.4, u2 = u1 + 0.2, u3 = u2 + 0.1;
+    e.nd = np_randint(L, 8u, 13u);
+#pragma unroll 1
+    for (uint32_t i = 0; i < (uint32_t)MAXD; ++i) {
+        uint32_t A = 0, B = 0;
+        if (i < e.nd) {
+            const uint32_t pz = np_randint(L, 0u, 4u), dz = np_randint(L, 0u, 4u);          // np.random.choice(list(CustomerZone))
+            const uint32_t pc = zone_cell(pz, P.randbelow(144u, 8));                        // random.choice(positions)
+            uint32_t dc = zone_cell(dz, P.randbelow(144u, 8));
+            while (dc == pc) dc = zone_cell(dz, P.randbelow(144u, 8));
+            const uint32_t urg = np_choice_cdf(L, u0 / u3, u1 / u3, u2 / u3, u3 / u3);
+            uint32_t req = 0;                                                               // 0 none, 1 motorcycle, 2 truck
+            if (dz == 3u) req = 1;
+            else if (dz == 2u) { if (L.random53() < 0.6) req = 2; }
+            uint32_t t0 = 0, commercial = 0;
+            if (dz == 1u) { t0 = np_randint(L, 50u, 200u); commercial = 1; }
+            const int px = (int)(pc & 31u), py = (int)(pc >> 5), dx = (int)(dc & 31u), dy = (int)(dc >> 5);
+            const int base = abs(px - dx) + abs(py - dy);
+            const double mult = urg == 0 ? 4.0 : urg == 1 ? 3.0 : urg == 2 ? 2.0 : 1.5;
+            const uint32_t deadline = (uint32_t)((int)((double)base * mult) + 50);
+            A = pc | (dc << 10) | (urg << 20) | (req << 22);                               // not completed, unassigned
+            B = t0 | (commercial << 8) | (deadline << 9);
+        }
+#pragma unroll
+        for (int k = 0; k < MAXD; ++k) { e.dA[k] = i == (uint32_t)k ? A : e.dA[k]; e.dB[k] = i == (uint32_t)k ? B : e.dB[k]; }
+    }
+    update_traffic(e, L);
+}
+
+__device__ __forceinline__ double weather_value(uint32_t w) { return w == 0 ? 0.8 : w == 1 ? 1.0 : w == 2 ? 1.2 : 1.5; }
+
+// _execute_vehicle_action :278-329 for vehicle K (compile-time)
+template <int K>
+__device__ __forceinline__ double vehicle_action(Env &e, int32_t a, int32_t max_steps) {
+    uint32_t x = e.veh[K] & 31u, y = (e.veh[K] >> 5) & 31u, cargo = (e.veh[K] >> 10) & 7u, asg1 = (e.veh[K] >> 13) & 15u;   // asg1 = assigned + 1
+    double reward = 0.0;
+    if (e.fuel[K] > 0.0) reward -= 2.0;
+    if (a >= 1 && a <= 4) {
+        if (e.fuel[K] >= vcons(K)) {
+            if (a == 1) y = y > 0 ? y - 1 : 0; else if (a == 2) y = y < 24 ? y + 1 : 24;                // :331-342 (clamped)
+            else if (a == 3) x = x > 0 ? x - 1 : 0; else x = x < 24 ? x + 1 : 24;
+            const uint32_t tx = x / 5u < 4u ? x / 5u : 4u, ty = y / 5u < 4u ? y / 5u : 4u;
+            const uint32_t lvl = e.traffic_at(ty * 5u + tx);
+            const double tc = lvl == 0 ? 1.0 : lvl == 1 ? 1.5 : 2.0;
+            const double cost = vcons(K) * weather_value(e.weather) * tc;
+            const double f = e.fuel[K] - cost;
+            e.fuel[K] = f > 0.0 ? f : 0.0;
+            if (tc > 1.5) reward -= 5.0;
+        } else reward -= 50.0;
+    } else if (a == 5) {                                                                                // _attempt_pickup :363-391
+        int best = -1;
+        uint32_t best_urg = 0;
+        if (cargo < vcap(K) && asg1 == 0) {
+#pragma unroll
+            for (int i = 0; i < MAXD; ++i) {
+                const uint32_t A = e.dA[i], B = e.dB[i];
+                const uint32_t t0 = B & 255u, t1 = ((B >> 8) & 1u) ? (t0 + 300u < 600u ? t0 + 300u : 600u) : (uint32_t)max_steps;
+                const uint32_t req = (A >> 22) & 3u, urg = (A >> 20) & 3u;
+                const bool ok = (uint32_t)i < e.nd && (A & 1023u) == (x | (y << 5)) && !((A >> 24) & 1u) && t0 <= e.timestep && e.timestep <= t1 &&
+                                ((A >> 25) & 3u) == 0 && (req == 0 || req == (uint32_t)K);
+                if (ok && (best < 0 || urg > best_urg)) { best = i; best_urg = urg; }
+            }
+        }
+        if (best < 0) reward += -10.0;
+        else {
+            cargo += 1; asg1 = (uint32_t)best + 1u;
+#pragma unroll
+            for (int i = 0; i < MAXD; ++i)
+                if (best == i) { e.dA[i] |= (uint32_t)(K + 1) << 25; e.dB[i] = (e.dB[i] & 0x3FFFFu) | (e.timestep << 18); }
+            reward += 20.0;
+        }
+    } else if (a == 6) {                                                                                // _attempt_dropoff :393-437
+        uint32_t A = 0, B = 0;
+#pragma unroll
+        for (int i = 0; i < MAXD; ++i) if (asg1 == (uint32_t)(i + 1)) { A = e.dA[i]; B = e.dB[i]; }
+        if (asg1 == 0 || ((A >> 10) & 1023u) != (x | (y << 5))) reward += -10.0;
+        else {
+            const uint32_t urg = (A >> 20) & 3u;
+            int r = urg == 0 ? 50 : urg == 1 ? 100 : 200;
+            const int px = (int)(A & 31u), py = (int)((A >> 5) & 31u), dx = (int)((A >> 10) & 31u), dy = (int)((A >> 15) & 31u);
+            const int dt = (int)e.timestep - (int)(B >> 18), opt = abs(px - dx) + abs(py - dy);
+            if (dt <= opt + 2) r += 15;
+            if (!(e.timestep <= ((B >> 9) & 511u))) r -= 20 * ((int)urg + 1);
+#pragma unroll
+            for (int i = 0; i < MAXD; ++i) if (asg1 == (uint32_t)(i + 1)) e.dA[i] |= 1u << 24;          // completed
+            cargo = cargo > 0 ? cargo - 1 : 0; asg1 = 0;
+            e.completed += 1;
+            reward += (double)r;
+        }
+    } else if (a == 7) {                                                                                // _attempt_refuel :439-448
+        const bool at = (x == 5 && y == 5) || (x == 20 && y == 5) || (x == 5 && y == 20);
+        if (at) { if (e.fuel[K] < vrange(K)) { e.fuel[K] = vrange(K); reward += 10.0; } else reward += -5.0; }
+        else reward += -10.0;
+    } else if (a != 0) reward -= 10.0;
+    e.veh[K] = x | (y << 5) | (cargo << 10) | (asg1 << 13);
+    return reward;
+}
+
+// returns terminated | truncated << 1
+__device__ __forceinline__ uint32_t env_step(Env &e, int32_t max_steps, int32_t a0, int32_t a1, int32_t a2, LdsDraws<DW> &L, double &reward) {   // :236-276
+    double total = 0.0;
+    total += vehicle_action<0>(e, a0, max_steps);
+    total += vehicle_action<1>(e, a1, max_steps);
+    total += vehicle_action<2>(e, a2, max_steps);
+    e.timestep += 1;
+    if (e.timestep % 50u == 0) update_traffic(e, L);
+    if (e.timestep % 100u == 0) {                                                                     // _update_weather :524-528
+        const double w0 = 0.3, w1 = w0 + 0.5, w2 = w1 + 0.15, w3 = w2 + 0.05;
+        e.weather = np_choice_cdf(L, w0 / w3, w1 / w3, w2 / w3, w3 / w3);
+    }
+    uint32_t urgent = 0;
+    bool all_done = true;
+#pragma unroll
+    for (int i = 0; i < MAXD; ++i) {                                                                  // _check_missed_deadlines :530-535
+        const uint32_t A = e.dA[i], B = e.dB[i];
+        const bool live = (uint32_t)i < e.nd, done = (A >> 24) & 1u, urg = ((A >> 20) & 3u) >= 2u;
+        if (live && e.timestep > ((B >> 9) & 511u) && !done && urg) e.missed += 1;
+        urgent += (live && urg) ? 1u : 0u;
+        all_done = all_done && (!live || done);
+    }
+    const bool fuel_out = !(e.fuel[0] > 0.0) && !(e.fuel[1] > 0.0) && !(e.fuel[2] > 0.0);
+    e.total_reward += total;
+    reward = total;
+    const bool term = all_done || fuel_out || (urgent > 0 && (double)e.missed >= (double)urgent * 0.5);   // :537-553
+    return (term ? 1u : 0u) | (e.timestep >= (uint32_t)max_steps ? 2u : 0u);
+}
+
+__device__ __forceinline__ void observe(const Env &e, int64_t nrows, float *__restrict__ dst, unsigned long long rowmask, uint32_t *__restrict__ tile) {
+    const uint32_t lane = threadIdx.x & 63u;
+    float *row = reinterpret_cast<float *>(tile) + lane * ROW;                                       // :555-593
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        row[2 * k] = (float)(e.veh[k] & 31u); row[2 * k + 1] = (float)((e.veh[k] >> 5) & 31u);
+        row[6 + k] = (float)(e.fuel[k] / vrange(k));
+        row[9 + k] = (float)((double)((e.veh[k] >> 10) & 7u) / (double)vcap(k));
+        row[12 + k] = (float)((int)((e.veh[k] >> 13) & 15u) - 1);
+    }
+#pragma unroll
+    for (int i = 0; i < MAXD; ++i) {
+        const uint32_t A = e.dA[i];
+        const bool live = (uint32_t)i < e.nd && !((A >> 24) & 1u);
+        row[15 + 2 * i] = live ? (float)(A & 31u) : -1.0f;
+        row[16 + 2 * i] = live ? (float)((A >> 5) & 31u) : -1.0f;
+        row[39 + i] = live ? (float)((A >> 20) & 3u) : -1.0f;
+    }
+#pragma unroll
+    for (int c = 0; c < 25; ++c) row[51 + c] = (float)(((c < 16 ? e.traffic[0] : e.traffic[1]) >> ((c & 15) * 2)) & 3u);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    uint32_t r = lane / (uint32_t)OBS, col = lane - r * (uint32_t)OBS;
+#pragma unroll 1
+    for (int m = 0; m < OBS; ++m) {
+        if ((int64_t)r < nrows && ((rowmask >> r) & 1ull)) reinterpret_cast<uint32_t *>(dst)[(int64_t)r * OBS + col] = tile[r * ROW + col];
+        col += 64u % OBS; r += 64u / OBS;
+        if (col >= (uint32_t)OBS) { col -= OBS; r += 1u; }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+template <bool ROLLOUT>
+__global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
+    __shared__ uint32_t tile[64 * ROW];
+    __shared__ uint32_t drawsP[64 * DROW], drawsL[64 * DROW];
+    const int64_t i0 = (int64_t)blockIdx.x * BLOCK;
+    const int64_t i = i0 + threadIdx.x;
+    const bool live = i < p.n;
+    const int64_t li = live ? i : i0;
+    const int64_t nrows = p.n - i0 < 64 ? p.n - i0 : 64;
+    Env e;
+    e.load(p.state, p.n, li);
+    LdsDraws<DW> P(drawsP + (threadIdx.x & 63u) * DROW, p.mtP + li * MT_STRIDE, e.ppos, e.ppretw);
+    LdsDraws<DW> L(drawsL + (threadIdx.x & 63u) * DROW, p.mtL + li * MT_STRIDE, e.lpos, e.lpretw);
+    const uint64_t key = ROLLOUT ? hash_env_key(p.a_seed, (uint64_t)(p.env0 + li)) : 0;
+    double rsum = 0.0;
+    int32_t dcount = 0;
+    const int ksteps = ROLLOUT ? p.k_steps : 1;
+#pragma unroll 1
+    for (int t = 0; t < ksteps; ++t) {
+        double reward = 0.0;
+        uint32_t flags = 0;
+        bool reset_now = false;
+        if (live) {
+            if (p.mode == CGE_AUTORESET_NEXT_STEP && e.needs_reset) {
+                reset_now = true;
+            } else {
+                int32_t a0, a1, a2;
+                if (p.actions) {
+                    const int32_t *ap = p.actions + ((int64_t)t * p.n + i) * 3;
+                    a0 = ap[0]; a1 = ap[1]; a2 = ap[2];
+                } else {
+                    a0 = (int32_t)hash_action_from_key(key, (uint64_t)(p.t0 + t), 8u, 0u);
+                    a1 = (int32_t)hash_action_from_key(key, (uint64_t)(p.t0 + t), 8u, 1u);
+                    a2 = (int32_t)hash_action_from_key(key, (uint64_t)(p.t0 + t), 8u, 2u);
+                }
+                flags = env_step(e, p.max_steps, a0, a1, a2, L, reward);
+                L.flush();
+                if (flags) {
+                    e.episodes += 1;
+                    if (p.mode == CGE_AUTORESET_SAME_STEP) reset_now = true;
+                    else if (p.mode == CGE_AUTORESET_NEXT_STEP) e.needs_reset = 1;
+                }
+            }
+        }
+        const unsigned long long fin_mask = __ballot(live && flags && reset_now);
+        if (fin_mask && p.final_obs) observe(e, nrows, p.final_obs + i0 * OBS, fin_mask, tile);
+        if (reset_now) { do_reset(e, p.max_steps, P, L); P.flush(); L.flush(); }
+        if (p.obs) observe(e, nrows, p.obs + (int64_t)t * p.obs_step_stride + i0 * OBS, ~0ull, tile);
+        if (live) {
+            if (ROLLOUT) {
+                rsum += reward;
+                dcount += flags ? 1 : 0;
+                if (p.reward) p.reward[(int64_t)t * p.n + i] = (float)reward;
+                if (p.terminated) p.terminated[(int64_t)t * p.n + i] = (uint8_t)flags;
+            } else {
+                p.reward[i] = (float)reward;
+                p.terminated[i] = (uint8_t)(flags & 1u);
+                p.truncated[i] = (uint8_t)((flags >> 1) & 1u);
+            }
+        }
+    }
+    if (live) {
+        e.ppos = P.pos; e.ppretw = P.pretw; e.lpos = L.pos; e.lpretw = L.pretw;
+        e.store(p.state, p.n, i);
+        if (ROLLOUT) {
+            if (p.reward_sum) p.reward_sum[i] = rsum;
+            if (p.done_count) p.done_count[i] = dcount;
+        }
+    }
+}
+
+// what: 0 reset(mask)+obs, 1 rewind cursors after seeding, 2 initial state of a fresh handle
+__global__ __launch_bounds__(BLOCK) void reset_kernel(Params p, int what) {
+    __shared__ uint32_t tile[64 * ROW];
+    __shared__ uint32_t drawsP[64 * DROW], drawsL[64 * DROW];
+    const int64_t i0 = (int64_t)blockIdx.x * BLOCK;
+    const int64_t i = i0 + threadIdx.x;
+    const bool live = i < p.n;
+    const int64_t li = live ? i : i0;
+    const int64_t nrows = p.n - i0 < 64 ? p.n - i0 : 64;
+    Env e;
+    e.load(p.state, p.n, li);
+    if (live) {
+        if (what == 1) { e.ppos = e.lpos = 0; e.ppretw = e.lpretw = 0; e.store(p.state, p.n, i); }
+        else if (what == 2) { e.weather = 1; e.store(p.state, p.n, i); }
+        else if (!p.mask || p.mask[i]) {
+            LdsDraws<DW> P(drawsP + (threadIdx.x & 63u) * DROW, p.mtP + li * MT_STRIDE, e.ppos, e.ppretw);
+            LdsDraws<DW> L(drawsL + (threadIdx.x & 63u) * DROW, p.mtL + li * MT_STRIDE, e.lpos, e.lpretw);
+            do_reset(e, p.max_steps, P, L);
+            P.flush(); L.flush();
+            e.ppos = P.pos; e.ppretw = P.pretw; e.lpos = L.pos; e.lpretw = L.pretw;
+            e.store(p.state, p.n, i);
+        }
+    }
+    if (what == 0 && p.obs) observe(e, nrows, p.obs + i0 * OBS, ~0ull, tile);
+}
+
+__global__ __launch_bounds__(256) void info_kernel(const uint4 *__restrict__ state, int64_t n, int field, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    Env e;
+    e.load(state, n, i);
+    double v = 0.0;
+    switch (field) {
+        case CGE_FLEET_INFO_TIMESTEP: v = e.timestep; break;
+        case CGE_FLEET_INFO_MISSED_DEADLINES: v = e.missed; break;
+        case CGE_FLEET_INFO_COMPLETED_DELIVERIES: v = e.completed; break;
+        case CGE_FLEET_INFO_NUM_REQUESTS: v = e.nd; break;
+        case CGE_FLEET_INFO_WEATHER_EFFECT: v = weather_value(e.weather); break;
+        case CGE_FLEET_INFO_TOTAL_REWARD: v = e.total_reward; break;
+        case CGE_FLEET_INFO_EPISODES: v = e.episodes; break;
+        case CGE_FLEET_INFO_NEEDS_RESET: v = e.needs_reset; break;
+        case CGE_FLEET_INFO_FUEL0: v = e.fuel[0]; break;
+        case CGE_FLEET_INFO_FUEL1: v = e.fuel[1]; break;
+        case CGE_FLEET_INFO_FUEL2: v = e.fuel[2]; break;
+    }
+    out[i] = v;
+}
+
+}  // namespace fleet
+}  // namespace cge
+
+using namespace cge;
+
+struct cge_fleet : HandleBase {
+    cge_fleet_config cfg{};
+    uint4 *state = nullptr;
+    uint32_t *mtP = nullptr, *mtL = nullptr;
+    fleet::Params params() const {
+        fleet::Params p{};
+        p.state = state; p.mtP = mtP; p.mtL = mtL; p.n = n; p.env0 = env0; p.mode = cfg.autoreset_mode; p.max_steps = cfg.max_timesteps;
+        return p;
+    }
+    unsigned blocks() const { return (unsigned)((n + fleet::BLOCK - 1) / fleet::BLOCK); }
+    void free_all() { (void)hipFree(state); (void)hipFree(mtP); (void)hipFree(mtL); }
+};
+
+extern "C" {
+
+int cge_fleet_create(const cge_fleet_config *cfg, int64_t n_envs, int device, int64_t env_index0, cge_fleet **out) {
+    if (!cfg || !out || n_envs <= 0 || env_index0 < 0) return CGE_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (cfg->autoreset_mode < 0 || cfg->autoreset_mode > 2 || cfg->max_timesteps < 0 || cfg->max_timesteps > 1023) return CGE_ERR_INVALID_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return CGE_ERR_NO_DEVICE;
+    cge_fleet *h = new cge_fleet();
+    h->cfg = *cfg;
+    if (h->cfg.max_timesteps == 0) h->cfg.max_timesteps = 800;
+    h->n = n_envs; h->env0 = env_index0; h->device = device;
+    DeviceGuard g(device);
+    const size_t sb = (size_t)fleet::COLS * n_envs * sizeof(uint4), mb = (size_t)n_envs * MT_STRIDE * sizeof(uint32_t);
+    hipError_t e;
+    if ((e = hipMalloc(&h->state, sb)) != hipSuccess || (e = hipMalloc(&h->mtP, mb)) != hipSuccess || (e = hipMalloc(&h->mtL, mb)) != hipSuccess ||
+        (e = hipMemset(h->state, 0, sb)) != hipSuccess) {
+        h->free_all();
+        delete h;
+        return CGE_ERR_HIP;
+    }
+    h->device_bytes = sb + 2 * mb;
+    e = launch_mt_seed(h->mtP, MT_STRIDE, n_envs, nullptr, 0, env_index0, 0, nullptr);
+    if (e == hipSuccess) e = launch_mt_seed(h->mtL, MT_STRIDE, n_envs, nullptr, 0, env_index0, 1, nullptr);
+    if (e == hipSuccess) {
+        fleet::Params p = h->params();
+        hipLaunchKernelGGL(fleet::reset_kernel, dim3(h->blocks()), dim3(fleet::BLOCK), 0, nullptr, p, 2);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) {
+        h->free_all();
+        delete h;
+        return CGE_ERR_HIP;
+    }
+    *out = h;
+    return CGE_OK;
+}
+
+int cge_fleet_destroy(cge_fleet *h) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    DeviceGuard g(h->device);
+    (void)hipDeviceSynchronize();
+    h->free_all();
+    delete h;
+    return CGE_OK;
+}
+
+int cge_fleet_seed(cge_fleet *h, const uint64_t *seeds, uint64_t base_seed, void *stream) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    DeviceGuard g(h->device);
+    if (!seeds && base_seed + (uint64_t)(h->env0 + h->n) > 0x100000000ull)
+        return h->fail(CGE_ERR_INVALID_ARG, "cge_fleet_seed: np.random.seed needs seeds < 2**32");
+    CGE_TRY(h, launch_mt_seed(h->mtP, MT_STRIDE, h->n, seeds, base_seed, h->env0, 0, as_stream(stream)));
+    CGE_TRY(h, launch_mt_seed(h->mtL, MT_STRIDE, h->n, seeds, base_seed, h->env0, 1, as_stream(stream)));
+    fleet::Params p = h->params();
+    hipLaunchKernelGGL(fleet::reset_kernel, dim3(h->blocks()), dim3(fleet::BLOCK), 0, as_stream(stream), p, 1);
+    CGE_TRY(h, hipGetLastError());
+    return CGE_OK;
+}
+
+int cge_fleet_reset(cge_fleet *h, const uint8_t *mask, float *obs_out, void *stream) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    DeviceGuard g(h->device);
+    fleet::Params p = h->params();
+    p.mask = mask; p.obs = obs_out;
+    hipLaunchKernelGGL(fleet::reset_kernel, dim3(h->blocks()), dim3(fleet::BLOCK), 0, as_stream(stream), p, 0);
+    CGE_TRY(h, hipGetLastError());
+    return CGE_OK;
+}
+
+int cge_fleet_step(cge_fleet *h, const int32_t *actions, float *obs_out, float *reward_out, uint8_t *terminated_out, uint8_t *truncated_out,
+                   float *final_obs_out, void *stream) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    if (!actions || !obs_out || !reward_out || !terminated_out || !truncated_out)
+        return h->fail(CGE_ERR_INVALID_ARG, "cge_fleet_step: null actions/obs/reward/terminated/truncated pointer");
+    DeviceGuard g(h->device);
+    fleet::Params p = h->params();
+    p.actions = actions; p.obs = obs_out; p.reward = reward_out; p.terminated = terminated_out; p.truncated = truncated_out;
+    p.final_obs = final_obs_out; p.k_steps = 1;
+    hipLaunchKernelGGL(fleet::step_kernel<false>, dim3(h->blocks()), dim3(fleet::BLOCK), 0, as_stream(stream), p);
+    CGE_TRY(h, hipGetLastError());
+    return CGE_OK;
+}
+
+int cge_fleet_rollout(cge_fleet *h, int32_t k_steps, const int32_t *actions, uint64_t action_seed, int64_t t0, float *obs_out,
+                      int64_t obs_step_stride, float *reward_traj_out, uint8_t *terminated_traj_out, double *reward_sum_out,
+                      int32_t *done_count_out, void *stream) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    if (k_steps < 0 || obs_step_stride < 0 || (obs_step_stride != 0 && obs_step_stride < h->n * fleet::OBS))
+        return h->fail(CGE_ERR_INVALID_ARG, "cge_fleet_rollout: bad k_steps / obs_step_stride");
+    if (k_steps == 0) return CGE_OK;
+    DeviceGuard g(h->device);
+    fleet::Params p = h->params();
+    p.k_steps = k_steps; p.actions = actions; p.a_seed = action_seed; p.t0 = t0; p.obs = obs_out; p.obs_step_stride = obs_step_stride;
+    p.reward = reward_traj_out; p.terminated = terminated_traj_out; p.reward_sum = reward_sum_out; p.done_count = done_count_out;
+    hipLaunchKernelGGL(fleet::step_kernel<true>, dim3(h->blocks()), dim3(fleet::BLOCK), 0, as_stream(stream), p);
+    CGE_TRY(h, hipGetLastError());
+    return CGE_OK;
+}
+
+int cge_fleet_info(cge_fleet *h, int32_t field_id, double *out, void *stream) {
+    if (!h || !out || field_id < 0 || field_id > CGE_FLEET_INFO_FUEL2) return CGE_ERR_INVALID_ARG;
+    DeviceGuard g(h->device);
+    hipLaunchKernelGGL(fleet::info_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, as_stream(stream), h->state, h->n, field_id, out);
+    CGE_TRY(h, hipGetLastError());
+    return CGE_OK;
+}
+
+size_t cge_fleet_device_bytes(const cge_fleet *h) { return h ? h->device_bytes : 0; }
+const char *cge_fleet_last_error(const cge_fleet *h) { return h ? h->last_error.c_str() : "null handle"; }
+
+}  // extern "C"

@@ -344,6 +344,42 @@ int cge_climate_info(cge_climate *h, int32_t field_id, double *out, void *stream
 size_t cge_climate_device_bytes(const cge_climate *h);
 const char *cge_climate_last_error(const cge_climate *h);
 
+/* ------------------------------------------------------------------------------------------ */
+/* Fleet  (fleet_management_env/fleet_env.py: FleetManagementEnv)                               */
+/*   obs float32 (76,) (:555-593; the declared space says 87)   action int32[3] in 0..7 (:157)   */
+/*   terminated (:537-553) AND truncated (timestep >= 800, :265) are both reported.              */
+/*   Generators: NumPy legacy np.random + CPython random, both seeded by reset(seed=) (:187-189). */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct cge_fleet cge_fleet;
+
+typedef struct {
+    int32_t max_timesteps;    /* 800 (:123); <= 1023 */
+    int32_t autoreset_mode;   /* CGE_AUTORESET_* */
+} cge_fleet_config;
+
+enum { /* cge_fleet_info float64 fields (_get_info :595-608 and per-vehicle state) */
+    CGE_FLEET_INFO_TIMESTEP = 0, CGE_FLEET_INFO_MISSED_DEADLINES = 1, CGE_FLEET_INFO_COMPLETED_DELIVERIES = 2,
+    CGE_FLEET_INFO_NUM_REQUESTS = 3, CGE_FLEET_INFO_WEATHER_EFFECT = 4, CGE_FLEET_INFO_TOTAL_REWARD = 5,
+    CGE_FLEET_INFO_EPISODES = 6, CGE_FLEET_INFO_NEEDS_RESET = 7,
+    CGE_FLEET_INFO_FUEL0 = 8, CGE_FLEET_INFO_FUEL1 = 9, CGE_FLEET_INFO_FUEL2 = 10
+};
+
+int cge_fleet_create(const cge_fleet_config *cfg, int64_t n_envs, int device, int64_t env_index0, cge_fleet **out);
+int cge_fleet_destroy(cge_fleet *h);
+/* reset(seed=s): np.random.seed(s_i) and random.seed(s_i); s_i < 2**32 */
+int cge_fleet_seed(cge_fleet *h, const uint64_t *seeds, uint64_t base_seed, void *stream);
+int cge_fleet_reset(cge_fleet *h, const uint8_t *mask, float *obs_out, void *stream);
+/* actions int32 [n_envs, 3]; a value outside 0..7 costs -10 (:326-327).  truncated_out is REQUIRED here. */
+int cge_fleet_step(cge_fleet *h, const int32_t *actions, float *obs_out, float *reward_out, uint8_t *terminated_out,
+                   uint8_t *truncated_out, float *final_obs_out, void *stream);
+/* done_count counts terminated-or-truncated steps; terminated_traj_out gets terminated | truncated << 1 */
+int cge_fleet_rollout(cge_fleet *h, int32_t k_steps, const int32_t *actions, uint64_t action_seed, int64_t t0,
+                      float *obs_out, int64_t obs_step_stride, float *reward_traj_out, uint8_t *terminated_traj_out,
+                      double *reward_sum_out, int32_t *done_count_out, void *stream);
+int cge_fleet_info(cge_fleet *h, int32_t field_id, double *out, void *stream);
+size_t cge_fleet_device_bytes(const cge_fleet *h);
+const char *cge_fleet_last_error(const cge_fleet *h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,7 @@ def test_header_declares_the_full_per_env_surface():
         assert f"cge_parking_{fn}" in names, fn
     for fn in ["create", "destroy", "seed", "reset", "step", "rollout", "info", "last_error", "device_bytes"]:
         assert f"cge_climate_{fn}" in names, fn
+        assert f"cge_fleet_{fn}" in names, fn
 
 
 def test_library_exports_every_declared_symbol():
