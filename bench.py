@@ -1,15 +1,24 @@
 #!/usr/bin/env python3
 """bench.py — env-steps/s of the batched step() hot path on MI355X, one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload snake_1m] [--path step|rollout]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload snake_1m] [--path rollout|step]
 
-A "step" is one pass of the hot path over one batch: one `step()` of 1,048,576 SnakeEnv 10x10
-instances per GPU (BASELINE.json configs[1]; weak scaling: per-GPU batch fixed, env indices sharded
-contiguously, no collective on the data path).  Inputs (actions) are resident in HBM before the timed
-region; every step writes the full (N,10,10) int8 observation, reward and flags, with fused auto-reset.
-Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` for the
-dominant kernel (HIP-event timed on the launch stream) and `cpu_baseline` (the oracle's C port of
-the reference timed on this box's host cores; reported, not the target).
+A "step" is one pass of the hot path over one batch: one env transition (with fused auto-reset) of every
+instance on the GPU, the full observation / reward / flags written to HBM.  Default workload = BASELINE.json
+configs[1]: SnakeEnv 10x10, 1,048,576 parallel envs per GPU (weak scaling: per-GPU batch fixed, global env
+indices sharded contiguously, no collective on the data path).  Two paths are measured in every run:
+
+  rollout (headline `value`)  the K timed steps fused in ONE launch per GPU — the K-steps-per-launch entry point
+                              SURVEY.md section 7 / BASELINE.md section 3 prescribe for the roofline target: env state
+                              stays in registers, the observation is still written to HBM every step, actions come
+                              from the device-side counter hash (cge_hash_action);
+  step   (`api_step` block)   K separate C-ABI step() calls through the VectorEnv facade with HBM-resident
+                              actions — what a gymnasium.vector consumer calls.
+
+`--path step` makes the API path the headline instead.  Prints ONE JSON line on rank 0 carrying `roofline` for
+the dominant kernel (algorithmic bytes of SURVEY 8d / HIP-event time on the launch stream; `traffic` = HBM bytes
+per launch from the committed rocprofv3 PMC passes, profiles/traffic.json) and `cpu_baseline` (the oracle's C
+port of the reference on this box's host cores: reported, not the target).
 """
 import argparse
 import json
@@ -25,87 +34,84 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
-# algorithmic bytes per env-step, SURVEY.md section 8d
-ALGO_BYTES = {"snake": 145, "crypto": 2346, "traffic": 1134}
-WORKLOADS = {
-    "snake_1m": dict(env="snake", n_per_gpu=1 << 20, grid=10,
-                     desc="SnakeEnv 10x10, 1,048,576 parallel envs per GPU, random actions, fused auto-reset"),
-    "snake_64k": dict(env="snake", n_per_gpu=1 << 16, grid=10, desc="SnakeEnv 10x10, 65,536 envs per GPU (quick check)"),
-    "crypto_1m": dict(env="crypto", n_per_gpu=1 << 20,
-                      desc="crypto_trading_env discrete, 1,048,576 parallel envs per GPU, random actions, fused auto-reset"),
+# algorithmic bytes per env-step (secondary envs: obs + actions + reward/flags + 2 x state + RNG)
+ENVS = {
+    "snake":   dict(algo=145,  n_act=4, act_shape=(),   dtype="i8",   step_kernel="cge::snake::step_kernel<10, 256, 1, 8>",
+                    roll_kernel="cge::snake::rollout_kernel<10, 256, 1, 8>", ref_py="3.4e5-4.2e5 steps/s/process"),
+    "crypto":  dict(algo=2346, n_act=5, act_shape=(),   dtype="f64",  step_kernel="cge::crypto::step_kernel<false>",
+                    roll_kernel="cge::crypto::step_kernel<true>", ref_py="1.64e3-1.68e3 steps/s/process"),
+    "traffic": dict(algo=1134, n_act=3, act_shape=(9,), dtype="int32", step_kernel="cge::traffic::step_kernel<false>",
+                    roll_kernel="cge::traffic::step_kernel<true>", ref_py="1.75e3-1.90e3 steps/s/process"),
+    "parking": dict(algo=662,  n_act=8, act_shape=(),   dtype="f64",  step_kernel="cge::parking::step_kernel<false>",
+                    roll_kernel="cge::parking::step_kernel<true>", ref_py="2.66e4 steps/s/process"),
+    "climate": dict(algo=218,  n_act=None, act_shape=None, dtype="f64", step_kernel="cge::climate::step_kernel<false>",
+                    roll_kernel="cge::climate::step_kernel<true>", ref_py="1.27e4 steps/s/process"),
+    "fleet":   dict(algo=642,  n_act=8, act_shape=(3,), dtype="f64",  step_kernel="cge::fleet::step_kernel<false>",
+                    roll_kernel="cge::fleet::step_kernel<true>", ref_py="2.01e4 steps/s/process"),
 }
-WORKLOADS["traffic_262k"] = dict(env="traffic", n_per_gpu=1 << 18,
-                                 desc="traffic_management_env (9 intersections), 262,144 parallel envs per GPU, random actions, fused auto-reset")
-KERNELS = {("snake", "step"): "cge::snake::step_kernel<10, 256, 1, 8>", ("snake", "rollout"): "cge::snake::rollout_kernel<10, 256, 1, 8>",
-           ("crypto", "step"): "cge::crypto::step_kernel<false>", ("crypto", "rollout"): "cge::crypto::step_kernel<true>",
-           ("traffic", "step"): "cge::traffic::step_kernel<false>", ("traffic", "rollout"): "cge::traffic::step_kernel<true>"}
-N_ACTIONS = {"snake": 4, "crypto": 5, "traffic": 3}
-DTYPE = {"snake": "i8", "crypto": "f64", "traffic": "int32"}
+WORKLOADS = {
+    "snake_1m": dict(env="snake", n=1 << 20, desc="SnakeEnv 10x10, 1,048,576 parallel envs per GPU, random actions, fused auto-reset"),
+    "snake_64k": dict(env="snake", n=1 << 16, desc="SnakeEnv 10x10, 65,536 envs per GPU (quick check)"),
+    "crypto_1m": dict(env="crypto", n=1 << 20, desc="crypto_trading_env discrete, 1,048,576 parallel envs per GPU"),
+    "traffic_262k": dict(env="traffic", n=1 << 18, desc="traffic_management_env (9 intersections), 262,144 parallel envs per GPU"),
+    "parking_131k": dict(env="parking", n=1 << 17, desc="smart_parking_env, 131,072 parallel envs per GPU"),
+    "climate_131k": dict(env="climate", n=1 << 17, desc="smartclimate, 131,072 parallel envs per GPU"),
+    "fleet_131k": dict(env="fleet", n=1 << 17, desc="fleet_management_env, 131,072 parallel envs per GPU"),
+    "hetero_131k": dict(env="hetero", n=1 << 17,
+                        desc="heterogeneous batch: every implemented env type x 131,072, co-resident on each GPU, one HIP stream per type"),
+}
 
 
-def cpu_baseline_snake(grid, budget_s=12.0):
-    """Times the oracle (C port of snake_env.py, single-threaded per handle) on all host cores:
-    one handle per thread, ctypes releases the GIL.  Bounded sample of the same workload."""
+def make_env(cge, name, n, dev, env0):
+    kw = dict(device=dev, autoreset_mode="SameStep", env_index0=env0, reuse_buffers=True)
+    if name == "snake":
+        return cge.SnakeVectorEnv(n, grid_size=10, **kw)
+    if name == "crypto":
+        return cge.CryptoVectorEnv(n, action_type="discrete", **kw)
+    return {"traffic": cge.TrafficVectorEnv, "parking": cge.ParkingVectorEnv, "climate": cge.ClimateVectorEnv,
+            "fleet": cge.FleetVectorEnv}[name](n, **kw)
+
+
+def make_actions(name, steps, n, dev):
+    """Synthetic action stream resident in HBM before the timed region."""
+    if name == "climate":
+        return (torch.rand((steps, n, 1), device=dev) * 16 + 16, torch.randint(0, 2, (steps, n, 4), dtype=torch.int8, device=dev))
+    spec = ENVS[name]
+    return torch.randint(0, spec["n_act"], (steps, n) + spec["act_shape"], dtype=torch.int32, device=dev)
+
+
+def act_at(name, actions, t):
+    return (actions[0][t], actions[1][t]) if name == "climate" else actions[t]
+
+
+def cpu_baseline(name, budget_s=12.0):
+    """Times the oracle (C port of the reference, single-threaded per handle) on the box's CPU share: one handle per
+    thread (ctypes releases the GIL), a bounded sample of the same workload (hash actions, auto-reset)."""
     import oracle
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, 16))        # a 1-GPU box's CPU share is 16 cores
-    n_each, k = 8192, 250
-    # calibrate on one core, then size the sample to roughly budget_s of wall time
-    o = oracle.SnakeOracle(n_each, grid, oracle.SAME_STEP)
-    o.reset()
+    n_each, k = {"snake": (8192, 250), "crypto": (256, 100), "traffic": (1024, 100), "parking": (1024, 100),
+                 "climate": (2048, 100), "fleet": (1024, 100)}[name]
+    ctor = {"snake": lambda: oracle.SnakeOracle(n_each, 10, oracle.SAME_STEP),
+            "crypto": lambda: oracle.CryptoOracle(n_each, "discrete", oracle.SAME_STEP),
+            "traffic": lambda: oracle.TrafficOracle(n_each, oracle.SAME_STEP), "parking": lambda: oracle.ParkingOracle(n_each, oracle.SAME_STEP),
+            "climate": lambda: oracle.ClimateOracle(n_each, oracle.SAME_STEP), "fleet": lambda: oracle.FleetOracle(n_each, oracle.SAME_STEP)}[name]
+
+    def new(c):
+        h = ctor()
+        h.seed(np.arange(c * n_each, (c + 1) * n_each, dtype=np.uint64))
+        h.reset()
+        return h
+
+    o = new(0)
     t = time.perf_counter()
     o.rollout(k, 123, 0, 0)
     one = time.perf_counter() - t
     reps = max(1, min(int(budget_s / max(one, 1e-3)), 2000))
-    handles = []
-    for c in range(cores):
-        h = oracle.SnakeOracle(n_each, grid, oracle.SAME_STEP)
-        h.seed(np.arange(c * n_each, (c + 1) * n_each, dtype=np.uint64))
-        h.reset()
-        handles.append(h)
-
-    def work(c):
-        for r in range(reps):
-            handles[c].rollout(k, 123, r * k, c * n_each)
-
-    th = [threading.Thread(target=work, args=(c,)) for c in range(cores)]
-    t = time.perf_counter()
-    for x in th:
-        x.start()
-    for x in th:
-        x.join()
-    dt = time.perf_counter() - t
-    steps = cores * reps * n_each * k
-    return dict(value=steps / dt, unit="env-steps/s", cores=cores, kind="port",
-                sample=f"{cores} threads x {n_each} envs x {reps * k} steps of the same workload (hash actions, auto-reset), "
-                       f"oracle/orc_snake.c; single-core rate {n_each * k / one:.3e}",
-                reference_python_note="reference Python measured in the build container (8-core Xeon 2.6 GHz): "
-                                      "3.4e5-4.2e5 steps/s/process, 1.81e6 over 8 processes (BASELINE.md section 2)")
-
-
-def cpu_baseline_crypto(budget_s=12.0):
-    import oracle
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 16))
-    n_each, k = 256, 100
-    o = oracle.CryptoOracle(n_each, "discrete", oracle.SAME_STEP)
-    o.reset()
-    t = time.perf_counter()
-    o.rollout(k, 123, 0, 0)
-    one = time.perf_counter() - t
-    reps = max(1, min(int(budget_s / max(one, 1e-3)), 2000))
-    handles = []
-    for c in range(cores):
-        h = oracle.CryptoOracle(n_each, "discrete", oracle.SAME_STEP)
-        h.seed(np.arange(c * n_each, (c + 1) * n_each, dtype=np.uint64))
-        h.reset()
-        handles.append(h)
+    handles = [new(c) for c in range(cores)]
 
     def work(c):
         for r in range(reps):
@@ -119,58 +125,28 @@ def cpu_baseline_crypto(budget_s=12.0):
         x.join()
     dt = time.perf_counter() - t
     return dict(value=cores * reps * n_each * k / dt, unit="env-steps/s", cores=cores, kind="port",
-                sample=f"{cores} threads x {n_each} envs x {reps * k} steps (hash actions, auto-reset, obs assembled every step), "
-                       f"oracle/orc_crypto.c; single-core rate {n_each * k / one:.3e}",
-                reference_python_note="reference Python in the build container: 1.64e3-1.68e3 steps/s/process (BASELINE.md section 2)")
-
-
-def cpu_baseline_traffic(budget_s=12.0):
-    import oracle
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 16))
-    n_each, k = 1024, 100
-    o = oracle.TrafficOracle(n_each, oracle.SAME_STEP)
-    o.reset()
-    t = time.perf_counter()
-    o.rollout(k, 123, 0, 0)
-    one = time.perf_counter() - t
-    reps = max(1, min(int(budget_s / max(one, 1e-3)), 2000))
-    handles = []
-    for c in range(cores):
-        h = oracle.TrafficOracle(n_each, oracle.SAME_STEP)
-        h.seed(np.arange(c * n_each, (c + 1) * n_each, dtype=np.uint64))
-        h.reset()
-        handles.append(h)
-
-    def work(c):
-        for r in range(reps):
-            handles[c].rollout(k, 123, r * k, c * n_each)
-
-    th = [threading.Thread(target=work, args=(c,)) for c in range(cores)]
-    t = time.perf_counter()
-    for x in th:
-        x.start()
-    for x in th:
-        x.join()
-    dt = time.perf_counter() - t
-    return dict(value=cores * reps * n_each * k / dt, unit="env-steps/s", cores=cores, kind="port",
-                sample=f"{cores} threads x {n_each} envs x {reps * k} steps (hash actions, auto-reset, obs assembled every step), "
-                       f"oracle/orc_traffic.c (collapsed state, no O(V*I) sqrt loop); single-core rate {n_each * k / one:.3e}",
-                reference_python_note="reference Python in the build container: 1.75e3-1.90e3 steps/s/process (BASELINE.md section 2)")
+                sample=f"{cores} threads x {n_each} envs x {reps * k} steps of the same workload, oracle/orc_{name}.c; "
+                       f"single-core rate {n_each * k / one:.3e}",
+                reference_python_note=f"the reference's own Python, measured in the build container (8-core Xeon 2.6 GHz): "
+                                      f"{ENVS[name]['ref_py']} (BASELINE.md section 2)")
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
-    tools_profile_summary.py: 2*FETCH_SIZE + WRITE_SIZE, the gfx950 read-side correction of
-    MI355X_MICROARCH.md section HBM).  None when no profile of this kernel has been committed."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             return json.load(f).get(kernel)
     except (OSError, ValueError):
         return None
+
+
+def roofline(name, kernel, gpu_ms, launches, steps_per_launch, n):
+    algo = ENVS[name]["algo"]
+    launch_s = gpu_ms * 1e-3 / launches
+    achieved = algo * n * steps_per_launch / launch_s / 1e9
+    return {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": pmc_traffic(kernel) if steps_per_launch == 1 else None, "algorithmic_bytes_per_env_step": algo,
+            "env_steps_per_launch": n * steps_per_launch, "avg_launch_us": launch_s * 1e6,
+            "timing": "HIP events on the launch stream over the timed region"}
 
 
 def main():
@@ -179,9 +155,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="snake_1m", choices=sorted(WORKLOADS))
-    ap.add_argument("--path", default="step", choices=["step", "rollout"],
-                    help="step: one C-ABI step() launch per step with HBM-resident actions (default); "
-                         "rollout: the K steps fused in one launch (device-side action hash)")
+    ap.add_argument("--path", default="rollout", choices=["rollout", "step"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -202,21 +176,17 @@ def main():
 
     import custom_gymnasium_environments_amd as cge
     wl = WORKLOADS[args.workload]
-    n = wl["n_per_gpu"]
-    K, W = args.steps, args.warmup
+    n, K, W = wl["n"], args.steps, args.warmup
     dev = torch.device("cuda", local_rank)
-    if wl["env"] == "snake":
-        env = cge.SnakeVectorEnv(n, grid_size=wl["grid"], device=dev, autoreset_mode="SameStep", env_index0=rank * n,
-                                 reuse_buffers=True)
-    elif wl["env"] == "crypto":
-        env = cge.CryptoVectorEnv(n, action_type="discrete", device=dev, autoreset_mode="SameStep", env_index0=rank * n,
-                                  reuse_buffers=True)
+    names = sorted(ENVS) if wl["env"] == "hetero" else [wl["env"]]
+    envs = {nm: make_env(cge, nm, n, dev, rank * n) for nm in names}
+    if len(names) > 1:
+        streams = {nm: torch.cuda.Stream(device=dev) for nm in names}
     else:
-        env = cge.TrafficVectorEnv(n, device=dev, autoreset_mode="SameStep", env_index0=rank * n, reuse_buffers=True)
-    env.reset(seed=0)
-    # synthetic action stream, resident in HBM before timing
-    ashape = (K + W, n, 9) if wl["env"] == "traffic" else (K + W, n)
-    actions = torch.randint(0, N_ACTIONS[wl["env"]], ashape, dtype=torch.int32, device=dev)
+        streams = {names[0]: torch.cuda.current_stream(dev)}
+    for e in envs.values():
+        e.reset(seed=0)
+    torch.cuda.synchronize()
 
     def barrier():
         torch.cuda.synchronize()
@@ -224,83 +194,80 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if args.path == "step":
-        for t in range(W):
-            env.step(actions[t])
+    def run_rollout(k, t0):
+        for nm in names:
+            with torch.cuda.stream(streams[nm]):
+                envs[nm].rollout(k, action_seed=123, t0=t0)
+
+    def run_steps(actions, lo, hi):
+        for t in range(lo, hi):
+            for nm in names:
+                with torch.cuda.stream(streams[nm]):
+                    envs[nm].step(act_at(nm, actions[nm], t))
+
+    def timed(fn):
         barrier()
+        evs = {nm: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for nm in names}
         t0 = time.perf_counter()
-        ev0.record()                      # same stream the kernels are launched on (torch current stream)
-        for t in range(W, W + K):
-            env.step(actions[t])
-        ev1.record()
+        for nm in names:
+            evs[nm][0].record(streams[nm])          # on the stream the kernels are launched on
+        fn()
+        for nm in names:
+            evs[nm][1].record(streams[nm])
         barrier()
         wall = time.perf_counter() - t0
-        launches = K
-        kernel = KERNELS[(wl["env"], "step")]
-    else:
-        env.rollout(max(W, 1), action_seed=123, t0=0)
-        barrier()
-        t0 = time.perf_counter()
-        ev0.record()
-        env.rollout(K, action_seed=123, t0=W)
-        ev1.record()
-        barrier()
-        wall = time.perf_counter() - t0
-        launches = 1
-        kernel = KERNELS[(wl["env"], "rollout")]
-    gpu_ms = ev0.elapsed_time(ev1)
-    if wl["env"] == "snake":
-        assert env.invalid_action_count() == 0
-    fused = None
-    if args.path == "step":
-        # reported beside the headline, outside its timed region: the same K steps fused in one launch
-        # (state stays in registers; obs still written to HBM every step; device-side action hash)
-        env.rollout(max(W, 1), action_seed=123, t0=0)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        env.rollout(K, action_seed=123, t0=W)
-        e1.record()
-        torch.cuda.synchronize()
-        f_ms = e0.elapsed_time(e1)
-        f_ach = ALGO_BYTES[wl["env"]] * n * K / (f_ms * 1e-3) / 1e9
-        fused = {"path": "rollout (one launch, K fused steps)", "kernel": KERNELS[(wl["env"], "rollout")],
-                 "env_steps_per_s_per_gpu": n * K / (f_ms * 1e-3), "us_per_step": f_ms * 1e3 / K,
-                 "roofline": {"bound": "hbm", "achieved": f_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": f_ach / HBM_PEAK_GBS}}
+        return wall, {nm: evs[nm][0].elapsed_time(evs[nm][1]) for nm in names}
 
-    wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
-    wall_max = float(wall_t.item())
+    results = {}
+    run_rollout(max(W, 1), 0)                                        # fused rollout: K steps in one launch per env type
+    results["rollout"] = timed(lambda: run_rollout(K, W))
+    actions = {nm: make_actions(nm, K + W, n, dev) for nm in names}  # API path: K step() calls, HBM-resident actions
+    run_steps(actions, 0, W)
+    results["step"] = timed(lambda: run_steps(actions, W, W + K))
+    if "snake" in envs:
+        assert envs["snake"].invalid_action_count() == 0
 
+    def reduce_max(x):
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    walls = {p: reduce_max(results[p][0]) for p in results}
     if rank == 0:
-        total_steps = n * world * K
-        value = total_steps / wall_max
-        algo = ALGO_BYTES[wl["env"]]
-        launch_s = gpu_ms * 1e-3 / launches
-        units_per_launch = n * (K if args.path == "rollout" else 1)
-        achieved = algo * units_per_launch / launch_s / 1e9
+        head, other = args.path, ("step" if args.path == "rollout" else "rollout")
+        total_envs = n * len(names) * world
+
+        def block(path):
+            wall, gpu_ms = walls[path], results[path][1]
+            b = {"path": path, "value": total_envs * K / wall, "unit": "env-steps/s", "ms_per_step": wall * 1e3 / K}
+            rl = {}
+            for nm in names:
+                kern = ENVS[nm]["roll_kernel" if path == "rollout" else "step_kernel"]
+                rl[nm] = roofline(nm, kern, gpu_ms[nm], 1 if path == "rollout" else K, K if path == "rollout" else 1, n)
+            b["roofline"] = rl[names[0]] if len(names) == 1 else rl
+            return b
+
+        hb = block(head)
         out = {
             "metric": "env steps/sec (whole node) at 1M parallel envs; achieved HBM GB/s vs peak",
-            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": wall_max * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": DTYPE[wl["env"]], "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {wl['desc']}", "envs_per_gpu": n, "path": args.path,
+            "value": hb["value"], "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": hb["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": ENVS[names[0]]["dtype"] if len(names) == 1 else "mixed", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {wl['desc']}", "envs_per_gpu": n * len(names), "env_types": names,
+                       "path": ("fused rollout: the K steps in one launch per GPU, obs written to HBM every step, device-side action hash"
+                                if head == "rollout" else "K C-ABI step() calls through the VectorEnv facade, HBM-resident actions"),
                        "autoreset": "SameStep", "parallelism": f"env-sharded x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kernel),
-                         "algorithmic_bytes_per_env_step": algo, "env_steps_per_launch": units_per_launch,
-                         "avg_launch_us": launch_s * 1e6, "timing": "HIP events on the launch stream over the timed region"},
+            "roofline": hb["roofline"] if len(names) == 1 else hb["roofline"]["snake"],
         }
-        if fused is not None:
-            out["fused_rollout"] = fused
+        if len(names) > 1:
+            out["roofline_per_env_type"] = hb["roofline"]
+        out["api_step" if other == "step" else "fused_rollout"] = block(other)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = (cpu_baseline_snake(wl["grid"]) if wl["env"] == "snake" else
-                                   cpu_baseline_crypto() if wl["env"] == "crypto" else cpu_baseline_traffic())
+            out["cpu_baseline"] = cpu_baseline(names[0] if len(names) == 1 else "snake")
         print(json.dumps(out), flush=True)
-    env.close()
+    for e in envs.values():
+        e.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
