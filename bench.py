@@ -46,8 +46,8 @@ ENVS = {
                     roll_kernel="cge::parking::step_kernel<true>", ref_py="2.66e4 steps/s/process"),
     "climate": dict(algo=218,  n_act=None, act_shape=None, dtype="f64", step_kernel="cge::climate::step_kernel<false>",
                     roll_kernel="cge::climate::step_kernel<true>", ref_py="1.27e4 steps/s/process"),
-    "fleet":   dict(algo=642,  n_act=8, act_shape=(3,), dtype="f64",  step_kernel="cge::fleet::step_kernel<false>",
-                    roll_kernel="cge::fleet::step_kernel<true>", ref_py="2.01e4 steps/s/process"),
+    "fleet":   dict(algo=642,  n_act=8, act_shape=(3,), dtype="f64",  step_kernel="cge::fleet::step_kernel + cge::fleet::dense_kernel",
+                    roll_kernel="cge::fleet::step_kernel + cge::fleet::dense_kernel", launches_per_step=True, ref_py="2.01e4 steps/s/process"),
 }
 WORKLOADS = {
     "snake_1m": dict(env="snake", n=1 << 20, desc="SnakeEnv 10x10, 1,048,576 parallel envs per GPU, random actions, fused auto-reset"),
@@ -244,7 +244,9 @@ def main():
             rl = {}
             for nm in names:
                 kern = ENVS[nm]["roll_kernel" if path == "rollout" else "step_kernel"]
-                rl[nm] = roofline(nm, kern, gpu_ms[nm], 1 if path == "rollout" else K, K if path == "rollout" else 1, n)
+                # fleet's rollout is K (step, dense) launch pairs, not one fused launch: price it per pair
+                fused = path == "rollout" and not ENVS[nm].get("launches_per_step")
+                rl[nm] = roofline(nm, kern, gpu_ms[nm], 1 if fused else K, K if fused else 1, n)
             b["roofline"] = rl[names[0]] if len(names) == 1 else rl
             return b
 

@@ -184,6 +184,156 @@ struct LdsDraws {
     }
 };
 
+// Bulk variant for kernels that run FEW waves and are bound by the latency of one lane's serial draw chain
+// (fleet's dense reset kernel): one rolled-loop fill parks W <= 227 twisted words per lane (no word of such a
+// window depends on another), so a whole episode reset normally needs a single, wave-convergent fill per
+// stream.  Same (pos, pretw) cursor contract as LdsDraws; flush() commits only the consumed words.
+template <int W>
+struct LdsBulkDraws {
+    static_assert(W <= MT_N - MT_M, "window words must be mutually independent");
+    uint32_t *row;
+    uint32_t *blk;
+    uint32_t pos, pretw, cur;
+    bool filled;
+
+    __device__ __forceinline__ LdsBulkDraws(uint32_t *lds_row, uint32_t *block, uint32_t pos_, uint32_t pretw_)
+        : row(lds_row), blk(block), pos(pos_), pretw(pretw_), cur(0), filled(false) {}
+    static constexpr int CH = 32;                              // words per round trip (2*CH+1 loads in flight)
+    static_assert(W % CH == 0, "window is filled in whole chunks");
+    __device__ __forceinline__ void fill() {
+#pragma unroll 1
+        for (int c0 = 0; c0 < W; c0 += CH) {
+            MtWindow<CH> w;                                    // loads first, unconditionally: one round trip per chunk
+            w.load(blk, pos + (uint32_t)c0);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) row[c0 + j] = w.twisted(j, pos + (uint32_t)c0, pretw);
+        }
+        cur = 0;
+        filled = true;
+    }
+    __device__ __forceinline__ void flush() {
+        if (!filled) return;
+        for (uint32_t j = 0; j < cur; ++j) {
+            uint32_t k = pos + j;
+            if (k >= pretw) {
+                k -= k >= (uint32_t)MT_N ? MT_N : 0;
+                blk[k] = row[j];
+            }
+        }
+        uint32_t p = pos + cur;
+        if (p >= (uint32_t)MT_N) { p -= MT_N; pretw = 0; }
+        pos = p;
+        cur = 0;
+        filled = false;
+    }
+    // rare (window exhausted mid-path): a real call, by value, so the cursor fields stay in registers
+    static __device__ __attribute__((noinline)) uint2 refill(uint32_t *row, uint32_t *blk, uint32_t pos, uint32_t pretw, uint32_t cur, bool filled) {
+        LdsBulkDraws d(row, blk, pos, pretw);
+        d.cur = cur; d.filled = filled;
+        d.flush();
+        d.fill();
+        return make_uint2(d.pos, d.pretw);
+    }
+    __device__ __forceinline__ uint32_t next() {
+        if (!filled || cur == (uint32_t)W) {
+            const uint2 r = refill(row, blk, pos, pretw, cur, filled);
+            pos = r.x; pretw = r.y; cur = 0; filled = true;
+        }
+        return mt_temper(row[cur++]);
+    }
+    __device__ __forceinline__ uint32_t randbelow(uint32_t n, int kbits) {
+        uint32_t r = next() >> (32 - kbits);
+        while (r >= n) r = next() >> (32 - kbits);
+        return r;
+    }
+    __device__ __forceinline__ double random53() {
+        const uint32_t a = next() >> 5, b = next() >> 6;
+        return (a * 67108864.0 + b) / 9007199254740992.0;
+    }
+};
+
+// readlane with a wave-uniform lane index; the builtin is typed int, so cast back before widening
+__device__ __forceinline__ uint32_t lane_u32(uint32_t v, int r) { return (uint32_t)__builtin_amdgcn_readlane((int)v, r); }
+__device__ __forceinline__ uint32_t *lane_ptr(uint32_t lo, uint32_t hi, int r) {
+    return reinterpret_cast<uint32_t *>(((uint64_t)lane_u32(hi, r) << 32) | (uint64_t)lane_u32(lo, r));
+}
+
+// Wave-cooperative fill / flush of LdsBulkDraws windows.  Lane r (< DLN) owns stream r and LDS row r; the whole
+// wave then serves one stream at a time: 64 lanes load 64 CONSECUTIVE state words (one 256-byte coalesced access
+// instead of 64 lanes each walking their own 2560-byte block), twist, and park the words in row r.  Per lane the
+// own-block walk costs 2W+1 narrow loads that all hit the same 2-4 cache lines while those are still in flight.
+// RG rows per round trip: all 3 * RG * ceil(W/64) loads are issued (unconditionally, from valid addresses) before
+// the first use, then twisted and parked — written loads-first on purpose, a fused per-word loop makes the
+// compiler wait for memory once per 64 words.
+template <int W, int DLN, int RG>
+__device__ __forceinline__ void coop_fill(LdsBulkDraws<W> &d, int row_stride, bool need) {
+    static_assert(DLN % RG == 0, "row groups");
+    constexpr int NQ = (W + 63) / 64;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lo = (uint32_t)reinterpret_cast<uintptr_t>(d.blk), hi = (uint32_t)(reinterpret_cast<uintptr_t>(d.blk) >> 32);
+    uint32_t *rows = d.row - (lane < (uint32_t)DLN ? lane : 0u) * row_stride;      // row 0 of this wave
+    const uint32_t needw = need ? 1u : 0u;
+#pragma unroll 1
+    for (int r0 = 0; r0 < DLN; r0 += RG) {
+        uint32_t a[RG][NQ], b[RG][NQ], c[RG][NQ];
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+            const uint32_t *blk = lane_ptr(lo, hi, r0 + g);
+            const uint32_t pos = lane_u32(d.pos, r0 + g);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                uint32_t k = pos + 64u * q + lane;                                  // < 624 + 256: one wrap
+                k -= k >= (uint32_t)MT_N ? MT_N : 0;
+                const uint32_t k1 = k + 1 == (uint32_t)MT_N ? 0 : k + 1;
+                const uint32_t km = k + MT_M >= (uint32_t)MT_N ? k + MT_M - MT_N : k + MT_M;
+                a[g][q] = blk[k]; b[g][q] = blk[k1]; c[g][q] = blk[km];
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+            const uint32_t pos = lane_u32(d.pos, r0 + g), pretw = lane_u32(d.pretw, r0 + g);
+            const bool on = lane_u32(needw, r0 + g) != 0;
+            uint32_t *row = rows + (r0 + g) * row_stride;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const uint32_t j = 64u * q + lane;
+                const uint32_t y = mt_twist(a[g][q], b[g][q], c[g][q]), m = 0u - (uint32_t)(pos + j < pretw);
+                if (on && j < (uint32_t)W) row[j] = (a[g][q] & m) | (y & ~m);
+            }
+        }
+    }
+    if (need) { d.cur = 0; d.filled = true; }
+}
+template <int W, int DLN>
+__device__ __forceinline__ void coop_flush(LdsBulkDraws<W> &d, int row_stride) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lo = (uint32_t)reinterpret_cast<uintptr_t>(d.blk), hi = (uint32_t)(reinterpret_cast<uintptr_t>(d.blk) >> 32);
+    uint32_t *rows = d.row - (lane < (uint32_t)DLN ? lane : 0u) * row_stride;
+    const uint32_t curw = (d.filled && lane < (uint32_t)DLN) ? d.cur : 0u;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 2
+    for (int r = 0; r < DLN; ++r) {
+        uint32_t *blk = lane_ptr(lo, hi, r);
+        const uint32_t pos = lane_u32(d.pos, r), pretw = lane_u32(d.pretw, r);
+        const uint32_t cur = lane_u32(curw, r);
+        const uint32_t *row = rows + r * row_stride;
+#pragma unroll
+        for (int q = 0; q < (W + 63) / 64; ++q) {
+            const uint32_t j = 64u * q + lane;
+            uint32_t k = pos + j;
+            if (j < cur && k >= pretw) {
+                k -= k >= (uint32_t)MT_N ? MT_N : 0;
+                blk[k] = row[j];
+            }
+        }
+    }
+    if (d.filled) {
+        uint32_t p = d.pos + d.cur;
+        if (p >= (uint32_t)MT_N) { p -= MT_N; d.pretw = 0; }
+        d.pos = p; d.cur = 0; d.filled = false;
+    }
+}
+
 // ------------------------------------------------------------------ small register arrays
 // Runtime-indexed register arrays go to scratch on hipcc; these helpers keep every index static
 // (fully unrolled select chains) so the env state stays in VGPRs.

@@ -9,9 +9,10 @@
 // deliveries in two dwords each (cells, urgency, vehicle requirement, window, deadline, pickup time), the 5x5
 // traffic map at 2 bits per cell, weather index, counters and both generators' cursors.  Rewards are sums of
 // small integers (exact); fuel is float64 in the reference's operation order -> obs and reward bit-identical.
-// RNG: draws are rare in step() (traffic every 50 steps, weather every 100) and heavy in reset() (~150 words
+// RNG: draws are rare in step() (traffic every 50 steps, weather every 100) and heavy in reset() (~220 words
 // over two interleaved streams: NumPy-legacy masked randint / choice(p) / random and CPython random.choice over
-// 144 cells) -> both MT19937 windows are parked in LDS (LdsDraws), 16 words per round trip.
+// 144 cells).  step_kernel therefore draws NOTHING: it lists the 1-3 % of envs that need draws, and dense_kernel
+// serves that list with full waves and one bulk LDS window per stream (LdsBulkDraws).
 // The (N,76) float32 obs is staged whole in LDS ([64][77] per wave) and written in one linear pass, so every
 // 128-byte line of the output is completed within a few instructions.
 #include <cstring>
@@ -27,8 +28,13 @@ constexpr int OBS = 76;
 constexpr int ROW = 77;
 constexpr int MAXD = 12;
 constexpr int COLS = 10;
-constexpr int DW = 16;
-constexpr int DROW = 17;
+// dense kernel: DL lanes (envs) per wave, one bulk window per stream sized so a whole reset normally fits
+// (L: nd + <=12 x ~8 + 58 traffic words ~ 170; P: <=12 x ~4 ~ 48), odd LDS row strides
+constexpr int DL = 8;
+constexpr int WL = 224, WP = 96;
+constexpr int LROW = WL + 1, PROW = WP + 1;
+using DrawsL = LdsBulkDraws<WL>;
+using DrawsP = LdsBulkDraws<WP>;
 constexpr int BLOCK = 64;
 
 struct Params {
@@ -45,7 +51,13 @@ struct Params {
     int64_t t0, obs_step_stride;
     double *reward_sum;
     int32_t *done_count;
+    int32_t t_index, accumulate;
+    uint32_t *work_count;      // [2] alternating counters of the deferred-work list
+    uint64_t *work_list;       // [n] entries: env index << 3 | W_* flags
+    int32_t parity;
 };
+
+enum : uint32_t { W_TRAFFIC = 1u, W_WEATHER = 2u, W_RESET = 4u };
 
 __device__ __forceinline__ double vrange(int k) { return k == 0 ? 80.0 : k == 1 ? 120.0 : 60.0; }     // :128-132
 __device__ __forceinline__ double vcons(int k) { return k == 0 ? 1.0 : k == 1 ? 0.5 : 2.0; }
@@ -118,7 +130,7 @@ struct Env {
 };
 
 // NumPy legacy helpers on the L stream
-__device__ __forceinline__ uint32_t np_randint(LdsDraws<DW> &L, uint32_t lo, uint32_t hi) {   // masked rejection on 32-bit words
+__device__ __forceinline__ uint32_t np_randint(DrawsL &L, uint32_t lo, uint32_t hi) {   // masked rejection on 32-bit words
     const uint32_t rng = hi - lo - 1u;
     uint32_t mask = rng;
     mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
@@ -127,12 +139,12 @@ __device__ __forceinline__ uint32_t np_randint(LdsDraws<DW> &L, uint32_t lo, uin
     return lo + v;
 }
 // choice(n, p): searchsorted(cumsum(p)/sum, random_sample(), 'right'); the normalised cdf values are passed in
-__device__ __forceinline__ uint32_t np_choice_cdf(LdsDraws<DW> &L, double c0, double c1, double c2, double c3) {
+__device__ __forceinline__ uint32_t np_choice_cdf(DrawsL &L, double c0, double c1, double c2, double c3) {
     const double u = L.random53();
     return (uint32_t)(c0 <= u) + (uint32_t)(c1 <= u) + (uint32_t)(c2 <= u) + (uint32_t)(c3 <= u);
 }
 
-__device__ __forceinline__ void update_traffic(Env &e, LdsDraws<DW> &L) {                      // :516-522
+__device__ __forceinline__ void update_traffic(Env &e, DrawsL &L) {                      // :516-522
     // cdf of p=[0.6,0.3,0.1]: cumsum then / last, evaluated in float64 exactly as NumPy does
     const double a0 = 0.6, a1 = a0 + 0.3, a2 = a1 + 0.1;
     const double c0 = a0 / a2, c1 = a1 / a2, c2 = a2 / a2;
@@ -161,7 +173,7 @@ __device__ __forceinline__ uint32_t zone_cell(uint32_t zone, uint32_t k) {      
     return x | (y << 5);
 }
 
-__device__ __forceinline__ void do_reset(Env &e, int32_t max_steps, LdsDraws<DW> &P, LdsDraws<DW> &L) {   // :185-234
+__device__ __forceinline__ void do_reset(Env &e, int32_t max_steps, DrawsP &P, DrawsL &L) {   // :185-234
     e.timestep = 0; e.total_reward = 0.0; e.completed = 0; e.missed = 0; e.weather = 1; e.needs_reset = 0;   // weather index 1 = 1.0
 #pragma unroll
     for (int k = 0; k < 3; ++k) { e.veh[k] = 12u | (12u << 5); e.fuel[k] = vrange(k); }
@@ -265,17 +277,16 @@ __device__ __forceinline__ double vehicle_action(Env &e, int32_t a, int32_t max_
 }
 
 // returns terminated | truncated << 1
-__device__ __forceinline__ uint32_t env_step(Env &e, int32_t max_steps, int32_t a0, int32_t a1, int32_t a2, LdsDraws<DW> &L, double &reward) {   // :236-276
+// The traffic (every 50 steps) and weather (every 100) redraws (:257-262) are DEFERRED: they touch the RNG, only ~2 %
+// of the lanes need them in a given step, and neither reward nor termination depends on them — the flags go to the
+// work list and dense_kernel applies them (in the reference's order) before the obs row is final.
+__device__ __forceinline__ uint32_t env_step(Env &e, int32_t max_steps, int32_t a0, int32_t a1, int32_t a2, uint32_t &work, double &reward) {   // :236-276
     double total = 0.0;
     total += vehicle_action<0>(e, a0, max_steps);
     total += vehicle_action<1>(e, a1, max_steps);
     total += vehicle_action<2>(e, a2, max_steps);
     e.timestep += 1;
-    if (e.timestep % 50u == 0) update_traffic(e, L);
-    if (e.timestep % 100u == 0) {                                                                     // _update_weather :524-528
-        const double w0 = 0.3, w1 = w0 + 0.5, w2 = w1 + 0.15, w3 = w2 + 0.05;
-        e.weather = np_choice_cdf(L, w0 / w3, w1 / w3, w2 / w3, w3 / w3);
-    }
+    work = (e.timestep % 50u == 0 ? W_TRAFFIC : 0u) | (e.timestep % 100u == 0 ? W_WEATHER : 0u);
     uint32_t urgent = 0;
     bool all_done = true;
 #pragma unroll
@@ -293,9 +304,8 @@ __device__ __forceinline__ uint32_t env_step(Env &e, int32_t max_steps, int32_t 
     return (term ? 1u : 0u) | (e.timestep >= (uint32_t)max_steps ? 2u : 0u);
 }
 
-__device__ __forceinline__ void observe(const Env &e, int64_t nrows, float *__restrict__ dst, unsigned long long rowmask, uint32_t *__restrict__ tile) {
-    const uint32_t lane = threadIdx.x & 63u;
-    float *row = reinterpret_cast<float *>(tile) + lane * ROW;                                       // :555-593
+__device__ __forceinline__ void stage_row(const Env &e, uint32_t *__restrict__ tile_row) {
+    float *row = reinterpret_cast<float *>(tile_row);                                                // :555-593
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         row[2 * k] = (float)(e.veh[k] & 31u); row[2 * k + 1] = (float)((e.veh[k] >> 5) & 31u);
@@ -313,6 +323,11 @@ __device__ __forceinline__ void observe(const Env &e, int64_t nrows, float *__re
     }
 #pragma unroll
     for (int c = 0; c < 25; ++c) row[51 + c] = (float)(((c < 16 ? e.traffic[0] : e.traffic[1]) >> ((c & 15) * 2)) & 3u);
+}
+
+__device__ __forceinline__ void observe(const Env &e, int64_t nrows, float *__restrict__ dst, unsigned long long rowmask, uint32_t *__restrict__ tile) {
+    const uint32_t lane = threadIdx.x & 63u;
+    stage_row(e, tile + lane * ROW);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     uint32_t r = lane / (uint32_t)OBS, col = lane - r * (uint32_t)OBS;
 #pragma unroll 1
@@ -324,101 +339,135 @@ __device__ __forceinline__ void observe(const Env &e, int64_t nrows, float *__re
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-template <bool ROLLOUT>
+// One lane per env, NO random draws: vehicle actions, deadlines, termination, and the obs row of the state as it
+// stands.  Everything that needs the generators — the traffic/weather redraws and the 8-12 new delivery requests
+// of an episode reset (~150 draws over two interleaved streams, ~10k instructions) — happens for ~1-3 % of the
+// lanes per step; executed in place it cost every wave that whole path at 1/64 lane utilisation (234 us per
+// 131k-env step, profiles/r01_fleet_step_v1_summary.txt).  Those envs are appended to a work list instead and
+// dense_kernel processes them with full waves.
 __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
     __shared__ uint32_t tile[64 * ROW];
-    __shared__ uint32_t drawsP[64 * DROW], drawsL[64 * DROW];
     const int64_t i0 = (int64_t)blockIdx.x * BLOCK;
     const int64_t i = i0 + threadIdx.x;
     const bool live = i < p.n;
     const int64_t li = live ? i : i0;
     const int64_t nrows = p.n - i0 < 64 ? p.n - i0 : 64;
+    const int t = p.t_index;
     Env e;
     e.load(p.state, p.n, li);
-    LdsDraws<DW> P(drawsP + (threadIdx.x & 63u) * DROW, p.mtP + li * MT_STRIDE, e.ppos, e.ppretw);
-    LdsDraws<DW> L(drawsL + (threadIdx.x & 63u) * DROW, p.mtL + li * MT_STRIDE, e.lpos, e.lpretw);
-    const uint64_t key = ROLLOUT ? hash_env_key(p.a_seed, (uint64_t)(p.env0 + li)) : 0;
-    double rsum = 0.0;
-    int32_t dcount = 0;
-    const int ksteps = ROLLOUT ? p.k_steps : 1;
-#pragma unroll 1
-    for (int t = 0; t < ksteps; ++t) {
-        double reward = 0.0;
-        uint32_t flags = 0;
-        bool reset_now = false;
-        if (live) {
-            if (p.mode == CGE_AUTORESET_NEXT_STEP && e.needs_reset) {
-                reset_now = true;
-            } else {
-                int32_t a0, a1, a2;
-                if (p.actions) {
-                    const int32_t *ap = p.actions + ((int64_t)t * p.n + i) * 3;
-                    a0 = ap[0]; a1 = ap[1]; a2 = ap[2];
-                } else {
-                    a0 = (int32_t)hash_action_from_key(key, (uint64_t)(p.t0 + t), 8u, 0u);
-                    a1 = (int32_t)hash_action_from_key(key, (uint64_t)(p.t0 + t), 8u, 1u);
-                    a2 = (int32_t)hash_action_from_key(key, (uint64_t)(p.t0 + t), 8u, 2u);
-                }
-                flags = env_step(e, p.max_steps, a0, a1, a2, L, reward);
-                L.flush();
-                if (flags) {
-                    e.episodes += 1;
-                    if (p.mode == CGE_AUTORESET_SAME_STEP) reset_now = true;
-                    else if (p.mode == CGE_AUTORESET_NEXT_STEP) e.needs_reset = 1;
-                }
-            }
-        }
-        const unsigned long long fin_mask = __ballot(live && flags && reset_now);
-        if (fin_mask && p.final_obs) observe(e, nrows, p.final_obs + i0 * OBS, fin_mask, tile);
-        if (reset_now) { do_reset(e, p.max_steps, P, L); P.flush(); L.flush(); }
-        if (p.obs) observe(e, nrows, p.obs + (int64_t)t * p.obs_step_stride + i0 * OBS, ~0ull, tile);
-        if (live) {
-            if (ROLLOUT) {
-                rsum += reward;
-                dcount += flags ? 1 : 0;
-                if (p.reward) p.reward[(int64_t)t * p.n + i] = (float)reward;
-                if (p.terminated) p.terminated[(int64_t)t * p.n + i] = (uint8_t)flags;
-            } else {
-                p.reward[i] = (float)reward;
-                p.terminated[i] = (uint8_t)(flags & 1u);
-                p.truncated[i] = (uint8_t)((flags >> 1) & 1u);
-            }
-        }
-    }
+    double reward = 0.0;
+    uint32_t flags = 0, work = 0;
     if (live) {
-        e.ppos = P.pos; e.ppretw = P.pretw; e.lpos = L.pos; e.lpretw = L.pretw;
+        if (p.mode == CGE_AUTORESET_NEXT_STEP && e.needs_reset) {
+            work = W_RESET;                                    // reset-only step: action ignored, reward 0
+        } else {
+            int32_t a0, a1, a2;
+            if (p.actions) {
+                const int32_t *ap = p.actions + ((int64_t)t * p.n + i) * 3;
+                a0 = ap[0]; a1 = ap[1]; a2 = ap[2];
+            } else {
+                const uint64_t key = hash_env_key(p.a_seed, (uint64_t)(p.env0 + i));
+                a0 = (int32_t)hash_action_from_key(key, (uint64_t)(p.t0 + t), 8u, 0u);
+                a1 = (int32_t)hash_action_from_key(key, (uint64_t)(p.t0 + t), 8u, 1u);
+                a2 = (int32_t)hash_action_from_key(key, (uint64_t)(p.t0 + t), 8u, 2u);
+            }
+            flags = env_step(e, p.max_steps, a0, a1, a2, work, reward);
+            if (flags) {
+                e.episodes += 1;
+                if (p.mode == CGE_AUTORESET_SAME_STEP) work |= W_RESET;
+                else if (p.mode == CGE_AUTORESET_NEXT_STEP) e.needs_reset = 1;
+            }
+        }
         e.store(p.state, p.n, i);
-        if (ROLLOUT) {
-            if (p.reward_sum) p.reward_sum[i] = rsum;
-            if (p.done_count) p.done_count[i] = dcount;
+        if (work) {
+            const uint32_t slot = atomicAdd(&p.work_count[p.parity], 1u);
+            p.work_list[slot] = ((uint64_t)i << 3) | work;
+        }
+        if (p.accumulate) {
+            if (p.reward_sum) p.reward_sum[i] += reward;
+            if (p.done_count) p.done_count[i] += flags ? 1 : 0;
+            if (p.reward) p.reward[(int64_t)t * p.n + i] = (float)reward;
+            if (p.terminated) p.terminated[(int64_t)t * p.n + i] = (uint8_t)flags;
+        } else {
+            p.reward[i] = (float)reward;
+            p.terminated[i] = (uint8_t)(flags & 1u);
+            p.truncated[i] = (uint8_t)((flags >> 1) & 1u);
         }
     }
+    // rows of envs on the work list are rewritten by dense_kernel (also their final_obs row)
+    if (p.obs) observe(e, nrows, p.obs + (int64_t)t * p.obs_step_stride + i0 * OBS, ~0ull, tile);
 }
 
-// what: 0 reset(mask)+obs, 1 rewind cursors after seeding, 2 initial state of a fresh handle
-__global__ __launch_bounds__(BLOCK) void reset_kernel(Params p, int what) {
-    __shared__ uint32_t tile[64 * ROW];
-    __shared__ uint32_t drawsP[64 * DROW], drawsL[64 * DROW];
-    const int64_t i0 = (int64_t)blockIdx.x * BLOCK;
-    const int64_t i = i0 + threadIdx.x;
-    const bool live = i < p.n;
-    const int64_t li = live ? i : i0;
-    const int64_t nrows = p.n - i0 < 64 ? p.n - i0 : 64;
-    Env e;
-    e.load(p.state, p.n, li);
-    if (live) {
-        if (what == 1) { e.ppos = e.lpos = 0; e.ppretw = e.lpretw = 0; e.store(p.state, p.n, i); }
-        else if (what == 2) { e.weather = 1; e.store(p.state, p.n, i); }
-        else if (!p.mask || p.mask[i]) {
-            LdsDraws<DW> P(drawsP + (threadIdx.x & 63u) * DROW, p.mtP + li * MT_STRIDE, e.ppos, e.ppretw);
-            LdsDraws<DW> L(drawsL + (threadIdx.x & 63u) * DROW, p.mtL + li * MT_STRIDE, e.lpos, e.lpretw);
-            do_reset(e, p.max_steps, P, L);
-            P.flush(); L.flush();
+// DL lanes per wave, one work-list entry each (dense): traffic / weather redraw, terminal obs -> final_obs, episode
+// reset, obs row.  list == nullptr: API reset(mask) / cursor rewind / fresh-handle init over ALL envs (`what`).
+// Few waves run here (1-3 % of the envs), so the kernel is bound by one lane's serial chain, not by throughput:
+// both streams' windows are filled once, wave-convergently, before any draw is consumed.
+// what: 0 work list, 1 reset(mask)+obs, 2 rewind cursors after seeding, 3 initial state of a fresh handle
+__global__ __launch_bounds__(BLOCK) void dense_kernel(Params p, int what) {
+    __shared__ uint32_t tile[DL * ROW];
+    __shared__ uint32_t drawsP[DL * PROW], drawsL[DL * LROW];
+    __shared__ int64_t row_env[DL];
+    const uint32_t count = what == 0 ? p.work_count[p.parity] : (uint32_t)p.n;
+    if (what == 0 && blockIdx.x == 0 && threadIdx.x == 0) p.work_count[p.parity ^ 1] = 0;       // next step's counter
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t slot = lane < (uint32_t)DL ? lane : 0u;
+#pragma unroll 1
+    for (uint32_t first = blockIdx.x * DL; first < count; first += gridDim.x * DL) {
+        const uint32_t tix = first + lane;
+        const bool live = lane < (uint32_t)DL && tix < count;
+        int64_t i;
+        uint32_t work;
+        if (what == 0) {
+            const uint64_t entry = p.work_list[live ? tix : first];
+            i = (int64_t)(entry >> 3);
+            work = live ? (uint32_t)(entry & 7u) : 0u;
+        } else {
+            i = live ? (int64_t)tix : (int64_t)first;
+            work = (live && what == 1 && (!p.mask || p.mask[i])) ? W_RESET : 0u;
+        }
+        Env e;
+        e.load(p.state, p.n, i);
+        if (what == 2) { if (live) { e.ppos = e.lpos = 0; e.ppretw = e.lpretw = 0; e.store(p.state, p.n, i); } continue; }
+        if (what == 3) { if (live) { e.weather = 1; e.store(p.state, p.n, i); } continue; }
+        DrawsP P(drawsP + slot * PROW, p.mtP + i * MT_STRIDE, e.ppos, e.ppretw);
+        DrawsL L(drawsL + slot * LROW, p.mtL + i * MT_STRIDE, e.lpos, e.lpretw);
+        coop_fill<WL, DL, 4>(L, LROW, work != 0);
+        coop_fill<WP, DL, 8>(P, PROW, (work & W_RESET) != 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (work & W_TRAFFIC) update_traffic(e, L);                                                   // :257-258
+        if (work & W_WEATHER) {                                                                       // _update_weather :524-528
+            const double w0 = 0.3, w1 = w0 + 0.5, w2 = w1 + 0.15, w3 = w2 + 0.05;
+            e.weather = np_choice_cdf(L, w0 / w3, w1 / w3, w2 / w3, w3 / w3);
+        }
+        if (lane < (uint32_t)DL) row_env[lane] = live ? i : -1;
+        const int nlive = (int)(count - first < (uint32_t)DL ? count - first : (uint32_t)DL);
+        const bool fin = what == 0 && (work & W_RESET) && p.mode == CGE_AUTORESET_SAME_STEP && p.final_obs;
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            // pass 0: terminal obs (after the redraws) of the envs that finished -> final_obs; pass 1: reset, then obs
+            const bool want = pass == 0 ? fin : (what == 1 ? live : work != 0);
+            if (pass == 1 && (work & W_RESET)) do_reset(e, p.max_steps, P, L);
+            float *dst = pass == 0 ? p.final_obs : (p.obs ? p.obs + (int64_t)p.t_index * p.obs_step_stride : nullptr);
+            const unsigned long long m = __ballot(want);
+            if (!m || !dst) continue;
+            if (lane < (uint32_t)DL) stage_row(e, tile + lane * ROW);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 1
+            for (int r = 0; r < nlive; ++r) {                  // each listed env's 304-byte row: two 64-lane stores
+                if (!((m >> r) & 1ull)) continue;
+                uint32_t *drow = reinterpret_cast<uint32_t *>(dst + row_env[r] * OBS);
+                drow[lane] = tile[r * ROW + lane];
+                if (lane < (uint32_t)(OBS - 64)) drow[64 + lane] = tile[r * ROW + 64 + lane];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        coop_flush<WP, DL>(P, PROW);
+        coop_flush<WL, DL>(L, LROW);
+        if (work) {
             e.ppos = P.pos; e.ppretw = P.pretw; e.lpos = L.pos; e.lpretw = L.pretw;
             e.store(p.state, p.n, i);
         }
     }
-    if (what == 0 && p.obs) observe(e, nrows, p.obs + i0 * OBS, ~0ull, tile);
 }
 
 __global__ __launch_bounds__(256) void info_kernel(const uint4 *__restrict__ state, int64_t n, int field, double *__restrict__ out) {
@@ -452,13 +501,33 @@ struct cge_fleet : HandleBase {
     cge_fleet_config cfg{};
     uint4 *state = nullptr;
     uint32_t *mtP = nullptr, *mtL = nullptr;
+    uint32_t *work_count = nullptr;
+    uint64_t *work_list = nullptr;
+    int parity = 0;
     fleet::Params params() const {
         fleet::Params p{};
         p.state = state; p.mtP = mtP; p.mtL = mtL; p.n = n; p.env0 = env0; p.mode = cfg.autoreset_mode; p.max_steps = cfg.max_timesteps;
+        p.work_count = work_count; p.work_list = work_list; p.parity = parity;
         return p;
     }
     unsigned blocks() const { return (unsigned)((n + fleet::BLOCK - 1) / fleet::BLOCK); }
-    void free_all() { (void)hipFree(state); (void)hipFree(mtP); (void)hipFree(mtL); }
+    void free_all() { (void)hipFree(state); (void)hipFree(mtP); (void)hipFree(mtL); (void)hipFree(work_count); (void)hipFree(work_list); }
+    // one env step = the RNG-free step kernel + the dense kernel over the envs it listed
+    hipError_t launch_step(fleet::Params &p, hipStream_t s) {
+        p.parity = parity;
+        hipLaunchKernelGGL(fleet::step_kernel, dim3(blocks()), dim3(fleet::BLOCK), 0, s, p);
+        hipLaunchKernelGGL(fleet::dense_kernel, dim3(dense_blocks(1024u)), dim3(fleet::BLOCK), 0, s, p, 0);
+        parity ^= 1;
+        return hipGetLastError();
+    }
+    unsigned dense_blocks(unsigned cap) const {
+        const unsigned b = (unsigned)((n + fleet::DL - 1) / fleet::DL);
+        return b < cap ? b : cap;
+    }
+    hipError_t launch_all(fleet::Params &p, int what, hipStream_t s) {
+        hipLaunchKernelGGL(fleet::dense_kernel, dim3(dense_blocks(1u << 20)), dim3(fleet::BLOCK), 0, s, p, what);
+        return hipGetLastError();
+    }
 };
 
 extern "C" {
@@ -477,18 +546,18 @@ int cge_fleet_create(const cge_fleet_config *cfg, int64_t n_envs, int device, in
     const size_t sb = (size_t)fleet::COLS * n_envs * sizeof(uint4), mb = (size_t)n_envs * MT_STRIDE * sizeof(uint32_t);
     hipError_t e;
     if ((e = hipMalloc(&h->state, sb)) != hipSuccess || (e = hipMalloc(&h->mtP, mb)) != hipSuccess || (e = hipMalloc(&h->mtL, mb)) != hipSuccess ||
-        (e = hipMemset(h->state, 0, sb)) != hipSuccess) {
+        (e = hipMalloc(&h->work_count, 2 * sizeof(uint32_t))) != hipSuccess || (e = hipMalloc(&h->work_list, (size_t)n_envs * sizeof(uint64_t))) != hipSuccess ||
+        (e = hipMemset(h->work_count, 0, 2 * sizeof(uint32_t))) != hipSuccess || (e = hipMemset(h->state, 0, sb)) != hipSuccess) {
         h->free_all();
         delete h;
         return CGE_ERR_HIP;
     }
-    h->device_bytes = sb + 2 * mb;
+    h->device_bytes = sb + 2 * mb + (size_t)n_envs * sizeof(uint64_t) + 2 * sizeof(uint32_t);
     e = launch_mt_seed(h->mtP, MT_STRIDE, n_envs, nullptr, 0, env_index0, 0, nullptr);
     if (e == hipSuccess) e = launch_mt_seed(h->mtL, MT_STRIDE, n_envs, nullptr, 0, env_index0, 1, nullptr);
     if (e == hipSuccess) {
         fleet::Params p = h->params();
-        hipLaunchKernelGGL(fleet::reset_kernel, dim3(h->blocks()), dim3(fleet::BLOCK), 0, nullptr, p, 2);
-        e = hipGetLastError();
+        e = h->launch_all(p, 3, nullptr);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e != hipSuccess) {
@@ -517,8 +586,7 @@ int cge_fleet_seed(cge_fleet *h, const uint64_t *seeds, uint64_t base_seed, void
     CGE_TRY(h, launch_mt_seed(h->mtP, MT_STRIDE, h->n, seeds, base_seed, h->env0, 0, as_stream(stream)));
     CGE_TRY(h, launch_mt_seed(h->mtL, MT_STRIDE, h->n, seeds, base_seed, h->env0, 1, as_stream(stream)));
     fleet::Params p = h->params();
-    hipLaunchKernelGGL(fleet::reset_kernel, dim3(h->blocks()), dim3(fleet::BLOCK), 0, as_stream(stream), p, 1);
-    CGE_TRY(h, hipGetLastError());
+    CGE_TRY(h, h->launch_all(p, 2, as_stream(stream)));
     return CGE_OK;
 }
 
@@ -527,8 +595,7 @@ int cge_fleet_reset(cge_fleet *h, const uint8_t *mask, float *obs_out, void *str
     DeviceGuard g(h->device);
     fleet::Params p = h->params();
     p.mask = mask; p.obs = obs_out;
-    hipLaunchKernelGGL(fleet::reset_kernel, dim3(h->blocks()), dim3(fleet::BLOCK), 0, as_stream(stream), p, 0);
-    CGE_TRY(h, hipGetLastError());
+    CGE_TRY(h, h->launch_all(p, 1, as_stream(stream)));
     return CGE_OK;
 }
 
@@ -541,8 +608,7 @@ int cge_fleet_step(cge_fleet *h, const int32_t *actions, float *obs_out, float *
     fleet::Params p = h->params();
     p.actions = actions; p.obs = obs_out; p.reward = reward_out; p.terminated = terminated_out; p.truncated = truncated_out;
     p.final_obs = final_obs_out; p.k_steps = 1;
-    hipLaunchKernelGGL(fleet::step_kernel<false>, dim3(h->blocks()), dim3(fleet::BLOCK), 0, as_stream(stream), p);
-    CGE_TRY(h, hipGetLastError());
+    CGE_TRY(h, h->launch_step(p, as_stream(stream)));
     return CGE_OK;
 }
 
@@ -557,8 +623,14 @@ int cge_fleet_rollout(cge_fleet *h, int32_t k_steps, const int32_t *actions, uin
     fleet::Params p = h->params();
     p.k_steps = k_steps; p.actions = actions; p.a_seed = action_seed; p.t0 = t0; p.obs = obs_out; p.obs_step_stride = obs_step_stride;
     p.reward = reward_traj_out; p.terminated = terminated_traj_out; p.reward_sum = reward_sum_out; p.done_count = done_count_out;
-    hipLaunchKernelGGL(fleet::step_kernel<true>, dim3(h->blocks()), dim3(fleet::BLOCK), 0, as_stream(stream), p);
-    CGE_TRY(h, hipGetLastError());
+    p.accumulate = 1;
+    if (reward_sum_out) CGE_TRY(h, hipMemsetAsync(reward_sum_out, 0, (size_t)h->n * sizeof(double), as_stream(stream)));
+    if (done_count_out) CGE_TRY(h, hipMemsetAsync(done_count_out, 0, (size_t)h->n * sizeof(int32_t), as_stream(stream)));
+    for (int32_t t = 0; t < k_steps; ++t) {                    // K x (step, dense): the state stays in HBM/L2 between launches
+        p.t_index = t;
+        p.obs = (obs_out && (obs_step_stride != 0 || t == k_steps - 1)) ? obs_out : nullptr;
+        CGE_TRY(h, h->launch_step(p, as_stream(stream)));
+    }
     return CGE_OK;
 }
 
