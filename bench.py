@@ -257,7 +257,9 @@ def main():
             "ms_per_step": hb["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ENVS[names[0]]["dtype"] if len(names) == 1 else "mixed", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {wl['desc']}", "envs_per_gpu": n * len(names), "env_types": names,
-                       "path": ("fused rollout: the K steps in one launch per GPU, obs written to HBM every step, device-side action hash"
+                       "path": (("rollout: K (step, dense-reset) launch pairs queued by one C-ABI call, obs written to HBM every step, device-side action hash"
+                                 if all(ENVS[nm].get("launches_per_step") for nm in names) else
+                                 "fused rollout: the K steps in one launch per GPU, obs written to HBM every step, device-side action hash")
                                 if head == "rollout" else "K C-ABI step() calls through the VectorEnv facade, HBM-resident actions"),
                        "autoreset": "SameStep", "parallelism": f"env-sharded x{world}, no data-path collective"},
             "roofline": hb["roofline"] if len(names) == 1 else hb["roofline"]["snake"],

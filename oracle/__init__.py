@@ -134,6 +134,13 @@ def _declare(L):
     L.orc_fleet_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.orc_fleet_rollout.argtypes = [vp, i32, u64, i64, i64, vp, vp, vp]
     L.orc_fleet_info.argtypes = [vp, i32, vp]
+    L.orc_manufacturing_create.argtypes = [i64, i32]; L.orc_manufacturing_create.restype = vp
+    L.orc_manufacturing_destroy.argtypes = [vp]
+    L.orc_manufacturing_seed.argtypes = [vp, vp]
+    L.orc_manufacturing_reset.argtypes = [vp, vp, vp]
+    L.orc_manufacturing_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.orc_manufacturing_rollout.argtypes = [vp, i32, u64, i64, i64, vp, vp, vp]
+    L.orc_manufacturing_info.argtypes = [vp, i32, vp]
 
 
 NEXT_STEP, SAME_STEP, DISABLED = 0, 1, 2
@@ -515,4 +522,20 @@ class FleetOracle(_SimpleOracle):
     def info(self, field):
         out = np.zeros(self.n, np.float64)
         lib().orc_fleet_info(self.h, FLEET_INFO[field] if isinstance(field, str) else field, _p(out))
+        return out
+
+
+MANUFACTURING_OBS = 73
+MANUFACTURING_INFO = {"raw_material": 0, "energy_consumption": 1, "total_reward": 2, "in_system": 3, "completed": 4, "scrapped": 5,
+                      "product_ids": 6, "history_len": 7, "oee_availability": 8, "oee_performance": 9, "oee_quality": 10,
+                      "timestep": 11, "episodes": 12, "needs_reset": 13, "overflow": 14}
+
+
+class ManufacturingOracle(_SimpleOracle):
+    """Batch of independent SmartManufacturingEnv restatements (oracle/orc_manufacturing.c); Discrete(25) actions."""
+    _name, _obs, _nact = "manufacturing", MANUFACTURING_OBS, 25
+
+    def info(self, field):
+        out = np.zeros(self.n, np.float64)
+        lib().orc_manufacturing_info(self.h, MANUFACTURING_INFO[field] if isinstance(field, str) else field, _p(out))
         return out

@@ -17,7 +17,8 @@ def pytest_configure(config):
 def golden(name):
     path = os.path.join(GOLDEN, name)
     if name.endswith(".npz"):
-        return np.load(path, allow_pickle=False)
+        with np.load(path, allow_pickle=False) as z:         # materialise once: NpzFile re-inflates a member on every access
+            return {k: z[k] for k in z.files}
     import json
     with open(path) as f:
         return json.load(f)

@@ -1,0 +1,71 @@
+"""Pins oracle/orc_manufacturing.c against golden vectors produced by running the reference's own manufacturing_env.py
+(tests/golden/gen/gen_manufacturing.py): float32 obs bit-for-bit (incl. the pairwise-summed per-type quality means), integer
+rewards exact, terminated/truncated exact, inventory / energy / list lengths / OEE metrics exact."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import golden
+
+
+@pytest.mark.parametrize("name", ["manufacturing_hash.npz", "manufacturing_biased.npz", "manufacturing_typea.npz"])
+def test_same_step_matches_reference_bitwise(oracle, name):
+    fx = golden(name)
+    A = fx["actions"]
+    n, T = A.shape[0], A.shape[1]
+    o = oracle.ManufacturingOracle(n, oracle.SAME_STEP)
+    o.seed(np.arange(n, dtype=np.uint64) + np.uint64(int(fx["seed0"])))
+    assert np.array_equal(o.reset().view(np.uint32), fx["obs0"].view(np.uint32))
+    reset_at = {(int(i), int(t)): k for k, (i, t) in enumerate(fx["reset_index"])}
+    for t in range(T):
+        obs, rew, te, tr, fin = o.step(A[:, t], want_final=True)
+        done = (te | tr).astype(bool)
+        assert np.array_equal(te, fx["terminated"][:, t]) and np.array_equal(tr, fx["truncated"][:, t]), t
+        assert np.array_equal(o.last_reward64, fx["reward"][:, t]), (t, o.last_reward64, fx["reward"][:, t])
+        step_obs = np.where(done[:, None], fin, obs)
+        assert np.array_equal(step_obs.view(np.uint32), fx["obs"][:, t].view(np.uint32)), (t, np.argwhere(step_obs != fx["obs"][:, t])[:5])
+        for i in np.nonzero(done)[0]:
+            assert np.array_equal(obs[i], fx["reset_obs"][reset_at[(int(i), t)]]), (i, t)
+        if t % 16 == 0 or done.any():
+            live = ~done
+            S = fx["state"][:, t]
+            for k, f in enumerate(["raw_material", "energy_consumption", "total_reward", "in_system", "completed", "scrapped", "product_ids",
+                                   "history_len", "oee_availability", "oee_performance", "oee_quality"]):
+                assert np.array_equal(o.info(f)[live], S[live, k]), (t, f)
+    assert len(reset_at) >= 4 and o.info("overflow").sum() == 0
+
+
+def test_kat_m1(oracle):
+    kat = golden("manufacturing_kat.json")
+    o = oracle.ManufacturingOracle(1, oracle.SAME_STEP)
+    o.seed(np.array([7], np.uint64))
+    obs = o.reset()
+    acts = np.random.default_rng(7).integers(0, 25, 3000)
+    h = hashlib.sha256(); h.update(obs.tobytes())
+    total, episodes = 0.0, 0
+    for a in acts:
+        obs, rew, te, tr, fin = o.step(np.array([a], np.int32), want_final=True)
+        done = bool(te[0] or tr[0])
+        step_obs = fin if done else obs
+        r = float(o.last_reward64[0])
+        h.update(step_obs.tobytes()); h.update(np.float64(r).tobytes()); h.update(bytes([int(te[0]), int(tr[0])]))
+        total += r
+        if done:
+            episodes += 1
+            h.update(obs.tobytes())
+    assert total == kat["sum_reward"] and episodes == kat["episodes"] and h.hexdigest() == kat["sha256"]
+
+
+def test_next_step_and_rollout_agree_with_step(oracle):
+    n, K = 5, 400
+    a = oracle.ManufacturingOracle(n, oracle.NEXT_STEP); b = oracle.ManufacturingOracle(n, oracle.NEXT_STEP)
+    seeds = np.arange(n, dtype=np.uint64) + np.uint64(40)
+    a.seed(seeds); b.seed(seeds); a.reset(); b.reset()
+    rs = np.zeros(n)
+    for t in range(K):
+        acts = np.array([oracle.hash_action(9, i, t, 25, 0) for i in range(n)], np.int32)
+        obs, rew, te, tr = a.step(acts)
+        rs += a.last_reward64
+    obs_b, rs_b, dc_b = b.rollout(K, 9)
+    assert np.array_equal(obs.view(np.uint32), obs_b.view(np.uint32)) and np.array_equal(rs, rs_b)
