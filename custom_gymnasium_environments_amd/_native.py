@@ -49,6 +49,10 @@ class FleetConfig(C.Structure):
     _fields_ = [("max_timesteps", C.c_int32), ("autoreset_mode", C.c_int32)]
 
 
+class ManufacturingConfig(C.Structure):
+    _fields_ = [("max_steps", C.c_int32), ("autoreset_mode", C.c_int32)]
+
+
 # name -> (restype, argtypes); also the list tests check against include/cge_amd.h
 _vp, _i32, _i64, _u32, _u64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_size_t
 SIGNATURES = {
@@ -122,6 +126,15 @@ SIGNATURES = {
     "cge_fleet_info": (C.c_int, [_vp, _i32, _vp, _vp]),
     "cge_fleet_device_bytes": (_sz, [_vp]),
     "cge_fleet_last_error": (C.c_char_p, [_vp]),
+    "cge_manufacturing_create": (C.c_int, [C.POINTER(ManufacturingConfig), _i64, C.c_int, _i64, C.POINTER(_vp)]),
+    "cge_manufacturing_destroy": (C.c_int, [_vp]),
+    "cge_manufacturing_seed": (C.c_int, [_vp, _vp, _u64, _vp]),
+    "cge_manufacturing_reset": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "cge_manufacturing_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cge_manufacturing_rollout": (C.c_int, [_vp, _i32, _vp, _u64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "cge_manufacturing_info": (C.c_int, [_vp, _i32, _vp, _vp]),
+    "cge_manufacturing_device_bytes": (_sz, [_vp]),
+    "cge_manufacturing_last_error": (C.c_char_p, [_vp]),
 }
 
 _lib = None

@@ -628,7 +628,6 @@ int cge_fleet_rollout(cge_fleet *h, int32_t k_steps, const int32_t *actions, uin
     if (done_count_out) CGE_TRY(h, hipMemsetAsync(done_count_out, 0, (size_t)h->n * sizeof(int32_t), as_stream(stream)));
     for (int32_t t = 0; t < k_steps; ++t) {                    // K x (step, dense): the state stays in HBM/L2 between launches
         p.t_index = t;
-        p.obs = (obs_out && (obs_step_stride != 0 || t == k_steps - 1)) ? obs_out : nullptr;
         CGE_TRY(h, h->launch_step(p, as_stream(stream)));
     }
     return CGE_OK;

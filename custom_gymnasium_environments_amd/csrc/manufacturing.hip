@@ -1,0 +1,828 @@
+// manufacturing.hip — batched SmartManufacturingEnv for MI355X (gfx950): kernels + C ABI (include/cge_amd.h).
+//
+// Re-expresses /root/reference/smart_manufacturing_env/manufacturing_env.py for N independent instances, one lane per env:
+//   reset :113-192, _get_observation :194-250, step :252-301, _process_action :303-359, _start_production :361-379,
+//   _update_production :381-425, _update_machine_status :427-462, _quality_control :464-480, _complete_product :482-500
+//   (its return value is discarded at :418), _calculate_timestep_rewards :502-531, _update_metrics :533-553,
+//   _check_termination :555-578, _update_supply_chain :580-595.
+// Fixed state per env: 84 dwords in 21 uint4 columns (PCG64, 5 stations incl. a cached copy of the product each is
+// working on, counters, thresholds, cached recent-quality means).  Variable state lives in per-env TABLES laid out
+// [slot][env] so that a wave walking slot s touches 64 consecutive values:
+//   pq/pm/pnext[320][N]  one row per product started in the episode (slot = product id; an episode can start at most
+//                        (250 + 29*99)/10 = 312): quality f64, {type, station+1, alive, remaining} u16, queue link u16
+//   comp[20][N]          ring of the last 20 completed qualities (:525, :552)
+//   hist[100][N]         ring of the last 100 quality_rate_history entries (:573-576)
+// The per-type quality means of the observation (:220-228) are np.mean over ALL products in the system in list order,
+// i.e. NumPy's pairwise summation: they are recomputed every step by a wave-uniform walk over the live slot range with
+// the 8 running accumulators of each type parked in LDS (bit-identical to the reference; a second pass handles a type
+// with more than 128 products, where NumPy's recursion splits the list).  Rewards are integers -> exact.
+#include <cstring>
+#include <vector>
+
+#include "cge_device.hpp"
+#include "cge_host.hpp"
+#include "cge_pcg.hpp"
+
+namespace cge {
+namespace mfg {
+
+constexpr int OBS = 73;
+constexpr int BLOCK = 64;
+constexpr int COLS = 21;
+constexpr int CAP = 320;
+constexpr uint32_t NONE = 1023u;
+constexpr int ACCROW = 55;          // f64 per lane in LDS: 6 types x (8 accumulators + running result) + pad
+constexpr uint32_t M_ALIVE = 1u << 6;
+enum : uint32_t { OPERATIONAL = 0, BROKEN = 1, MAINTENANCE = 2 };
+enum : uint32_t { BALANCED = 0, RUSH = 1, QUALITY = 2 };
+
+struct Params {
+    uint4 *state;
+    double *pq;
+    uint16_t *pm, *pnext;
+    double *comp, *hist;
+    int64_t n, env0;
+    int32_t mode, max_steps, k_steps;
+    const int32_t *actions;
+    uint64_t a_seed;
+    int64_t t0;
+    float *obs;
+    int64_t obs_step_stride;
+    float *reward;
+    uint8_t *terminated, *truncated;
+    float *final_obs;
+    const uint8_t *mask;
+    const uint64_t *seeds;
+    uint64_t base_seed;
+    double *reward_sum;
+    int32_t *done_count;
+};
+
+__device__ __forceinline__ double mk_double(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
+__device__ __forceinline__ uint32_t fld9(uint64_t w, uint32_t k) { return (uint32_t)(w >> (9u * k)) & 511u; }
+__device__ __forceinline__ uint32_t timesteps2(uint32_t t) {                                                  // 2 x timesteps
+    return t == 0 ? 20u : t == 1 ? 30u : t == 2 ? 40u : t == 3 ? 50u : t == 4 ? 60u : 36u;
+}
+// product meta word: type(3) | station+1 (3) << 3 | alive << 6 | remaining half-steps (6) << 7
+__device__ __forceinline__ uint32_t mk_meta(uint32_t type, uint32_t csp1, uint32_t alive, uint32_t rem2) { return type | (csp1 << 3) | (alive << 6) | (rem2 << 7); }
+
+struct Env {
+    Pcg64 g;
+    uint32_t mode, emergency, disruption, disruption_cd, timestep, needs_reset, overflow, raw, energy, targets;
+    uint32_t nprod, lo, ncomp, ngood, nscrap, nhist, cnt_lt, cnt_gt, episodes;
+    uint64_t completed, qlen, cnt[5], nT, curm;
+    int32_t total_reward;
+    double util[5], degr[5], curq[5], mean20, mean10, thr[3];
+    uint32_t status[5], ops[5], cur[5], qhead[5], qtail[5];
+    int32_t mcount[5];
+
+    __device__ __forceinline__ void unpack(const uint32_t (&r)[COLS * 4]) {
+        g.state = ((u128)(((uint64_t)r[3] << 32) | r[2]) << 64) | (((uint64_t)r[1] << 32) | r[0]);
+        g.inc = ((u128)(((uint64_t)r[7] << 32) | r[6]) << 64) | (((uint64_t)r[5] << 32) | r[4]);
+        g.uinteger = r[8];
+        const uint32_t m = r[9];
+        g.has_uint32 = m & 1u; mode = (m >> 1) & 3u; emergency = (m >> 3) & 1u; disruption = (m >> 4) & 1u; disruption_cd = (m >> 5) & 63u;
+        timestep = (m >> 11) & 2047u; needs_reset = (m >> 22) & 1u; overflow = (m >> 23) & 1u;
+        raw = r[10] & 1023u; energy = r[10] >> 10; targets = r[11];
+        completed = ((uint64_t)r[13] << 32) | r[12];
+        total_reward = (int32_t)r[14];
+        nprod = r[15] & 1023u; lo = (r[15] >> 10) & 1023u; ncomp = (r[15] >> 20) & 1023u;
+        ngood = r[16] & 1023u; nscrap = (r[16] >> 10) & 1023u; nhist = r[16] >> 20;
+        cnt_lt = r[17] & 127u; cnt_gt = (r[17] >> 7) & 127u; episodes = r[17] >> 14;
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            util[s] = mk_double(r[18 + 2 * s], r[19 + 2 * s]); degr[s] = mk_double(r[28 + 2 * s], r[29 + 2 * s]); curq[s] = mk_double(r[38 + 2 * s], r[39 + 2 * s]);
+            status[s] = r[58 + s] & 3u; ops[s] = (r[58 + s] >> 2) & 4095u; mcount[s] = (int32_t)(r[58 + s] >> 14) - 32768;
+            cur[s] = r[63 + s] & 1023u; qhead[s] = (r[63 + s] >> 10) & 1023u; qtail[s] = (r[63 + s] >> 20) & 1023u;
+            cnt[s] = ((uint64_t)r[71 + 2 * s] << 32) | r[70 + 2 * s];
+        }
+        mean20 = mk_double(r[48], r[49]); mean10 = mk_double(r[50], r[51]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) thr[c] = mk_double(r[52 + 2 * c], r[53 + 2 * c]);
+        qlen = ((uint64_t)r[69] << 32) | r[68];
+        nT = ((uint64_t)r[81] << 32) | r[80];
+        curm = ((uint64_t)r[83] << 32) | r[82];
+    }
+    __device__ __forceinline__ void pack(uint32_t (&r)[COLS * 4]) const {
+        const uint64_t sl = (uint64_t)g.state, sh = (uint64_t)(g.state >> 64), il = (uint64_t)g.inc, ih = (uint64_t)(g.inc >> 64);
+        r[0] = (uint32_t)sl; r[1] = (uint32_t)(sl >> 32); r[2] = (uint32_t)sh; r[3] = (uint32_t)(sh >> 32);
+        r[4] = (uint32_t)il; r[5] = (uint32_t)(il >> 32); r[6] = (uint32_t)ih; r[7] = (uint32_t)(ih >> 32);
+        r[8] = g.uinteger;
+        r[9] = g.has_uint32 | (mode << 1) | (emergency << 3) | (disruption << 4) | (disruption_cd << 5) | (timestep << 11) | (needs_reset << 22) | (overflow << 23);
+        r[10] = raw | (energy << 10); r[11] = targets;
+        r[12] = (uint32_t)completed; r[13] = (uint32_t)(completed >> 32);
+        r[14] = (uint32_t)total_reward;
+        r[15] = nprod | (lo << 10) | (ncomp << 20);
+        r[16] = ngood | (nscrap << 10) | (nhist << 20);
+        r[17] = cnt_lt | (cnt_gt << 7) | (episodes << 14);
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            r[18 + 2 * s] = (uint32_t)__double2loint(util[s]); r[19 + 2 * s] = (uint32_t)__double2hiint(util[s]);
+            r[28 + 2 * s] = (uint32_t)__double2loint(degr[s]); r[29 + 2 * s] = (uint32_t)__double2hiint(degr[s]);
+            r[38 + 2 * s] = (uint32_t)__double2loint(curq[s]); r[39 + 2 * s] = (uint32_t)__double2hiint(curq[s]);
+            r[58 + s] = status[s] | (ops[s] << 2) | ((uint32_t)(mcount[s] + 32768) << 14);
+            r[63 + s] = cur[s] | (qhead[s] << 10) | (qtail[s] << 20);
+            r[70 + 2 * s] = (uint32_t)cnt[s]; r[71 + 2 * s] = (uint32_t)(cnt[s] >> 32);
+        }
+        r[48] = (uint32_t)__double2loint(mean20); r[49] = (uint32_t)__double2hiint(mean20);
+        r[50] = (uint32_t)__double2loint(mean10); r[51] = (uint32_t)__double2hiint(mean10);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { r[52 + 2 * c] = (uint32_t)__double2loint(thr[c]); r[53 + 2 * c] = (uint32_t)__double2hiint(thr[c]); }
+        r[68] = (uint32_t)qlen; r[69] = (uint32_t)(qlen >> 32);
+        r[80] = (uint32_t)nT; r[81] = (uint32_t)(nT >> 32);
+        r[82] = (uint32_t)curm; r[83] = (uint32_t)(curm >> 32);
+    }
+    __device__ __forceinline__ void load(const uint4 *__restrict__ s, int64_t n, int64_t i) {
+        uint32_t r[COLS * 4];
+#pragma unroll
+        for (int c = 0; c < COLS; ++c) {
+            const uint4 v = s[(int64_t)c * n + i];
+            r[4 * c] = v.x; r[4 * c + 1] = v.y; r[4 * c + 2] = v.z; r[4 * c + 3] = v.w;
+        }
+        unpack(r);
+    }
+    __device__ __forceinline__ void store(uint4 *__restrict__ s, int64_t n, int64_t i) const {
+        uint32_t r[COLS * 4];
+        pack(r);
+#pragma unroll
+        for (int c = 0; c < COLS; ++c) s[(int64_t)c * n + i] = make_uint4(r[4 * c], r[4 * c + 1], r[4 * c + 2], r[4 * c + 3]);
+    }
+};
+
+struct Tab {       // this env's column of every table
+    double *pq;
+    uint16_t *pm, *pnext;
+    double *comp, *hist;
+    int64_t n;
+    __device__ __forceinline__ Tab(const Params &p, int64_t i) : pq(p.pq + i), pm(p.pm + i), pnext(p.pnext + i), comp(p.comp + i), hist(p.hist + i), n(p.n) {}
+};
+
+__device__ __forceinline__ double combine8(const double *a) { return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7])); }
+
+// np.mean of the last m = min(ncomp, last) completed qualities (ring of 20), NumPy pairwise order, m <= 20
+__device__ __forceinline__ double recent_mean(const Env &e, const Tab &tb, uint32_t last) {
+    const uint32_t m = e.ncomp < last ? e.ncomp : last;
+    double v[20];
+    uint32_t idx = (e.ncomp - m) % 20u;
+#pragma unroll
+    for (int k = 0; k < 20; ++k) {
+        v[k] = (uint32_t)k < m ? tb.comp[(int64_t)idx * tb.n] : 0.0;
+        idx = idx + 1u == 20u ? 0u : idx + 1u;
+    }
+    double res;
+    if (m < 8u) {
+        res = 0.0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) res = (uint32_t)k < m ? res + v[k] : res;
+    } else {
+        const uint32_t nfull = m & ~7u;
+        double r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = nfull == 16u ? v[j] + v[8 + j] : v[j];
+        res = combine8(r);
+#pragma unroll
+        for (int k = 8; k < 20; ++k) res = ((uint32_t)k >= nfull && (uint32_t)k < m) ? res + v[k] : res;
+    }
+    return res / (double)m;
+}
+
+// exact np.mean(quality_rate_history[-100:]) over the ring, oldest entry at nhist % 100
+__device__ __forceinline__ double hist_mean(const Env &e, const Tab &tb) {
+    uint32_t idx = e.nhist % 100u;
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = 0.0;
+#pragma unroll 1
+    for (int b = 0; b < 12; ++b) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double x = tb.hist[(int64_t)idx * tb.n];
+            r[j] = b == 0 ? x : r[j] + x;
+            idx = idx + 1u == 100u ? 0u : idx + 1u;
+        }
+    }
+    double res = combine8(r);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        res += tb.hist[(int64_t)idx * tb.n];
+        idx = idx + 1u == 100u ? 0u : idx + 1u;
+    }
+    return res / 100.0;
+}
+
+template <int S>
+__device__ __forceinline__ void queue_push(Env &e, const Tab &tb, uint32_t id) {
+    if (fld9(e.qlen, S) == 0) e.qhead[S] = id;
+    else tb.pnext[(int64_t)e.qtail[S] * tb.n] = (uint16_t)id;
+    e.qtail[S] = id;
+    e.qlen += 1ull << (9 * S);
+}
+
+__device__ __forceinline__ void do_reset(Env &e) {                                                   // :113-192
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        e.status[s] = OPERATIONAL; e.util[s] = 0.0; e.ops[s] = 0;
+        e.mcount[s] = (int32_t)e.g.integers(100, 200);
+        e.cur[s] = NONE; e.qhead[s] = 0; e.qtail[s] = 0; e.degr[s] = 0.0; e.curq[s] = 0.0; e.cnt[s] = 0;
+    }
+    e.qlen = 0; e.nT = 0; e.curm = 0; e.nprod = 0; e.lo = 0; e.ncomp = 0; e.ngood = 0; e.nscrap = 0; e.nhist = 0; e.cnt_lt = 0; e.cnt_gt = 0;
+    e.thr[0] = 0.70; e.thr[1] = 0.80; e.thr[2] = 0.85;
+    e.raw = 250;
+    uint32_t tg = 0;
+    tg |= (uint32_t)e.g.integers(5, 10);
+    tg |= (uint32_t)e.g.integers(4, 8) << 4;
+    tg |= (uint32_t)e.g.integers(3, 6) << 8;
+    tg |= (uint32_t)e.g.integers(2, 5) << 12;
+    tg |= (uint32_t)e.g.integers(2, 4) << 16;
+    tg |= (uint32_t)e.g.integers(3, 7) << 20;
+    e.targets = tg; e.completed = 0;
+    e.mode = BALANCED; e.emergency = 0; e.timestep = 0; e.total_reward = 0; e.disruption = 0; e.disruption_cd = 0; e.energy = 0;
+    e.mean20 = 0.0; e.mean10 = 0.0; e.needs_reset = 0;
+}
+
+// one station of _update_production :386-425
+template <int S>
+__device__ __forceinline__ void station_update(Env &e, const Tab &tb, bool &completed_any) {
+    if (e.status[S] != OPERATIONAL) return;
+    if (e.cur[S] != NONE) {
+        const uint32_t id = e.cur[S];
+        uint32_t cm = (uint32_t)(e.curm >> (12 * S)) & 4095u;                       // type(3) | station+1 (3) | remaining half-steps (6)
+        const uint32_t type = cm & 7u, csp1 = (cm >> 3) & 7u;
+        int32_t rem2 = (int32_t)(cm >> 6) - 2;
+        double q = e.curq[S];
+        if (e.mode == RUSH) { rem2 -= 1; q *= 0.98; }
+        else if (e.mode == QUALITY) q *= 1.02;
+        q *= (1 - e.degr[S]);
+        if (rem2 <= 0) {
+            e.cur[S] = NONE; e.ops[S] += 1;
+            const uint32_t next = csp1;                                             // current_station + 1
+            const uint32_t req = type == 5u ? 3u : type + 1u;                       // stations_required :35-40
+            if (next < req) {
+                tb.pq[(int64_t)id * tb.n] = q;
+                tb.pm[(int64_t)id * tb.n] = (uint16_t)mk_meta(type, next + 1u, 1u, 0u);
+                if (S == 0 && csp1 == 0) {                                          // first visit ends: queued at station 0 again (:367, :410-415)
+                    queue_push<0>(e, tb, id);
+                    e.cnt[0] += 1ull << (9u * type);
+                } else {
+                    e.cnt[S] -= 1ull << (9u * type);
+                    if (S < 4) { queue_push<(S < 4 ? S + 1 : 4)>(e, tb, id); e.cnt[S < 4 ? S + 1 : 4] += 1ull << (9u * type); }
+                }
+            } else {                                                                // _complete_product :482-500
+                e.completed += 1ull << (9u * type);
+                tb.comp[(int64_t)(e.ncomp % 20u) * tb.n] = q;
+                e.ncomp += 1; e.ngood += q > 0.7 ? 1u : 0u;
+                tb.pm[(int64_t)id * tb.n] = (uint16_t)mk_meta(type, csp1, 0u, 0u);
+                e.nT -= 1ull << (9u * type);
+                e.cnt[S] -= 1ull << (9u * type);
+                completed_any = true;
+            }
+        } else {
+            e.curq[S] = q;
+            tb.pq[(int64_t)id * tb.n] = q;                                          // the observation's per-type mean reads the table
+            cm = (cm & 63u) | ((uint32_t)rem2 << 6);
+            e.curm = (e.curm & ~(4095ull << (12 * S))) | ((uint64_t)cm << (12 * S));
+        }
+    }
+    if (e.cur[S] == NONE && fld9(e.qlen, S) > 0) {                                 // load next product from queue
+        const uint32_t id = e.qhead[S];
+        e.cur[S] = id;
+        e.curq[S] = tb.pq[(int64_t)id * tb.n];
+        const uint32_t m = tb.pm[(int64_t)id * tb.n];
+        const uint32_t cm = (m & 63u) | (((m >> 7) & 63u) << 6);
+        e.curm = (e.curm & ~(4095ull << (12 * S))) | ((uint64_t)cm << (12 * S));
+        e.qlen -= 1ull << (9 * S);
+        if (fld9(e.qlen, S) > 0) e.qhead[S] = tb.pnext[(int64_t)id * tb.n];
+        e.util[S] = 0.8;
+    } else {
+        e.util[S] *= 0.95;
+    }
+}
+
+template <int S>
+__device__ __forceinline__ void machine_update(Env &e) {                                             // :429-462
+    if (e.status[S] == MAINTENANCE) {
+        e.mcount[S] -= 1;
+        if (e.mcount[S] <= 0) { e.status[S] = OPERATIONAL; e.degr[S] = 0.0; e.ops[S] = 0; e.mcount[S] = (int32_t)e.g.integers(100, 200); }
+    } else if (e.status[S] == OPERATIONAL) {
+        const double prob = 0.001 * (1 + (double)e.ops[S] / 100);
+        if (e.g.random() < prob) { e.status[S] = BROKEN; e.mcount[S] = 30; }
+        if (e.ops[S] % 100u == 0) e.degr[S] += 0.005;
+        e.mcount[S] -= 1;
+    } else {
+        e.mcount[S] -= 1;
+        if (e.mcount[S] <= 0) { e.status[S] = OPERATIONAL; e.mcount[S] = (int32_t)e.g.integers(100, 200); }
+    }
+}
+
+template <int C, int S>
+__device__ __forceinline__ void quality_check(Env &e, const Tab &tb, int32_t &reward) {              // :468-478
+    if (e.cur[S] != NONE && e.curq[S] < e.thr[C]) {
+        const uint32_t cm = (uint32_t)(e.curm >> (12 * S)) & 4095u, type = cm & 7u;
+        tb.pm[(int64_t)e.cur[S] * tb.n] = (uint16_t)mk_meta(type, (cm >> 3) & 7u, 0u, 0u);
+        e.nT -= 1ull << (9u * type);
+        e.cnt[S] -= 1ull << (9u * type);
+        e.cur[S] = NONE; e.nscrap += 1;
+        reward -= 100;
+    }
+}
+
+// returns terminated | truncated << 1
+__device__ __forceinline__ uint32_t env_step(Env &e, const Tab &tb, int32_t max_steps, int32_t action, int32_t &reward_out) {   // :252-301
+    int32_t reward = 0;
+    e.timestep += 1;
+    if (action >= 0 && action <= 5) {                                                                 // _process_action :303-359
+        if (e.raw >= 10u) {
+            if (e.nprod < (uint32_t)CAP) {                                                            // _start_production :361-379
+                const uint32_t id = e.nprod, type = (uint32_t)action;
+                const double q = 0.85 + e.g.uniform(-0.1, 0.1);
+                tb.pq[(int64_t)id * tb.n] = q;
+                tb.pm[(int64_t)id * tb.n] = (uint16_t)mk_meta(type, 0u, 1u, timesteps2(type));
+                e.nT += 1ull << (9u * type);
+                if (e.status[0] == OPERATIONAL) queue_push<0>(e, tb, id);
+                e.nprod += 1;
+            } else {
+                e.overflow = 1;                                                                       // cannot happen inside an episode
+            }
+            e.raw -= 10u;
+        } else reward -= 50;
+    } else if (action >= 6 && action <= 10) {
+        const uint32_t s = (uint32_t)(action - 6);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) if (s == (uint32_t)k) { const double u = e.util[k] + 0.2; e.util[k] = u < 1.0 ? u : 1.0; }
+        e.energy += 5;
+    } else if (action >= 11 && action <= 15) {
+        const uint32_t s = (uint32_t)(action - 11);
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            if (s == (uint32_t)k && e.status[k] == OPERATIONAL) { e.status[k] = MAINTENANCE; e.mcount[k] = 20; reward += 50; }
+    } else if (action >= 16 && action <= 20) {
+        const uint32_t c = (uint32_t)(action - 16);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) if (c == (uint32_t)k) { const double t = e.thr[k] + 0.05; e.thr[k] = t < 0.95 ? t : 0.95; }
+    } else if (action == 21) {
+        e.emergency ^= 1u;
+        if (e.emergency) reward -= 100;
+    } else if (action == 22) { e.mode = RUSH; e.energy += 10; }
+    else if (action == 23) e.mode = QUALITY;
+    else if (action == 24) e.mode = BALANCED;
+    bool completed_any = false;
+    if (!e.emergency) {                                                                               // _update_production :381-425
+        station_update<0>(e, tb, completed_any); station_update<1>(e, tb, completed_any); station_update<2>(e, tb, completed_any);
+        station_update<3>(e, tb, completed_any); station_update<4>(e, tb, completed_any);
+    }
+    machine_update<0>(e); machine_update<1>(e); machine_update<2>(e); machine_update<3>(e); machine_update<4>(e);
+    quality_check<0, 1>(e, tb, reward); quality_check<1, 3>(e, tb, reward); quality_check<2, 4>(e, tb, reward);
+    // _update_metrics :533-553 — both recent-quality means only change when a product completes
+    if (completed_any) { e.mean20 = recent_mean(e, tb, 20u); e.mean10 = recent_mean(e, tb, 10u); }
+    if (e.ncomp > 0) {
+        const uint32_t pos = e.nhist % 100u;
+        if (e.nhist >= 100u) {
+            const double old = tb.hist[(int64_t)pos * tb.n];
+            e.cnt_lt -= old < 0.61 ? 1u : 0u; e.cnt_gt -= old > 0.59 ? 1u : 0u;
+        }
+        tb.hist[(int64_t)pos * tb.n] = e.mean20;
+        e.cnt_lt += e.mean20 < 0.61 ? 1u : 0u; e.cnt_gt += e.mean20 > 0.59 ? 1u : 0u;
+        e.nhist += 1;
+    }
+    // _calculate_timestep_rewards :502-531
+    uint32_t broken = 0;
+    bool all_met = true;
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        if (e.status[s] == OPERATIONAL && e.cur[s] == NONE && fld9(e.qlen, s) == 0) reward -= 10;
+        broken += e.status[s] == BROKEN ? 1u : 0u;
+    }
+    reward -= (int32_t)broken * 50;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const uint32_t done = fld9(e.completed, k), target = (e.targets >> (4 * k)) & 15u;
+        if (e.timestep > 1000u && done < target) reward -= 50;
+        all_met = all_met && done >= target;
+    }
+    if (e.ncomp > 0) { if (e.mean10 > 0.9) reward += 20; else if (e.mean10 < 0.6) reward -= 30; }
+    // _check_termination :555-578.  The 100-entry history mean is only evaluated when its sign is not already decided:
+    // no entry below 0.61 -> mean > 0.6; no entry above 0.59 -> mean < 0.6 (summation error is ~1e-14).
+    bool term = all_met || broken >= 3u || e.timestep >= (uint32_t)max_steps;
+    if (!term && e.nhist >= 100u && e.cnt_lt != 0u) term = e.cnt_gt == 0u ? true : hist_mean(e, tb) < 0.6;
+    const bool trunc = e.timestep >= (uint32_t)max_steps;
+    // _update_supply_chain :580-595
+    if (!e.disruption && e.g.random() < 0.01) { e.disruption = 1; e.disruption_cd = (uint32_t)e.g.integers(20, 50); }
+    if (e.disruption) { e.disruption_cd -= 1; if (e.disruption_cd == 0) e.disruption = 0; }
+    else if (e.timestep % 50u == 0) { const uint32_t r = e.raw + (uint32_t)e.g.integers(50, 100); e.raw = r < 500u ? r : 500u; }
+    e.total_reward += reward;
+    reward_out = reward;
+    return (term ? 1u : 0u) | (trunc ? 2u : 0u);
+}
+
+__device__ __forceinline__ uint32_t wave_min(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64); v = o < v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64); v = o > v ? o : v; }
+    return v;
+}
+
+// NumPy pairwise sum of the qualities of the `nt` products of `type` (nt > 128, rare): the recursion of
+// pairwise_sum splits the list into at most four leaves of <= 128 for nt <= 320; one more walk over the slots.
+__device__ __forceinline__ double big_type_sum(const Env &e, const Tab &tb, bool mine, uint32_t type, uint32_t nt, double *a, uint32_t smin, uint32_t smax) {
+    uint32_t b[5] = {0, 0, 0, 0, 0};          // leaf boundaries in the type's own index space, nleaf leaves
+    uint32_t nleaf = 0;
+    bool split_left = false, split_right = false;
+    if (mine) {
+        uint32_t n2 = nt / 2u; n2 -= n2 % 8u;
+        const uint32_t nr = nt - n2;
+        split_left = n2 > 128u; split_right = nr > 128u;
+        uint32_t k = 0;
+        b[k++] = 0;
+        if (split_left) { uint32_t h = n2 / 2u; h -= h % 8u; b[k++] = h; }
+        b[k++] = n2;
+        if (split_right) { uint32_t h = nr / 2u; h -= h % 8u; b[k++] = n2 + h; }
+        b[k] = nt;
+        nleaf = k;
+    }
+    double leafsum[4] = {0.0, 0.0, 0.0, 0.0};
+    uint32_t j = 0, leaf = 0;
+#pragma unroll 1
+    for (uint32_t s = smin; s < smax; ++s) {
+        const bool in = mine && s >= e.lo && s < e.nprod;
+        const uint32_t m = in ? tb.pm[(int64_t)s * tb.n] : 0u;
+        if (in && (m & M_ALIVE) && (m & 7u) == type) {
+            const double q = tb.pq[(int64_t)s * tb.n];
+            const uint32_t lo = sel(b, leaf), hi = sel(b, leaf + 1u);
+            const uint32_t n = hi - lo, jj = j - lo, nfull = n & ~7u;
+            if (jj < nfull) { if (jj < 8u) a[jj] = q; else a[jj & 7u] += q; }
+            else { const double res = jj == nfull ? (nfull ? combine8(a) : 0.0) : a[8]; a[8] = res + q; }
+            ++j;
+            if (j == hi) {                                                          // leaf finished
+                const double tot = (n & 7u) == 0u ? combine8(a) : a[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) leafsum[k] = leaf == (uint32_t)k ? tot : leafsum[k];
+                ++leaf;
+            }
+        }
+    }
+    (void)nleaf;
+    // tree: S(left) + S(right), each side one leaf or the sum of two
+    double left, right;
+    if (split_left) { left = leafsum[0] + leafsum[1]; right = split_right ? leafsum[2] + leafsum[3] : leafsum[2]; }
+    else { left = leafsum[0]; right = split_right ? leafsum[1] + leafsum[2] : leafsum[1]; }
+    return left + right;
+}
+
+// obs[50..55]: np.mean of quality_score per product type over products_in_system (:220-228), NumPy pairwise order.
+// Wave-uniform walk over the union of the lanes' live slot ranges; per lane 6 x (8 accumulators + result) in LDS.
+__device__ __forceinline__ void type_means(Env &e, const Tab &tb, bool live, double *acc_lane, double (&mean)[6]) {
+    const uint32_t smin = wave_min(live ? e.lo : (uint32_t)CAP), smax = wave_max(live ? e.nprod : 0u);
+    uint64_t jc = 0;
+    uint32_t first_alive = e.nprod;
+#pragma unroll 2
+    for (uint32_t s = smin; s < smax; ++s) {
+        const bool in = live && s >= e.lo && s < e.nprod;
+        const uint32_t m = in ? tb.pm[(int64_t)s * tb.n] : 0u;
+        const double q = in ? tb.pq[(int64_t)s * tb.n] : 0.0;
+        if (in && (m & M_ALIVE)) {
+            first_alive = s < first_alive ? s : first_alive;
+            const uint32_t t = m & 7u, nt = fld9(e.nT, t), j = fld9(jc, t);
+            jc += 1ull << (9u * t);
+            if (nt <= 128u) {
+                const uint32_t nfull = nt & ~7u;
+                double *a = acc_lane + t * 9u;
+                if (j < nfull) { if (j < 8u) a[j] = q; else a[j & 7u] += q; }
+                else { const double res = j == nfull ? (nfull ? combine8(a) : 0.0) : a[8]; a[8] = res + q; }
+            }
+        }
+    }
+    if (live) e.lo = first_alive;
+    unsigned long long big = 0;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        const uint32_t nt = live ? fld9(e.nT, t) : 0u;
+        const double *a = acc_lane + t * 9;
+        double res = 0.0;
+        if (nt != 0u && nt <= 128u) res = (nt & 7u) == 0u ? combine8(a) : a[8];
+        mean[t] = nt ? res / (double)nt : 0.0;
+        big |= __ballot(nt > 128u) ? (1ull << t) : 0ull;
+    }
+    if (big) {
+#pragma unroll 1
+        for (uint32_t t = 0; t < 6u; ++t) {
+            if (!((big >> t) & 1ull)) continue;
+            const uint32_t nt = live ? fld9(e.nT, t) : 0u;
+            const bool mine = nt > 128u;
+            const double tot = big_type_sum(e, tb, mine, t, nt, acc_lane, smin, smax);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) mean[k] = (mine && t == (uint32_t)k) ? tot / (double)nt : mean[k];
+        }
+    }
+}
+
+__device__ __forceinline__ void stage_row(const Env &e, const double (&mean)[6], float *row) {       // :194-250
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) row[6 * s + k] = (float)fld9(e.cnt[s], k);
+        row[30 + 3 * s] = e.status[s] == OPERATIONAL ? 1.0f : 0.0f; row[31 + 3 * s] = e.status[s] == BROKEN ? 1.0f : 0.0f;
+        row[32 + 3 * s] = e.status[s] == MAINTENANCE ? 1.0f : 0.0f;
+        row[45 + s] = (float)fld9(e.qlen, s);
+        row[63 + s] = (float)(e.util[s] * 100);
+        row[68 + s] = (float)e.mcount[s];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        row[50 + k] = fld9(e.nT, k) ? (float)(mean[k] * 100) : 85.0f;
+        const int32_t rem = (int32_t)((e.targets >> (4 * k)) & 15u) - (int32_t)fld9(e.completed, k);
+        row[57 + k] = (float)(rem > 0 ? rem : 0);
+    }
+    row[56] = (float)e.raw;
+}
+
+__device__ __forceinline__ void store_rows(int64_t nrows, float *__restrict__ dst, unsigned long long rowmask, const uint32_t *__restrict__ tile) {
+    const uint32_t lane = threadIdx.x & 63u;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    uint32_t r = 0, col = lane;                                 // OBS = 73 > 64: lane walks the tile linearly
+#pragma unroll 1
+    for (int m = 0; m < OBS; ++m) {
+        if ((int64_t)r < nrows && ((rowmask >> r) & 1ull)) reinterpret_cast<uint32_t *>(dst)[(int64_t)r * OBS + col] = tile[r * OBS + col];
+        col += 64u;
+        if (col >= (uint32_t)OBS) { col -= OBS; r += 1u; }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+template <bool ROLLOUT>
+__global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
+    __shared__ double lds[64 * ACCROW];                        // accumulators during the slot walk, then the obs tile
+    uint32_t *tile = reinterpret_cast<uint32_t *>(lds);
+    const int64_t i0 = (int64_t)blockIdx.x * BLOCK;
+    const int64_t i = i0 + threadIdx.x;
+    const bool live = i < p.n;
+    const int64_t li = live ? i : i0;
+    const int64_t nrows = p.n - i0 < 64 ? p.n - i0 : 64;
+    const uint32_t lane = threadIdx.x & 63u;
+    Env e;
+    e.load(p.state, p.n, li);
+    const Tab tb(p, li);
+    const uint64_t key = ROLLOUT ? hash_env_key(p.a_seed, (uint64_t)(p.env0 + li)) : 0;
+    double rsum = 0.0;
+    int32_t dcount = 0;
+    const int ksteps = ROLLOUT ? p.k_steps : 1;
+#pragma unroll 1
+    for (int t = 0; t < ksteps; ++t) {
+        int32_t reward = 0;
+        uint32_t flags = 0;
+        bool reset_now = false;
+        if (live) {
+            if (p.mode == CGE_AUTORESET_NEXT_STEP && e.needs_reset) {
+                do_reset(e);
+            } else {
+                const int32_t a = p.actions ? p.actions[(int64_t)t * p.n + i] : (int32_t)hash_action_from_key(key, (uint64_t)(p.t0 + t), 25u, 0u);
+                flags = env_step(e, tb, p.max_steps, a, reward);
+                if (flags) {
+                    e.episodes += 1;
+                    if (p.mode == CGE_AUTORESET_SAME_STEP) reset_now = true;
+                    else if (p.mode == CGE_AUTORESET_NEXT_STEP) e.needs_reset = 1;
+                }
+            }
+        }
+        const bool want_obs = p.obs != nullptr;                // a rollout writes the obs of every step (stride 0: in place)
+        const unsigned long long fin_mask = __ballot(reset_now);
+        if (want_obs || (fin_mask && p.final_obs)) {
+            double mean[6];
+            type_means(e, tb, live, lds + lane * ACCROW, mean);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (fin_mask && p.final_obs) {
+                stage_row(e, mean, reinterpret_cast<float *>(tile) + lane * OBS);
+                store_rows(nrows, p.final_obs + i0 * OBS, fin_mask, tile);
+            }
+            if (reset_now) do_reset(e);                        // fresh episode: nothing in the system, means default to 85
+            if (want_obs) {
+                stage_row(e, mean, reinterpret_cast<float *>(tile) + lane * OBS);
+                store_rows(nrows, p.obs + (int64_t)t * p.obs_step_stride + i0 * OBS, ~0ull, tile);
+            }
+        } else if (reset_now) {
+            do_reset(e);
+        }
+        if (live) {
+            if (ROLLOUT) {
+                rsum += (double)reward;
+                dcount += flags ? 1 : 0;
+                if (p.reward) p.reward[(int64_t)t * p.n + i] = (float)reward;
+                if (p.terminated) p.terminated[(int64_t)t * p.n + i] = (uint8_t)flags;
+            } else {
+                p.reward[i] = (float)reward;
+                p.terminated[i] = (uint8_t)(flags & 1u);
+                p.truncated[i] = (uint8_t)((flags >> 1) & 1u);
+            }
+        }
+    }
+    if (live) {
+        e.store(p.state, p.n, i);
+        if (ROLLOUT) {
+            if (p.reward_sum) p.reward_sum[i] = rsum;
+            if (p.done_count) p.done_count[i] = dcount;
+        }
+    }
+}
+
+// what: 0 = reset(mask) + obs, 1 = reseed the generators, 2 = fresh-handle state (generators seeded, nothing in the system)
+__global__ __launch_bounds__(BLOCK) void reset_kernel(Params p, int what) {
+    __shared__ double lds[64 * ACCROW];
+    uint32_t *tile = reinterpret_cast<uint32_t *>(lds);
+    const int64_t i0 = (int64_t)blockIdx.x * BLOCK;
+    const int64_t i = i0 + threadIdx.x;
+    const bool live = i < p.n;
+    const int64_t li = live ? i : i0;
+    const int64_t nrows = p.n - i0 < 64 ? p.n - i0 : 64;
+    const uint32_t lane = threadIdx.x & 63u;
+    Env e;
+    e.load(p.state, p.n, li);
+    const Tab tb(p, li);
+    if (live) {
+        if (what == 1 || what == 2) {
+            e.g.seed(p.seeds ? p.seeds[i] : p.base_seed + (uint64_t)(p.env0 + i));
+            if (what == 2) {
+#pragma unroll
+                for (int s = 0; s < 5; ++s) { e.cur[s] = NONE; e.status[s] = OPERATIONAL; }
+                e.thr[0] = 0.70; e.thr[1] = 0.80; e.thr[2] = 0.85; e.raw = 250;
+            }
+            e.store(p.state, p.n, i);
+        } else if (!p.mask || p.mask[i]) {
+            do_reset(e);
+            e.store(p.state, p.n, i);
+        }
+    }
+    if (what == 0 && p.obs) {
+        double mean[6];
+        type_means(e, tb, live, lds + lane * ACCROW, mean);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stage_row(e, mean, reinterpret_cast<float *>(tile) + lane * OBS);
+        store_rows(nrows, p.obs + i0 * OBS, ~0ull, tile);
+    }
+}
+
+__global__ __launch_bounds__(256) void info_kernel(const uint4 *__restrict__ state, int64_t n, int field, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    Env e;
+    e.load(state, n, i);
+    double v = 0.0;
+    uint32_t c = 0;
+    switch (field) {
+        case CGE_MANUFACTURING_INFO_RAW_MATERIAL: v = e.raw; break;
+        case CGE_MANUFACTURING_INFO_ENERGY_CONSUMPTION: v = e.energy; break;
+        case CGE_MANUFACTURING_INFO_TOTAL_REWARD: v = e.total_reward; break;
+        case CGE_MANUFACTURING_INFO_IN_SYSTEM:
+            for (int k = 0; k < 6; ++k) c += fld9(e.nT, k);
+            v = c; break;
+        case CGE_MANUFACTURING_INFO_COMPLETED: v = e.ncomp; break;
+        case CGE_MANUFACTURING_INFO_SCRAPPED: v = e.nscrap; break;
+        case CGE_MANUFACTURING_INFO_PRODUCT_IDS: v = e.nprod; break;
+        case CGE_MANUFACTURING_INFO_HISTORY_LEN: v = e.nhist; break;
+        case CGE_MANUFACTURING_INFO_OEE_AVAILABILITY:
+            for (int s = 0; s < 5; ++s) c += e.status[s] == OPERATIONAL ? 1u : 0u;
+            v = (double)c / 5; break;
+        case CGE_MANUFACTURING_INFO_OEE_PERFORMANCE: {                                   // np.mean of 5 utilisation rates (:541-542); 1.0 after reset
+            double sum = 0.0;
+            for (int s = 0; s < 5; ++s) sum += e.util[s];
+            v = e.timestep == 0 ? 1.0 : sum / 5.0; break;
+        }
+        case CGE_MANUFACTURING_INFO_OEE_QUALITY: v = e.ncomp ? (double)e.ngood / (double)e.ncomp : 1.0; break;
+        case CGE_MANUFACTURING_INFO_TIMESTEP: v = e.timestep; break;
+        case CGE_MANUFACTURING_INFO_EPISODES: v = e.episodes; break;
+        case CGE_MANUFACTURING_INFO_NEEDS_RESET: v = e.needs_reset; break;
+        case CGE_MANUFACTURING_INFO_OVERFLOW: v = e.overflow; break;
+    }
+    out[i] = v;
+}
+
+}  // namespace mfg
+}  // namespace cge
+
+using namespace cge;
+
+struct cge_manufacturing : HandleBase {
+    cge_manufacturing_config cfg{};
+    uint4 *state = nullptr;
+    double *pq = nullptr, *comp = nullptr, *hist = nullptr;
+    uint16_t *pm = nullptr, *pnext = nullptr;
+    mfg::Params params() const {
+        mfg::Params p{};
+        p.state = state; p.pq = pq; p.pm = pm; p.pnext = pnext; p.comp = comp; p.hist = hist;
+        p.n = n; p.env0 = env0; p.mode = cfg.autoreset_mode; p.max_steps = cfg.max_steps;
+        return p;
+    }
+    unsigned blocks() const { return (unsigned)((n + mfg::BLOCK - 1) / mfg::BLOCK); }
+    void free_all() { (void)hipFree(state); (void)hipFree(pq); (void)hipFree(pm); (void)hipFree(pnext); (void)hipFree(comp); (void)hipFree(hist); }
+};
+
+extern "C" {
+
+int cge_manufacturing_create(const cge_manufacturing_config *cfg, int64_t n_envs, int device, int64_t env_index0, cge_manufacturing **out) {
+    if (!cfg || !out || n_envs <= 0 || env_index0 < 0) return CGE_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (cfg->autoreset_mode < 0 || cfg->autoreset_mode > 2 || cfg->max_steps < 0 || cfg->max_steps > 1500) return CGE_ERR_INVALID_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return CGE_ERR_NO_DEVICE;
+    cge_manufacturing *h = new cge_manufacturing();
+    h->cfg = *cfg;
+    if (h->cfg.max_steps == 0) h->cfg.max_steps = 1500;
+    h->n = n_envs; h->env0 = env_index0; h->device = device;
+    DeviceGuard g(device);
+    const size_t N = (size_t)n_envs;
+    const size_t sb = (size_t)mfg::COLS * N * sizeof(uint4), qb = (size_t)mfg::CAP * N * 8, mb = (size_t)mfg::CAP * N * 2, cb = 20 * N * 8, hb = 100 * N * 8;
+    hipError_t e;
+    if ((e = hipMalloc(&h->state, sb)) != hipSuccess || (e = hipMalloc(&h->pq, qb)) != hipSuccess || (e = hipMalloc(&h->pm, mb)) != hipSuccess ||
+        (e = hipMalloc(&h->pnext, mb)) != hipSuccess || (e = hipMalloc(&h->comp, cb)) != hipSuccess || (e = hipMalloc(&h->hist, hb)) != hipSuccess ||
+        (e = hipMemset(h->state, 0, sb)) != hipSuccess) {
+        h->free_all();
+        delete h;
+        return CGE_ERR_HIP;
+    }
+    h->device_bytes = sb + qb + 2 * mb + cb + hb;
+    mfg::Params p = h->params();                               // default generators: PCG64(SeedSequence(env_index0 + i)); no reset
+    hipLaunchKernelGGL(mfg::reset_kernel, dim3(h->blocks()), dim3(mfg::BLOCK), 0, nullptr, p, 2);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) {
+        h->free_all();
+        delete h;
+        return CGE_ERR_HIP;
+    }
+    *out = h;
+    return CGE_OK;
+}
+
+int cge_manufacturing_destroy(cge_manufacturing *h) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    DeviceGuard g(h->device);
+    (void)hipDeviceSynchronize();
+    h->free_all();
+    delete h;
+    return CGE_OK;
+}
+
+int cge_manufacturing_seed(cge_manufacturing *h, const uint64_t *seeds, uint64_t base_seed, void *stream) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    DeviceGuard g(h->device);
+    mfg::Params p = h->params();
+    p.seeds = seeds; p.base_seed = base_seed;
+    hipLaunchKernelGGL(mfg::reset_kernel, dim3(h->blocks()), dim3(mfg::BLOCK), 0, as_stream(stream), p, 1);
+    CGE_TRY(h, hipGetLastError());
+    return CGE_OK;
+}
+
+int cge_manufacturing_reset(cge_manufacturing *h, const uint8_t *mask, float *obs_out, void *stream) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    DeviceGuard g(h->device);
+    mfg::Params p = h->params();
+    p.mask = mask; p.obs = obs_out;
+    hipLaunchKernelGGL(mfg::reset_kernel, dim3(h->blocks()), dim3(mfg::BLOCK), 0, as_stream(stream), p, 0);
+    CGE_TRY(h, hipGetLastError());
+    return CGE_OK;
+}
+
+int cge_manufacturing_step(cge_manufacturing *h, const int32_t *actions, float *obs_out, float *reward_out, uint8_t *terminated_out,
+                           uint8_t *truncated_out, float *final_obs_out, void *stream) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    if (!actions || !obs_out || !reward_out || !terminated_out || !truncated_out)
+        return h->fail(CGE_ERR_INVALID_ARG, "cge_manufacturing_step: null actions/obs/reward/terminated/truncated pointer");
+    DeviceGuard g(h->device);
+    mfg::Params p = h->params();
+    p.actions = actions; p.obs = obs_out; p.reward = reward_out; p.terminated = terminated_out; p.truncated = truncated_out;
+    p.final_obs = final_obs_out; p.k_steps = 1;
+    hipLaunchKernelGGL(mfg::step_kernel<false>, dim3(h->blocks()), dim3(mfg::BLOCK), 0, as_stream(stream), p);
+    CGE_TRY(h, hipGetLastError());
+    return CGE_OK;
+}
+
+int cge_manufacturing_rollout(cge_manufacturing *h, int32_t k_steps, const int32_t *actions, uint64_t action_seed, int64_t t0, float *obs_out,
+                              int64_t obs_step_stride, float *reward_traj_out, uint8_t *terminated_traj_out, double *reward_sum_out,
+                              int32_t *done_count_out, void *stream) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    if (k_steps < 0 || obs_step_stride < 0 || (obs_step_stride != 0 && obs_step_stride < h->n * mfg::OBS))
+        return h->fail(CGE_ERR_INVALID_ARG, "cge_manufacturing_rollout: bad k_steps / obs_step_stride");
+    if (k_steps == 0) return CGE_OK;
+    DeviceGuard g(h->device);
+    mfg::Params p = h->params();
+    p.k_steps = k_steps; p.actions = actions; p.a_seed = action_seed; p.t0 = t0; p.obs = obs_out; p.obs_step_stride = obs_step_stride;
+    p.reward = reward_traj_out; p.terminated = terminated_traj_out; p.reward_sum = reward_sum_out; p.done_count = done_count_out;
+    hipLaunchKernelGGL(mfg::step_kernel<true>, dim3(h->blocks()), dim3(mfg::BLOCK), 0, as_stream(stream), p);
+    CGE_TRY(h, hipGetLastError());
+    return CGE_OK;
+}
+
+int cge_manufacturing_info(cge_manufacturing *h, int32_t field_id, double *out, void *stream) {
+    if (!h || !out || field_id < 0 || field_id > CGE_MANUFACTURING_INFO_OVERFLOW) return CGE_ERR_INVALID_ARG;
+    DeviceGuard g(h->device);
+    hipLaunchKernelGGL(mfg::info_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, as_stream(stream), h->state, h->n, field_id, out);
+    CGE_TRY(h, hipGetLastError());
+    return CGE_OK;
+}
+
+size_t cge_manufacturing_device_bytes(const cge_manufacturing *h) { return h ? h->device_bytes : 0; }
+const char *cge_manufacturing_last_error(const cge_manufacturing *h) { return h ? h->last_error.c_str() : "null handle"; }
+
+}  // extern "C"

@@ -380,6 +380,43 @@ int cge_fleet_info(cge_fleet *h, int32_t field_id, double *out, void *stream);
 size_t cge_fleet_device_bytes(const cge_fleet *h);
 const char *cge_fleet_last_error(const cge_fleet *h);
 
+/* ------------------------------------------------------------------------------------------ */
+/* Manufacturing  (smart_manufacturing_env/manufacturing_env.py: SmartManufacturingEnv)         */
+/*   obs float32 (73,) (:194-250)   action int32 in 0..24 (:85, :303-359)                        */
+/*   terminated (:555-578) AND truncated (timestep >= 1500, :282) are both reported.             */
+/*   Generator: gymnasium's self.np_random = Generator(PCG64(SeedSequence(seed))) (:115).        */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct cge_manufacturing cge_manufacturing;
+
+typedef struct {
+    int32_t max_steps;        /* 1500 (:282, :569); <= 1500 (bounds the per-episode product table) */
+    int32_t autoreset_mode;   /* CGE_AUTORESET_* */
+} cge_manufacturing_config;
+
+enum { /* cge_manufacturing_info float64 fields (info dict :293-299, oee_metrics :533-548, list lengths) */
+    CGE_MANUFACTURING_INFO_RAW_MATERIAL = 0, CGE_MANUFACTURING_INFO_ENERGY_CONSUMPTION = 1, CGE_MANUFACTURING_INFO_TOTAL_REWARD = 2,
+    CGE_MANUFACTURING_INFO_IN_SYSTEM = 3, CGE_MANUFACTURING_INFO_COMPLETED = 4, CGE_MANUFACTURING_INFO_SCRAPPED = 5,
+    CGE_MANUFACTURING_INFO_PRODUCT_IDS = 6, CGE_MANUFACTURING_INFO_HISTORY_LEN = 7, CGE_MANUFACTURING_INFO_OEE_AVAILABILITY = 8,
+    CGE_MANUFACTURING_INFO_OEE_PERFORMANCE = 9, CGE_MANUFACTURING_INFO_OEE_QUALITY = 10, CGE_MANUFACTURING_INFO_TIMESTEP = 11,
+    CGE_MANUFACTURING_INFO_EPISODES = 12, CGE_MANUFACTURING_INFO_NEEDS_RESET = 13, CGE_MANUFACTURING_INFO_OVERFLOW = 14
+};
+
+int cge_manufacturing_create(const cge_manufacturing_config *cfg, int64_t n_envs, int device, int64_t env_index0, cge_manufacturing **out);
+int cge_manufacturing_destroy(cge_manufacturing *h);
+/* reset(seed=s): env i gets Generator(PCG64(SeedSequence(s_i))); s_i = seeds[i] or base_seed + env_index0 + i */
+int cge_manufacturing_seed(cge_manufacturing *h, const uint64_t *seeds, uint64_t base_seed, void *stream);
+int cge_manufacturing_reset(cge_manufacturing *h, const uint8_t *mask, float *obs_out, void *stream);
+/* actions int32 [n_envs]; a value outside 0..24 is a no-op (falls through every branch of :303-359). */
+int cge_manufacturing_step(cge_manufacturing *h, const int32_t *actions, float *obs_out, float *reward_out, uint8_t *terminated_out,
+                           uint8_t *truncated_out, float *final_obs_out, void *stream);
+/* done_count counts terminated-or-truncated steps; terminated_traj_out gets terminated | truncated << 1 */
+int cge_manufacturing_rollout(cge_manufacturing *h, int32_t k_steps, const int32_t *actions, uint64_t action_seed, int64_t t0,
+                              float *obs_out, int64_t obs_step_stride, float *reward_traj_out, uint8_t *terminated_traj_out,
+                              double *reward_sum_out, int32_t *done_count_out, void *stream);
+int cge_manufacturing_info(cge_manufacturing *h, int32_t field_id, double *out, void *stream);
+size_t cge_manufacturing_device_bytes(const cge_manufacturing *h);
+const char *cge_manufacturing_last_error(const cge_manufacturing *h);
+
 #ifdef __cplusplus
 }
 #endif
