@@ -48,6 +48,10 @@ ENVS = {
                     roll_kernel="cge::climate::step_kernel<true>", ref_py="1.27e4 steps/s/process"),
     "fleet":   dict(algo=642,  n_act=8, act_shape=(3,), dtype="f64",  step_kernel="cge::fleet::step_kernel + cge::fleet::dense_kernel",
                     roll_kernel="cge::fleet::step_kernel + cge::fleet::dense_kernel", launches_per_step=True, ref_py="2.01e4 steps/s/process"),
+    # 292 obs + 2 x 336 state + action/reward/flags; plus 10 bytes (quality f64 + meta u16) per product in the system, which the
+    # per-type np.mean of the observation has to read every step: added from the measured mean occupancy (algo_per_product)
+    "manufacturing": dict(algo=974, algo_per_product=10, n_act=25, act_shape=(), dtype="f64", step_kernel="cge::mfg::step_kernel<false>",
+                          roll_kernel="cge::mfg::step_kernel<true>", ref_py="not in BASELINE.md"),
 }
 WORKLOADS = {
     "snake_1m": dict(env="snake", n=1 << 20, desc="SnakeEnv 10x10, 1,048,576 parallel envs per GPU, random actions, fused auto-reset"),
@@ -57,6 +61,7 @@ WORKLOADS = {
     "parking_131k": dict(env="parking", n=1 << 17, desc="smart_parking_env, 131,072 parallel envs per GPU"),
     "climate_131k": dict(env="climate", n=1 << 17, desc="smartclimate, 131,072 parallel envs per GPU"),
     "fleet_131k": dict(env="fleet", n=1 << 17, desc="fleet_management_env, 131,072 parallel envs per GPU"),
+    "manufacturing_131k": dict(env="manufacturing", n=1 << 17, desc="smart_manufacturing_env, 131,072 parallel envs per GPU"),
     "hetero_131k": dict(env="hetero", n=1 << 17,
                         desc="heterogeneous batch: every implemented env type x 131,072, co-resident on each GPU, one HIP stream per type"),
 }
@@ -69,7 +74,7 @@ def make_env(cge, name, n, dev, env0):
     if name == "crypto":
         return cge.CryptoVectorEnv(n, action_type="discrete", **kw)
     return {"traffic": cge.TrafficVectorEnv, "parking": cge.ParkingVectorEnv, "climate": cge.ClimateVectorEnv,
-            "fleet": cge.FleetVectorEnv}[name](n, **kw)
+            "fleet": cge.FleetVectorEnv, "manufacturing": cge.ManufacturingVectorEnv}[name](n, **kw)
 
 
 def make_actions(name, steps, n, dev):
@@ -94,11 +99,12 @@ def cpu_baseline(name, budget_s=12.0):
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, 16))        # a 1-GPU box's CPU share is 16 cores
     n_each, k = {"snake": (8192, 250), "crypto": (256, 100), "traffic": (1024, 100), "parking": (1024, 100),
-                 "climate": (2048, 100), "fleet": (1024, 100)}[name]
+                 "climate": (2048, 100), "fleet": (1024, 100), "manufacturing": (512, 100)}[name]
     ctor = {"snake": lambda: oracle.SnakeOracle(n_each, 10, oracle.SAME_STEP),
             "crypto": lambda: oracle.CryptoOracle(n_each, "discrete", oracle.SAME_STEP),
             "traffic": lambda: oracle.TrafficOracle(n_each, oracle.SAME_STEP), "parking": lambda: oracle.ParkingOracle(n_each, oracle.SAME_STEP),
-            "climate": lambda: oracle.ClimateOracle(n_each, oracle.SAME_STEP), "fleet": lambda: oracle.FleetOracle(n_each, oracle.SAME_STEP)}[name]
+            "climate": lambda: oracle.ClimateOracle(n_each, oracle.SAME_STEP), "fleet": lambda: oracle.FleetOracle(n_each, oracle.SAME_STEP),
+            "manufacturing": lambda: oracle.ManufacturingOracle(n_each, oracle.SAME_STEP)}[name]
 
     def new(c):
         h = ctor()
@@ -139,8 +145,8 @@ def pmc_traffic(kernel):
         return None
 
 
-def roofline(name, kernel, gpu_ms, launches, steps_per_launch, n):
-    algo = ENVS[name]["algo"]
+def roofline(name, kernel, gpu_ms, launches, steps_per_launch, n, occupancy=0.0):
+    algo = ENVS[name]["algo"] + ENVS[name].get("algo_per_product", 0) * occupancy
     launch_s = gpu_ms * 1e-3 / launches
     achieved = algo * n * steps_per_launch / launch_s / 1e9
     return {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -205,7 +211,13 @@ def main():
                 with torch.cuda.stream(streams[nm]):
                     envs[nm].step(act_at(nm, actions[nm], t))
 
-    def timed(fn):
+    occupancy = {}
+
+    def mean_occupancy():
+        return {nm: float(envs[nm].info("in_system").mean().item()) for nm in names if "algo_per_product" in ENVS[nm]}
+
+    def timed(fn, tag=None):
+        before = mean_occupancy()
         barrier()
         evs = {nm: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for nm in names}
         t0 = time.perf_counter()
@@ -216,14 +228,16 @@ def main():
             evs[nm][1].record(streams[nm])
         barrier()
         wall = time.perf_counter() - t0
+        after = mean_occupancy()
+        occupancy[tag] = {nm: 0.5 * (before[nm] + after[nm]) for nm in before}
         return wall, {nm: evs[nm][0].elapsed_time(evs[nm][1]) for nm in names}
 
     results = {}
     run_rollout(max(W, 1), 0)                                        # fused rollout: K steps in one launch per env type
-    results["rollout"] = timed(lambda: run_rollout(K, W))
+    results["rollout"] = timed(lambda: run_rollout(K, W), "rollout")
     actions = {nm: make_actions(nm, K + W, n, dev) for nm in names}  # API path: K step() calls, HBM-resident actions
     run_steps(actions, 0, W)
-    results["step"] = timed(lambda: run_steps(actions, W, W + K))
+    results["step"] = timed(lambda: run_steps(actions, W, W + K), "step")
     if "snake" in envs:
         assert envs["snake"].invalid_action_count() == 0
 
@@ -246,7 +260,7 @@ def main():
                 kern = ENVS[nm]["roll_kernel" if path == "rollout" else "step_kernel"]
                 # fleet's rollout is K (step, dense) launch pairs, not one fused launch: price it per pair
                 fused = path == "rollout" and not ENVS[nm].get("launches_per_step")
-                rl[nm] = roofline(nm, kern, gpu_ms[nm], 1 if fused else K, K if fused else 1, n)
+                rl[nm] = roofline(nm, kern, gpu_ms[nm], 1 if fused else K, K if fused else 1, n, occupancy[path].get(nm, 0.0))
             b["roofline"] = rl[names[0]] if len(names) == 1 else rl
             return b
 
