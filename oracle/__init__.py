@@ -134,6 +134,13 @@ def _declare(L):
     L.orc_fleet_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.orc_fleet_rollout.argtypes = [vp, i32, u64, i64, i64, vp, vp, vp]
     L.orc_fleet_info.argtypes = [vp, i32, vp]
+    L.orc_hospital_create.argtypes = [i64, i32]; L.orc_hospital_create.restype = vp
+    L.orc_hospital_destroy.argtypes = [vp]
+    L.orc_hospital_seed.argtypes = [vp, vp]
+    L.orc_hospital_reset.argtypes = [vp, vp, vp]
+    L.orc_hospital_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.orc_hospital_rollout.argtypes = [vp, i32, u64, i64, i64, vp, vp, vp]
+    L.orc_hospital_info.argtypes = [vp, i32, vp]
     L.orc_manufacturing_create.argtypes = [i64, i32]; L.orc_manufacturing_create.restype = vp
     L.orc_manufacturing_destroy.argtypes = [vp]
     L.orc_manufacturing_seed.argtypes = [vp, vp]
@@ -538,4 +545,20 @@ class ManufacturingOracle(_SimpleOracle):
     def info(self, field):
         out = np.zeros(self.n, np.float64)
         lib().orc_manufacturing_info(self.h, MANUFACTURING_INFO[field] if isinstance(field, str) else field, _p(out))
+        return out
+
+
+HOSPITAL_OBS = 243
+HOSPITAL_INFO = {"deaths": 0, "patients_treated": 1, "total_wait_time": 2, "time": 3, "outbreak_active": 4, "mass_casualty_event": 5,
+                 "next_patient_id": 6, "queue0": 7, "queue1": 8, "queue2": 9, "queue3": 10, "queue4": 11, "queue5": 12,
+                 "occupied_beds": 13, "medicine_total": 14, "episodes": 15, "needs_reset": 16, "overflow": 17}
+
+
+class HospitalOracle(_SimpleOracle):
+    """Batch of independent HospitalManagementEnv restatements (oracle/orc_hospital.c); Discrete(35) actions."""
+    _name, _obs, _nact = "hospital", HOSPITAL_OBS, 35
+
+    def info(self, field):
+        out = np.zeros(self.n, np.float64)
+        lib().orc_hospital_info(self.h, HOSPITAL_INFO[field] if isinstance(field, str) else field, _p(out))
         return out
