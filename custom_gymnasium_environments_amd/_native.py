@@ -49,6 +49,10 @@ class FleetConfig(C.Structure):
     _fields_ = [("max_timesteps", C.c_int32), ("autoreset_mode", C.c_int32)]
 
 
+class HospitalConfig(C.Structure):
+    _fields_ = [("max_episode_length", C.c_int32), ("autoreset_mode", C.c_int32)]
+
+
 class ManufacturingConfig(C.Structure):
     _fields_ = [("max_steps", C.c_int32), ("autoreset_mode", C.c_int32)]
 
@@ -135,6 +139,15 @@ SIGNATURES = {
     "cge_manufacturing_info": (C.c_int, [_vp, _i32, _vp, _vp]),
     "cge_manufacturing_device_bytes": (_sz, [_vp]),
     "cge_manufacturing_last_error": (C.c_char_p, [_vp]),
+    "cge_hospital_create": (C.c_int, [C.POINTER(HospitalConfig), _i64, C.c_int, _i64, C.POINTER(_vp)]),
+    "cge_hospital_destroy": (C.c_int, [_vp]),
+    "cge_hospital_seed": (C.c_int, [_vp, _vp, _u64, _vp]),
+    "cge_hospital_reset": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "cge_hospital_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cge_hospital_rollout": (C.c_int, [_vp, _i32, _vp, _u64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "cge_hospital_info": (C.c_int, [_vp, _i32, _vp, _vp]),
+    "cge_hospital_device_bytes": (_sz, [_vp]),
+    "cge_hospital_last_error": (C.c_char_p, [_vp]),
 }
 
 _lib = None

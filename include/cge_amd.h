@@ -417,6 +417,44 @@ int cge_manufacturing_info(cge_manufacturing *h, int32_t field_id, double *out, 
 size_t cge_manufacturing_device_bytes(const cge_manufacturing *h);
 const char *cge_manufacturing_last_error(const cge_manufacturing *h);
 
+/* ------------------------------------------------------------------------------------------ */
+/* Hospital  (hospital_management_env/hospital_env.py: HospitalManagementEnv)                   */
+/*   obs float32 (243,) (:256-321; the declared space says 295)   action int32 in 0..34 (:165)   */
+/*   terminated (:726-742) AND truncated (current_time >= 1440, :357) are both reported.         */
+/*   Generator: the process-global CPython `random`; the env never seeds it (:186), so           */
+/*   cge_hospital_seed is the caller's random.seed(s_i) for env i.                               */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct cge_hospital cge_hospital;
+
+typedef struct {
+    int32_t max_episode_length;   /* 1440 (:94); <= 2000 */
+    int32_t autoreset_mode;       /* CGE_AUTORESET_* */
+} cge_hospital_config;
+
+enum { /* cge_hospital_info float64 fields (info dict :362-367 and internal counters) */
+    CGE_HOSPITAL_INFO_DEATHS = 0, CGE_HOSPITAL_INFO_PATIENTS_TREATED = 1, CGE_HOSPITAL_INFO_TOTAL_WAIT_TIME = 2, CGE_HOSPITAL_INFO_TIME = 3,
+    CGE_HOSPITAL_INFO_OUTBREAK_ACTIVE = 4, CGE_HOSPITAL_INFO_MASS_CASUALTY_EVENT = 5, CGE_HOSPITAL_INFO_NEXT_PATIENT_ID = 6,
+    CGE_HOSPITAL_INFO_QUEUE0 = 7, /* .. QUEUE0 + 5: len(patient_queues[Department(d)]) */
+    CGE_HOSPITAL_INFO_OCCUPIED_BEDS = 13, CGE_HOSPITAL_INFO_MEDICINE_TOTAL = 14, CGE_HOSPITAL_INFO_EPISODES = 15,
+    CGE_HOSPITAL_INFO_NEEDS_RESET = 16, CGE_HOSPITAL_INFO_OVERFLOW = 17
+};
+
+int cge_hospital_create(const cge_hospital_config *cfg, int64_t n_envs, int device, int64_t env_index0, cge_hospital **out);
+int cge_hospital_destroy(cge_hospital *h);
+/* random.seed(s_i) for env i; s_i = seeds[i] or base_seed + env_index0 + i */
+int cge_hospital_seed(cge_hospital *h, const uint64_t *seeds, uint64_t base_seed, void *stream);
+int cge_hospital_reset(cge_hospital *h, const uint8_t *mask, float *obs_out, void *stream);
+/* actions int32 [n_envs]; a value outside 0..34 is a no-op.  truncated_out is REQUIRED. */
+int cge_hospital_step(cge_hospital *h, const int32_t *actions, float *obs_out, float *reward_out, uint8_t *terminated_out,
+                      uint8_t *truncated_out, float *final_obs_out, void *stream);
+/* done_count counts terminated-or-truncated steps; terminated_traj_out gets terminated | truncated << 1 */
+int cge_hospital_rollout(cge_hospital *h, int32_t k_steps, const int32_t *actions, uint64_t action_seed, int64_t t0,
+                         float *obs_out, int64_t obs_step_stride, float *reward_traj_out, uint8_t *terminated_traj_out,
+                         double *reward_sum_out, int32_t *done_count_out, void *stream);
+int cge_hospital_info(cge_hospital *h, int32_t field_id, double *out, void *stream);
+size_t cge_hospital_device_bytes(const cge_hospital *h);
+const char *cge_hospital_last_error(const cge_hospital *h);
+
 #ifdef __cplusplus
 }
 #endif
