@@ -50,6 +50,9 @@ ENVS = {
                     roll_kernel="cge::fleet::step_kernel + cge::fleet::dense_kernel", launches_per_step=True, ref_py="2.01e4 steps/s/process"),
     # 292 obs + 2 x 336 state + action/reward/flags; plus 10 bytes (quality f64 + meta u16) per product in the system, which the
     # per-type np.mean of the observation has to read every step: added from the measured mean occupancy (algo_per_product)
+    # 972 obs + 2 x 768 state + action/reward/flags + ~70 MT19937 words read and written per step (2 x 280)
+    "hospital": dict(algo=3078, n_act=35, act_shape=(), dtype="f64", step_kernel="cge::hosp::step_kernel<false>",
+                     roll_kernel="cge::hosp::step_kernel<true>", ref_py="not in BASELINE.md"),
     "manufacturing": dict(algo=974, algo_per_product=10, n_act=25, act_shape=(), dtype="f64", step_kernel="cge::mfg::step_kernel<false>",
                           roll_kernel="cge::mfg::step_kernel<true>", ref_py="not in BASELINE.md"),
 }
@@ -62,6 +65,7 @@ WORKLOADS = {
     "climate_131k": dict(env="climate", n=1 << 17, desc="smartclimate, 131,072 parallel envs per GPU"),
     "fleet_131k": dict(env="fleet", n=1 << 17, desc="fleet_management_env, 131,072 parallel envs per GPU"),
     "manufacturing_131k": dict(env="manufacturing", n=1 << 17, desc="smart_manufacturing_env, 131,072 parallel envs per GPU"),
+    "hospital_131k": dict(env="hospital", n=1 << 17, desc="hospital_management_env, 131,072 parallel envs per GPU"),
     "hetero_131k": dict(env="hetero", n=1 << 17,
                         desc="heterogeneous batch: every implemented env type x 131,072, co-resident on each GPU, one HIP stream per type"),
 }
@@ -74,7 +78,7 @@ def make_env(cge, name, n, dev, env0):
     if name == "crypto":
         return cge.CryptoVectorEnv(n, action_type="discrete", **kw)
     return {"traffic": cge.TrafficVectorEnv, "parking": cge.ParkingVectorEnv, "climate": cge.ClimateVectorEnv,
-            "fleet": cge.FleetVectorEnv, "manufacturing": cge.ManufacturingVectorEnv}[name](n, **kw)
+            "fleet": cge.FleetVectorEnv, "manufacturing": cge.ManufacturingVectorEnv, "hospital": cge.HospitalVectorEnv}[name](n, **kw)
 
 
 def make_actions(name, steps, n, dev):
@@ -99,12 +103,13 @@ def cpu_baseline(name, budget_s=12.0):
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, 16))        # a 1-GPU box's CPU share is 16 cores
     n_each, k = {"snake": (8192, 250), "crypto": (256, 100), "traffic": (1024, 100), "parking": (1024, 100),
-                 "climate": (2048, 100), "fleet": (1024, 100), "manufacturing": (512, 100)}[name]
+                 "climate": (2048, 100), "fleet": (1024, 100), "manufacturing": (512, 100), "hospital": (256, 100)}[name]
     ctor = {"snake": lambda: oracle.SnakeOracle(n_each, 10, oracle.SAME_STEP),
             "crypto": lambda: oracle.CryptoOracle(n_each, "discrete", oracle.SAME_STEP),
             "traffic": lambda: oracle.TrafficOracle(n_each, oracle.SAME_STEP), "parking": lambda: oracle.ParkingOracle(n_each, oracle.SAME_STEP),
             "climate": lambda: oracle.ClimateOracle(n_each, oracle.SAME_STEP), "fleet": lambda: oracle.FleetOracle(n_each, oracle.SAME_STEP),
-            "manufacturing": lambda: oracle.ManufacturingOracle(n_each, oracle.SAME_STEP)}[name]
+            "manufacturing": lambda: oracle.ManufacturingOracle(n_each, oracle.SAME_STEP),
+            "hospital": lambda: oracle.HospitalOracle(n_each, oracle.SAME_STEP)}[name]
 
     def new(c):
         h = ctor()

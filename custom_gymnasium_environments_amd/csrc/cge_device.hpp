@@ -184,6 +184,60 @@ struct LdsDraws {
     }
 };
 
+// Same queue, but the refill is a real (by-value) call instead of being inlined at every draw site.  For kernels with
+// many draw sites (hospital: ~60) the inlined flush + 16-word fill made the kernel ~90k instructions of straight-line
+// code and instruction fetch the bottleneck; the cursor fields still live in registers.
+template <int W>
+struct LdsDrawsCall {
+    uint32_t *row;
+    uint32_t *blk;
+    uint32_t pos, pretw, cur;
+    bool filled;
+
+    __device__ __forceinline__ LdsDrawsCall(uint32_t *lds_row, uint32_t *block, uint32_t pos_, uint32_t pretw_)
+        : row(lds_row), blk(block), pos(pos_), pretw(pretw_), cur(0), filled(false) {}
+    static __device__ __attribute__((noinline)) uint2 refill(uint32_t *row, uint32_t *blk, uint32_t pos, uint32_t pretw, uint32_t cur, bool filled) {
+        LdsDraws<W> d(row, blk, pos, pretw);
+        d.cur = cur; d.filled = filled;
+        d.flush();
+        d.fill();
+        return make_uint2(d.pos, d.pretw);
+    }
+    __device__ __forceinline__ void flush() {
+        LdsDraws<W> d(row, blk, pos, pretw);
+        d.cur = cur; d.filled = filled;
+        d.flush();
+        pos = d.pos; pretw = d.pretw; cur = 0; filled = false;
+    }
+    __device__ __forceinline__ uint32_t next() {
+        if (!filled || cur == (uint32_t)W) {
+            const uint2 r = refill(row, blk, pos, pretw, cur, filled);
+            pos = r.x; pretw = r.y; cur = 0; filled = true;
+        }
+        return mt_temper(row[cur++]);
+    }
+    // Wave-convergent top-up.  Lanes consume at different rates, so with refills only "when empty" every draw site ends
+    // up refilling for SOME lane and the wave executes the ~500-instruction refill at nearly every site (measured on
+    // hospital: 50k VALU per wave-step).  Called at a program point that the lanes reach together, this refills ALL of them
+    // as soon as ANY has fewer than `need` words left, which also re-synchronises their cursors.
+    __device__ __forceinline__ void ensure(uint32_t need) {
+        const bool shortfall = !filled || (uint32_t)W - cur < need;
+        if (__ballot(shortfall) != 0ull) {
+            const uint2 r = refill(row, blk, pos, pretw, cur, filled);
+            pos = r.x; pretw = r.y; cur = 0; filled = true;
+        }
+    }
+    __device__ __forceinline__ uint32_t randbelow(uint32_t n, int kbits) {
+        uint32_t r = next() >> (32 - kbits);
+        while (r >= n) r = next() >> (32 - kbits);
+        return r;
+    }
+    __device__ __forceinline__ double random53() {
+        const uint32_t a = next() >> 5, b = next() >> 6;
+        return (a * 67108864.0 + b) / 9007199254740992.0;
+    }
+};
+
 // Bulk variant for kernels that run FEW waves and are bound by the latency of one lane's serial draw chain
 // (fleet's dense reset kernel): one rolled-loop fill parks W <= 227 twisted words per lane (no word of such a
 // window depends on another), so a whole episode reset normally needs a single, wave-convergent fill per

@@ -38,7 +38,7 @@ constexpr int RING = 3008;
 constexpr int NA = 131, NB = OBS - NA;      // obs chunks: columns [0,131) and [131,243)
 constexpr int TILE = 131;                   // LDS dwords per lane (odd stride)
 constexpr int DW = 16, DROW = 17;
-using Draws = LdsDraws<DW>;
+using Draws = LdsDrawsCall<DW>;
 
 // sub-queues: 0 (E,3) 1 (E,4) 2 (E,5) 3 (ICU,5) 4 (WARD,1) 5 (WARD,2)
 __host__ __device__ constexpr int q_cap(int k) { return k == 0 ? 512 : k == 1 ? 256 : k == 2 ? 64 : k == 3 ? 128 : 1024; }
@@ -469,6 +469,7 @@ __device__ __forceinline__ void wave_step(const Params &p, int64_t i, int64_t i0
     if (run) {
         m.time += 1;
         const uint32_t now = m.time;
+        D.ensure(6);
         // ---- _process_action :371-464 (draws first; effects on DOC / NUR / BED / EQ are applied when those groups are loaded)
         if (a >= 0 && a <= 5) {
             if (m.navail > 0) { nurse_pick = D.randbelow(m.navail, bit_length(m.navail)); reward += 10; }
@@ -489,11 +490,13 @@ __device__ __forceinline__ void wave_step(const Params &p, int64_t i, int64_t i0
         } else if (a == 33) { m.mass = 1; reward -= 100; }
         else if (a == 34) { m.mass = 0; reward += 5; }
         // ---- _generate_patients :466-525
+        D.ensure(4);
         {
             double base = (double)(20u + D.randbelow(16u, 5)) / 60.0;
             if (m.outbreak) base *= 1.5;
             if (m.mass) base *= 2.0;
             if (D.random53() < base) {
+                D.ensure(4);
                 const double roll = D.random53();
                 double cum = 0.0;
                 uint32_t sev = 1;
@@ -503,9 +506,11 @@ __device__ __forceinline__ void wave_step(const Params &p, int64_t i, int64_t i0
                 cum += 0.35; const bool c2 = roll < cum;
                 sev = c5 ? 5u : c4 ? 4u : c3 ? 3u : c2 ? 2u : 1u;                                // the last bucket (MINOR) is also the default
                 (void)D.randbelow(90u, 7);                                                      // age
+                D.ensure(4);
                 if (m.outbreak) { if (!(D.random53() < 0.6)) (void)D.randbelow(15u, 4); }       // disease type
                 else (void)D.randbelow(15u, 4);
                 uint32_t ins = 0;
+                D.ensure(4);
                 if (D.random53() < 0.2) ins = 10u + D.randbelow(21u, 5);
                 const uint32_t tt = treatment_time(sev);
                 if (sev == 5u) q_push<3>(m, rg, now, ins, tt);
@@ -564,6 +569,7 @@ __device__ __forceinline__ void wave_step(const Params &p, int64_t i, int64_t i0
         bd.store(p.state, p.n, i);
         stage_doctors_beds(dc, bd, now, row);
         // ---- _update_queues :607-649
+        D.ensure(4);
         update_queue<0>(m, rg, D, now, reward); update_queue<1>(m, rg, D, now, reward); update_queue<2>(m, rg, D, now, reward);
         const bool term = m.deaths >= 3u || tired == (uint32_t)NDOC;                            // _check_termination :726-742 (utilisation never exceeds 1)
         const bool trunc = m.time >= (uint32_t)p.max_steps;
@@ -627,6 +633,7 @@ __device__ __forceinline__ void wave_step(const Params &p, int64_t i, int64_t i0
             }
 #pragma unroll
             for (int k = 0; k < NEQ; ++k) {
+                D.ensure(4);                                                                // <= 4 words per machine
                 if ((eq.in_use >> k) & 1u) {
                     eq.status[k] = dmax(0.0, eq.status[k] - 0.01);
                     if (D.random53() < 0.001) eq.status[k] = 0.0;
@@ -636,14 +643,17 @@ __device__ __forceinline__ void wave_step(const Params &p, int64_t i, int64_t i0
             }
 #pragma unroll
             for (int k = 0; k < NMED; ++k) {
+                if (k % 2 == 0) D.ensure(4);                                                // ~1.3 words per medicine
                 if (m.treated > 0u) { const uint32_t c = D.randbelow(3u, 2); eq.med[k] = eq.med[k] > c ? eq.med[k] - c : 0u; }
                 row[171 - NA + k] = (float)((double)eq.med[k] / 100.0);
             }
             eq.store(p.state, p.n, i);
         }
         // ---- _check_special_events :688-711
+        D.ensure(4);
         if (!m.outbreak) { if (D.random53() < 0.001) { m.outbreak = 1; (void)D.randbelow(4u, 3); } }
         else if (D.random53() < 0.01) m.outbreak = 0;
+        D.ensure(4);
         if (!m.mass && D.random53() < 0.0005) {
             m.mass = 1;
             const uint32_t cnt = 5u + D.randbelow(6u, 3);
