@@ -418,10 +418,23 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // ------------------------------------------------------------------ obs tile -> HBM
 // Streams `bytes_valid` bytes (multiple of 4) of an LDS tile to `dst` with the widest stores the
-// destination alignment allows.  Must be called by every thread of the block after a barrier.
-template <int BLOCK>
-__device__ __forceinline__ void store_tile(const uint32_t *tile, int8_t *dst, uint32_t bytes_valid) {
-    const uint32_t tid = threadIdx.x;
+// destination alignment allows.  Must be called after a barrier by BLOCK cooperating threads numbered tid = 0..BLOCK-1
+// (the whole workgroup by default; snake's rollout uses a dedicated 64-lane writer wave).
+// FULL = bytes of a complete tile: when the tile is complete and the destination 16-byte aligned (every workgroup but
+// the last of a batch), the copy is a fixed number of (ds_read_b128, global_store_dwordx4) pairs at constant offsets —
+// the generic loops below spend ~20 VALU per 16 bytes on 64-bit address arithmetic.
+template <int BLOCK, int FULL = 0>
+__device__ __forceinline__ void store_tile(const uint32_t *tile, int8_t *dst, uint32_t bytes_valid, uint32_t tid = threadIdx.x) {
+    if (FULL > 0 && bytes_valid == (uint32_t)FULL && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+        constexpr int NVEC = FULL / 16, ITERS = NVEC / BLOCK, TAIL = NVEC % BLOCK;
+        static_assert(FULL % 16 == 0, "whole tiles are a multiple of 16 bytes");
+        const uint4 *t4 = reinterpret_cast<const uint4 *>(tile) + tid;
+        uint4 *d4 = reinterpret_cast<uint4 *>(dst) + tid;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) d4[it * BLOCK] = t4[it * BLOCK];
+        if (TAIL && tid < (uint32_t)TAIL) d4[ITERS * BLOCK] = t4[ITERS * BLOCK];
+        return;
+    }
     if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
         const uint32_t nvec = bytes_valid >> 4;
         const uint4 *t4 = reinterpret_cast<const uint4 *>(tile);

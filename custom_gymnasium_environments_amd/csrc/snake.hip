@@ -251,19 +251,95 @@ struct Params {
     unsigned long long *err_count;
 };
 
+__device__ __forceinline__ uint32_t shfl_u32(uint32_t v, uint32_t src) { return (uint32_t)__shfl((int)v, (int)src, 64); }
+
+// Wave-cooperative _place_food (snake_env.py:121-129).  Under random play ~7 % of the lanes need a new food cell in a
+// step, so virtually every wave has one — and a per-lane placement loop (8 window words: load, twist, temper, reject,
+// occupancy test, commit) made all 64 lanes pay ~650 VALU for the few that needed it.  Here the lanes that need food are
+// served 8 at a time by groups of 8 lanes: lane j of group g draws word j of owner g's MT19937 window, the (row, col)
+// pairing with rejection is resolved with ballots inside the group, the consumed words are committed by the lanes that
+// produced them and one packed word goes back to the owner.  Must be called by all 64 lanes of the wave.
+template <int G>
+__device__ __forceinline__ void wave_place_food(Env<G> &e, uint32_t *blk, bool need) {
+    using L = Lay<G>;
+    const uint32_t lane = threadIdx.x & 63u, g = lane >> 3, j = lane & 7u;
+    const uint32_t plo = (uint32_t)reinterpret_cast<uintptr_t>(blk), phi = (uint32_t)(reinterpret_cast<uintptr_t>(blk) >> 32);
+    uint32_t carry = 0;                                        // owner side: bit 0 = a row is pending, bits 1.. = that row
+    bool pending_me = need;
+    unsigned long long pending = __ballot(pending_me);
+#pragma unroll 1
+    while (pending) {
+        unsigned long long m = pending;
+        uint32_t owner = 64u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {                          // the q-th pending lane owns group q in this pass
+            const uint32_t o = m ? (uint32_t)__ffsll((long long)m) - 1u : 64u;
+            m = m ? (m & (m - 1ull)) : 0ull;
+            owner = g == (uint32_t)q ? o : owner;
+        }
+        const bool active = owner < 64u;
+        const uint32_t src = active ? owner : lane;
+        const uint32_t *oblk = reinterpret_cast<const uint32_t *>(((uint64_t)shfl_u32(phi, src) << 32) | (uint64_t)shfl_u32(plo, src));
+        const uint32_t pos = shfl_u32(e.mt_pos, src), pretw = shfl_u32(e.mt_pretw, src), ocarry = shfl_u32(carry, src);
+        uint32_t occ[L::OCCW];
+#pragma unroll
+        for (int w = 0; w < L::OCCW; ++w) occ[w] = shfl_u32(e.occ[w], src);
+        uint32_t k = pos + j;
+        const bool ready = k < pretw;
+        k -= k >= (uint32_t)MT_N ? MT_N : 0;
+        const uint32_t k1 = k + 1 == (uint32_t)MT_N ? 0 : k + 1;
+        const uint32_t km = k + MT_M >= (uint32_t)MT_N ? k + MT_M - MT_N : k + MT_M;
+        uint32_t a = 0, b = 0, c = 0;
+        if (active) { a = oblk[k]; b = oblk[k1]; c = oblk[km]; }
+        const uint32_t y = ready ? a : mt_twist(a, b, c);
+        const uint32_t r = mt_temper(y) >> (32 - L::KBITS);
+        const bool valid = active && r < (uint32_t)G;
+        const uint32_t vm = (uint32_t)(__ballot(valid) >> (8u * g)) & 0xFFu;
+        const uint32_t below = vm & ((1u << j) - 1u);
+        const uint32_t idx = (uint32_t)__popc(below) + (ocarry & 1u);            // index among the valid draws, a carried row counts
+        const uint32_t prevj = below ? 31u - (uint32_t)__clz((int)below) : 0u;
+        const uint32_t rprev = shfl_u32(r, g * 8u + prevj);
+        const uint32_t row = below ? rprev : (ocarry >> 1);
+        const uint32_t cell = row * (uint32_t)G + r;
+        const bool cand = valid && (idx & 1u) && !((sel(occ, cell >> 5) >> (cell & 31u)) & 1u);
+        const uint32_t cm = (uint32_t)(__ballot(cand) >> (8u * g)) & 0xFFu;
+        const uint32_t jdone = cm ? (uint32_t)__ffs((int)cm) - 1u : 7u;
+        const uint32_t used = cm ? jdone + 1u : 8u;
+        if (active && j < used && pos + j >= pretw) const_cast<uint32_t *>(oblk)[k] = y;   // persist the consumed words
+        const uint32_t wcell = shfl_u32(cell, g * 8u + jdone);
+        // not placed with these 8 words: an unpaired row (odd number of valid draws) carries into the next window
+        const uint32_t nv = (uint32_t)__popc(vm) + (ocarry & 1u);
+        const uint32_t lastv = vm ? 31u - (uint32_t)__clz((int)vm) : 0u;
+        const uint32_t rlast = shfl_u32(r, g * 8u + lastv);
+        const uint32_t ncarry = (nv & 1u) ? (1u | ((vm ? rlast : (ocarry >> 1)) << 1)) : 0u;
+        const uint32_t packed = wcell | (used << 10) | ((cm ? 1u : 0u) << 14) | (ncarry << 15);
+        // owners pick up their group's result
+        const uint32_t og = (uint32_t)__popcll(pending & ((1ull << lane) - 1ull));
+        const uint32_t res = shfl_u32(packed, (og < 8u ? og : 0u) * 8u);
+        if (pending_me && og < 8u) {
+            uint32_t np = e.mt_pos + ((res >> 10) & 15u);
+            if (np >= (uint32_t)MT_N) { np -= MT_N; e.mt_pretw = 0; }
+            e.mt_pos = np;
+            if ((res >> 14) & 1u) { e.food = res & 1023u; pending_me = false; }
+            else carry = res >> 15;
+        }
+        pending = __ballot(pending_me);
+    }
+    if (need) e.flags |= F_FOOD_VALID;
+}
+
 // One env transition with fused auto-reset.  Everything except the food draw happens first; the RNG
 // window load is issued, the obs body is staged while it is in flight, then the food is placed.
 template <int G, int FW = FOOD_WINDOW>
-__device__ __forceinline__ void transition(Env<G> &e, const Params &p, int64_t i, uint32_t action, bool valid_action,
-                                           uint32_t *__restrict__ obs_row, float &reward, bool &term) {
+__device__ __forceinline__ uint32_t transition(Env<G> &e, const Params &p, int64_t i, uint32_t action, bool valid_action,
+                                               uint32_t *__restrict__ obs_row, float &reward, bool &term) {
     using L = Lay<G>;
-    uint32_t *__restrict__ blk = p.mt + i * MT_STRIDE;
-    bool need_food = false;
+    bool need_food = false, was_reset = false;
     reward = 0.0f;
     term = false;
     if (p.mode == CGE_AUTORESET_NEXT_STEP && (e.flags & F_NEEDS_RESET)) {
         e.reset_body();
-        need_food = true;
+        need_food = true; was_reset = true;
     } else if (!valid_action) {
         atomicAdd(p.err_count, 1ull);   // reference: ValueError (snake_env.py:69-70)
     } else {
@@ -277,18 +353,15 @@ __device__ __forceinline__ void transition(Env<G> &e, const Params &p, int64_t i
                     e.write_obs_food(frow);
                 }
                 e.reset_body();
-                need_food = true;
+                need_food = true; was_reset = true;
             } else if (p.mode == CGE_AUTORESET_NEXT_STEP) {
                 e.flags |= F_NEEDS_RESET;
             }
         }
     }
     if (need_food) need_food = e.can_place_food();
-    MtWindow<FW> win;
-    if (need_food) win.load(blk, e.mt_pos);
     if (obs_row) e.write_obs_body(obs_row);
-    if (need_food) e.place_food(blk, win);
-    if (obs_row) e.write_obs_food(obs_row);
+    return (need_food ? 1u : 0u) | (was_reset ? 2u : 0u);      // the caller runs wave_place_food with the whole wave, then write_obs_food
 }
 
 template <int G, int BLOCK, int MINW, int FW>
@@ -298,13 +371,20 @@ __global__ __launch_bounds__(BLOCK, MINW) void step_kernel(Params p) {
     uint32_t *tile = reinterpret_cast<uint32_t *>(tile4);
     const int64_t first = (int64_t)blockIdx.x * BLOCK;
     const int64_t i = first + threadIdx.x;
-    if (i < p.n) {
-        Env<G> e;
-        e.load(p.state, p.n, i);
+    const bool live_lane = i < p.n;
+    const int64_t li = live_lane ? i : first;
+    Env<G> e;
+    e.load(p.state, p.n, li);
+    float r = 0.0f;
+    bool term = false, need_food = false;
+    uint32_t *row = tile + threadIdx.x * L::OBS_DW;
+    if (live_lane) {
         const int32_t a = p.actions[i];
-        float r;
-        bool term;
-        transition<G, FW>(e, p, i, (uint32_t)a, (uint32_t)a <= 3u, tile + threadIdx.x * L::OBS_DW, r, term);
+        need_food = transition<G, FW>(e, p, i, (uint32_t)a, (uint32_t)a <= 3u, row, r, term) & 1u;
+    }
+    wave_place_food<G>(e, p.mt + li * MT_STRIDE, need_food);
+    if (live_lane) {
+        e.write_obs_food(row);
         e.store(p.state, p.n, i);
         p.reward[i] = r;
         p.terminated[i] = term ? 1 : 0;
@@ -312,19 +392,35 @@ __global__ __launch_bounds__(BLOCK, MINW) void step_kernel(Params p) {
     }
     lds_barrier();
     const int64_t live = p.n - first < BLOCK ? p.n - first : BLOCK;
-    store_tile<BLOCK>(tile, p.obs + first * L::CELLS, (uint32_t)(live * L::CELLS));
+    store_tile<BLOCK, BLOCK * L::CELLS>(tile, p.obs + first * L::CELLS, (uint32_t)(live * L::CELLS));
 }
 
-// k fused steps per launch: state stays in VGPRs, only obs (+ optional explicit actions) touch HBM per step
+// k fused steps per launch: state stays in VGPRs, only obs (+ optional explicit actions) touch HBM per step.
+// The workgroup is BLOCK compute lanes plus one 64-lane WRITER wave that does nothing but stream the obs tile to HBM.
+// On gfx950 loads and stores share one in-order counter (vmcnt): when the compute waves issued the obs stores
+// themselves, their next food-placement loads had to wait for those stores to retire, so output and compute never
+// overlapped (12 us of compute + 13 us of stores per 1M-env step).  With the stores on their own wave the compute waves
+// only wait for their own loads; two LDS-only barriers per step hand the tile back and forth:
+//   B1(t) rows hold obs(t) -> writer reads them | compute does transition(t+1) in registers | B2(t) rows may change.
 template <int G, int BLOCK, int MINW, int FW>
-__global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
+__global__ __launch_bounds__(BLOCK + 64, MINW) void rollout_kernel(Params p) {
     using L = Lay<G>;
     __shared__ uint4 tile4[BLOCK * L::OBS_DW / 4];
     uint32_t *tile = reinterpret_cast<uint32_t *>(tile4);
     const int64_t first = (int64_t)blockIdx.x * BLOCK;
+    const int64_t live = p.n - first < BLOCK ? p.n - first : BLOCK;
+    if (threadIdx.x >= (unsigned)BLOCK) {                      // ---- writer wave
+        if (!p.obs) return;
+        const uint32_t w = threadIdx.x - BLOCK;
+        for (int t = 0; t < p.k_steps; ++t) {
+            lds_barrier();                                     // B1(t)
+            store_tile<64, BLOCK * L::CELLS>(tile, p.obs + (int64_t)t * p.obs_step_stride + first * L::CELLS, (uint32_t)(live * L::CELLS), w);
+            lds_barrier();                                     // B2(t): LDS reads done (lgkmcnt), the stores drain on their own
+        }
+        return;
+    }
     const int64_t i = first + threadIdx.x;
     const bool live_lane = i < p.n;
-    const int64_t live = p.n - first < BLOCK ? p.n - first : BLOCK;
     Env<G> e;
     uint64_t key = 0;
     float rsum = 0.0f;
@@ -333,10 +429,22 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
         e.load(p.state, p.n, i);
         key = hash_env_key(p.a_seed, (uint64_t)(p.env0 + i));
     }
+    // The lane's obs row lives in LDS for the whole rollout and is kept up to date INCREMENTALLY: a move sets the new head
+    // byte and clears the vacated tail byte, a new food sets one byte; only an episode reset rewrites the row, and that is
+    // done by the wave together (25 lanes clear the row of each resetting env) — rebuilding 25 dwords per lane per step
+    // cost every wave ~175 VALU for the ~7 % of lanes that had actually changed more than two cells.
     uint32_t *row = p.obs ? tile + threadIdx.x * L::OBS_DW : nullptr;
+    int8_t *rowb = reinterpret_cast<int8_t *>(row);
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t *wave_rows = tile + (threadIdx.x & ~63u) * L::OBS_DW;
+    if (row && live_lane) { e.write_obs_body(row); e.write_obs_food(row); }
     // explicit actions are fetched one step ahead so the load's latency hides behind the previous step
     uint32_t a_next = (live_lane && p.actions && p.k_steps > 0) ? (uint32_t)p.actions[i] : 0u;
+    uint32_t *blk = p.mt + (live_lane ? i : first) * MT_STRIDE;
     for (int t = 0; t < p.k_steps; ++t) {
+        float r = 0.0f;
+        bool term = false, need_food = false, was_reset = false;
+        const uint32_t old_head = e.head, old_tail = e.tail;
         if (live_lane) {
             uint32_t a;
             if (p.actions) {
@@ -345,20 +453,34 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
             } else {
                 a = hash_action_from_key(key, (uint64_t)(p.t0 + t), 4u, 0u);
             }
-            float r;
-            bool term;
-            transition<G, FW>(e, p, i, a, a <= 3u, row, r, term);
+            const uint32_t f = transition<G, FW>(e, p, i, a, a <= 3u, nullptr, r, term);
+            need_food = f & 1u; was_reset = f & 2u;
+        }
+        wave_place_food<G>(e, blk, need_food);
+        if (row) {
+            if (t > 0) lds_barrier();                          // B2(t-1): the writer has read obs(t-1)
+            unsigned long long rm = __ballot(was_reset);
+            while (rm) {                                       // wave-uniform: clear the rows of the envs that were reset
+                const uint32_t rl = (uint32_t)__ffsll((long long)rm) - 1u;
+                rm &= rm - 1ull;
+                if (lane < (uint32_t)L::OBS_DW) wave_rows[rl * L::OBS_DW + lane] = 0u;
+                if (L::OBS_DW > 64) for (uint32_t q = lane + 64u; q < (uint32_t)L::OBS_DW; q += 64u) wave_rows[rl * L::OBS_DW + q] = 0u;
+            }
+            if (live_lane) {
+                if (was_reset) rowb[e.head] = 1;
+                else if (e.head != old_head) { rowb[e.head] = 1; if (e.tail != old_tail) rowb[old_tail] = 0; }
+                if (need_food) e.write_obs_food(row);
+            }
+            lds_barrier();                                     // B1(t): rows hold obs(t)
+        }
+        if (live_lane) {
             rsum += r;
             dcount += term ? 1 : 0;
             if (p.reward) p.reward[(int64_t)t * p.n + i] = r;                   // optional [k, n] trajectories
             if (p.terminated) p.terminated[(int64_t)t * p.n + i] = term ? 1 : 0;
         }
-        if (p.obs) {
-            lds_barrier();
-            store_tile<BLOCK>(tile, p.obs + (int64_t)t * p.obs_step_stride + first * L::CELLS, (uint32_t)(live * L::CELLS));
-            lds_barrier();
-        }
     }
+    if (row && p.k_steps > 0) lds_barrier();                   // B2(k-1), pairs with the writer's last barrier
     if (live_lane) {
         e.store(p.state, p.n, i);
         if (p.reward_sum) p.reward_sum[i] = rsum;
@@ -504,7 +626,7 @@ void set_variant(Ops &o) {
         hipLaunchKernelGGL((step_kernel<G, BLOCK, MINW, FW>), dim3((unsigned)((p.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, p);
     };
     o.rollout = [](const Params &p, hipStream_t s) {
-        hipLaunchKernelGGL((rollout_kernel<G, BLOCK, MINW, FW>), dim3((unsigned)((p.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, p);
+        hipLaunchKernelGGL((rollout_kernel<G, BLOCK, MINW, FW>), dim3((unsigned)((p.n + BLOCK - 1) / BLOCK)), dim3(BLOCK + 64), 0, s, p);
     };
 }
 
