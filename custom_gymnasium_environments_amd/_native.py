@@ -110,6 +110,9 @@ SIGNATURES = {
     "cge_parking_rollout": (C.c_int, [_vp, _i32, _vp, _u64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "cge_parking_info": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "cge_parking_info64": (C.c_int, [_vp, _i32, _vp, _vp]),
+    "cge_parking_snapshot_bytes": (_sz, [_vp]),
+    "cge_parking_snapshot_get": (C.c_int, [_vp, _vp, _vp]),
+    "cge_parking_snapshot_set": (C.c_int, [_vp, _vp, _vp]),
     "cge_parking_device_bytes": (_sz, [_vp]),
     "cge_parking_last_error": (C.c_char_p, [_vp]),
     "cge_climate_create": (C.c_int, [C.POINTER(ClimateConfig), _i64, C.c_int, _i64, C.POINTER(_vp)]),
@@ -119,6 +122,9 @@ SIGNATURES = {
     "cge_climate_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cge_climate_rollout": (C.c_int, [_vp, _i32, _vp, _vp, _u64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "cge_climate_info": (C.c_int, [_vp, _i32, _vp, _vp]),
+    "cge_climate_snapshot_bytes": (_sz, [_vp]),
+    "cge_climate_snapshot_get": (C.c_int, [_vp, _vp, _vp]),
+    "cge_climate_snapshot_set": (C.c_int, [_vp, _vp, _vp]),
     "cge_climate_device_bytes": (_sz, [_vp]),
     "cge_climate_last_error": (C.c_char_p, [_vp]),
     "cge_fleet_create": (C.c_int, [C.POINTER(FleetConfig), _i64, C.c_int, _i64, C.POINTER(_vp)]),
@@ -128,6 +134,9 @@ SIGNATURES = {
     "cge_fleet_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cge_fleet_rollout": (C.c_int, [_vp, _i32, _vp, _u64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "cge_fleet_info": (C.c_int, [_vp, _i32, _vp, _vp]),
+    "cge_fleet_snapshot_bytes": (_sz, [_vp]),
+    "cge_fleet_snapshot_get": (C.c_int, [_vp, _vp, _vp]),
+    "cge_fleet_snapshot_set": (C.c_int, [_vp, _vp, _vp]),
     "cge_fleet_device_bytes": (_sz, [_vp]),
     "cge_fleet_last_error": (C.c_char_p, [_vp]),
     "cge_manufacturing_create": (C.c_int, [C.POINTER(ManufacturingConfig), _i64, C.c_int, _i64, C.POINTER(_vp)]),
@@ -137,6 +146,9 @@ SIGNATURES = {
     "cge_manufacturing_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cge_manufacturing_rollout": (C.c_int, [_vp, _i32, _vp, _u64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "cge_manufacturing_info": (C.c_int, [_vp, _i32, _vp, _vp]),
+    "cge_manufacturing_snapshot_bytes": (_sz, [_vp]),
+    "cge_manufacturing_snapshot_get": (C.c_int, [_vp, _vp, _vp]),
+    "cge_manufacturing_snapshot_set": (C.c_int, [_vp, _vp, _vp]),
     "cge_manufacturing_device_bytes": (_sz, [_vp]),
     "cge_manufacturing_last_error": (C.c_char_p, [_vp]),
     "cge_hospital_create": (C.c_int, [C.POINTER(HospitalConfig), _i64, C.c_int, _i64, C.POINTER(_vp)]),
@@ -146,6 +158,9 @@ SIGNATURES = {
     "cge_hospital_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cge_hospital_rollout": (C.c_int, [_vp, _i32, _vp, _u64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "cge_hospital_info": (C.c_int, [_vp, _i32, _vp, _vp]),
+    "cge_hospital_snapshot_bytes": (_sz, [_vp]),
+    "cge_hospital_snapshot_get": (C.c_int, [_vp, _vp, _vp]),
+    "cge_hospital_snapshot_set": (C.c_int, [_vp, _vp, _vp]),
     "cge_hospital_device_bytes": (_sz, [_vp]),
     "cge_hospital_last_error": (C.c_char_p, [_vp]),
 }

@@ -173,6 +173,13 @@ struct LdsDraws {
         else if (cur == (uint32_t)W) { flush(); fill(); }
         return mt_temper(row[cur++]);
     }
+    // Wave-convergent top-up: refill ALL active lanes as soon as ANY of them has fewer than `need` words left.  Without
+    // it the lanes' cursors drift apart and every draw site ends up refilling (a ~500-instruction path plus a memory round
+    // trip) for some lane; one call at the top of a step bounds that to one refill per wave-step.
+    __device__ __forceinline__ void ensure(uint32_t need) {
+        const bool shortfall = !filled || (uint32_t)W - cur < need;
+        if (__ballot(shortfall) != 0ull) { flush(); fill(); }
+    }
     __device__ __forceinline__ uint32_t randbelow(uint32_t n, int kbits) {   // CPython _randbelow_with_getrandbits
         uint32_t r = next() >> (32 - kbits);
         while (r >= n) r = next() >> (32 - kbits);

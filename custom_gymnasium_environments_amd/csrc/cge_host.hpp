@@ -5,6 +5,9 @@
 
 #include <cstdio>
 #include <string>
+#include <utility>
+#include <vector>
+#include <cstring>
 
 #include "../../include/cge_amd.h"
 
@@ -49,6 +52,42 @@ struct DeviceGuard {
     } while (0)
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Whole-handle snapshots (checkpoint / resume) for the env types without a canonical per-env record: a 32-byte header
+// {magic, n_envs, env tag, extra} followed by the handle's device arrays in their device layout.  Only valid for a handle
+// created with the same n_envs and config.  H provides blobs() -> vector<pair<void*, size_t>>, snap_tag, snap_extra().
+struct SnapHeader { uint64_t magic; int64_t n; uint32_t tag, extra; uint64_t reserved; };
+constexpr uint64_t SNAP_MAGIC = 0x3150414e53454743ull;   // "CGESNAP1"
+template <class H>
+size_t snapshot_bytes(const H *h) {
+    size_t t = sizeof(SnapHeader);
+    for (const auto &b : h->blobs()) t += b.second;
+    return t;
+}
+template <class H>
+int snapshot_get(H *h, void *host, hipStream_t s) {
+    if (!h || !host) return CGE_ERR_INVALID_ARG;
+    DeviceGuard g(h->device);
+    CGE_TRY(h, hipStreamSynchronize(s));
+    SnapHeader hd{SNAP_MAGIC, h->n, H::snap_tag, h->snap_extra(), 0};
+    memcpy(host, &hd, sizeof hd);
+    char *dst = static_cast<char *>(host) + sizeof hd;
+    for (const auto &b : h->blobs()) { CGE_TRY(h, hipMemcpy(dst, b.first, b.second, hipMemcpyDeviceToHost)); dst += b.second; }
+    return CGE_OK;
+}
+template <class H>
+int snapshot_set(H *h, const void *host, hipStream_t s) {
+    if (!h || !host) return CGE_ERR_INVALID_ARG;
+    DeviceGuard g(h->device);
+    SnapHeader hd;
+    memcpy(&hd, host, sizeof hd);
+    if (hd.magic != SNAP_MAGIC || hd.n != h->n || hd.tag != H::snap_tag) return h->fail(CGE_ERR_INVALID_ARG, "snapshot_set: not a snapshot of this env type / batch size");
+    CGE_TRY(h, hipStreamSynchronize(s));
+    const char *src = static_cast<const char *>(host) + sizeof hd;
+    for (const auto &b : h->blobs()) { CGE_TRY(h, hipMemcpy(b.first, src, b.second, hipMemcpyHostToDevice)); src += b.second; }
+    h->set_snap_extra(hd.extra);
+    return CGE_OK;
+}
 
 // Seeds n MT19937 stream blocks (cge_device.hpp layout, `stride_words` apart starting at `mt`).
 //   kind 0: CPython random.seed(s)  = init_by_array(32-bit limbs of s)

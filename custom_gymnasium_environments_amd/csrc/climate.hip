@@ -256,6 +256,10 @@ using namespace cge;
 struct cge_climate : HandleBase {
     cge_climate_config cfg{};
     uint4 *state = nullptr;
+    static constexpr uint32_t snap_tag = 2u;
+    std::vector<std::pair<void *, size_t>> blobs() const { return {{state, (size_t)climate::COLS * n * sizeof(uint4)}}; }
+    uint32_t snap_extra() const { return 0u; }
+    void set_snap_extra(uint32_t v) { (void)v; }
     climate::Params params() const {
         climate::Params p{};
         p.state = state; p.n = n; p.env0 = env0; p.mode = cfg.autoreset_mode; p.max_occ = cfg.max_occupancy; p.max_steps = cfg.episode_minutes;
@@ -368,6 +372,9 @@ int cge_climate_info(cge_climate *h, int32_t field_id, double *out, void *stream
     return CGE_OK;
 }
 
+size_t cge_climate_snapshot_bytes(const cge_climate *h) { return h ? snapshot_bytes(h) : 0; }
+int cge_climate_snapshot_get(cge_climate *h, void *host_buf, void *stream) { return snapshot_get(h, host_buf, as_stream(stream)); }
+int cge_climate_snapshot_set(cge_climate *h, const void *host_buf, void *stream) { return snapshot_set(h, host_buf, as_stream(stream)); }
 size_t cge_climate_device_bytes(const cge_climate *h) { return h ? h->device_bytes : 0; }
 const char *cge_climate_last_error(const cge_climate *h) { return h ? h->last_error.c_str() : "null handle"; }
 

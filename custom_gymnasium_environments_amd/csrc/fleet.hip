@@ -504,6 +504,10 @@ struct cge_fleet : HandleBase {
     uint32_t *work_count = nullptr;
     uint64_t *work_list = nullptr;
     int parity = 0;
+    static constexpr uint32_t snap_tag = 3u;
+    std::vector<std::pair<void *, size_t>> blobs() const { return {{state, (size_t)fleet::COLS * n * sizeof(uint4)}, {mtP, (size_t)n * MT_STRIDE * 4}, {mtL, (size_t)n * MT_STRIDE * 4}, {work_count, 2 * sizeof(uint32_t)}}; }
+    uint32_t snap_extra() const { return (uint32_t)parity; }
+    void set_snap_extra(uint32_t v) { parity = (int)(v & 1u); (void)v; }
     fleet::Params params() const {
         fleet::Params p{};
         p.state = state; p.mtP = mtP; p.mtL = mtL; p.n = n; p.env0 = env0; p.mode = cfg.autoreset_mode; p.max_steps = cfg.max_timesteps;
@@ -641,6 +645,9 @@ int cge_fleet_info(cge_fleet *h, int32_t field_id, double *out, void *stream) {
     return CGE_OK;
 }
 
+size_t cge_fleet_snapshot_bytes(const cge_fleet *h) { return h ? snapshot_bytes(h) : 0; }
+int cge_fleet_snapshot_get(cge_fleet *h, void *host_buf, void *stream) { return snapshot_get(h, host_buf, as_stream(stream)); }
+int cge_fleet_snapshot_set(cge_fleet *h, const void *host_buf, void *stream) { return snapshot_set(h, host_buf, as_stream(stream)); }
 size_t cge_fleet_device_bytes(const cge_fleet *h) { return h ? h->device_bytes : 0; }
 const char *cge_fleet_last_error(const cge_fleet *h) { return h ? h->last_error.c_str() : "null handle"; }
 

@@ -903,6 +903,10 @@ struct cge_hospital : HandleBase {
     uint4 *state = nullptr;
     uint32_t *mt = nullptr, *ring = nullptr;
     uint8_t *ringtt = nullptr;
+    static constexpr uint32_t snap_tag = 5u;
+    std::vector<std::pair<void *, size_t>> blobs() const { return {{state, (size_t)hosp::COLS * n * sizeof(uint4)}, {mt, (size_t)n * MT_STRIDE * 4}, {ring, (size_t)n * hosp::RING * 4}, {ringtt, (size_t)n * hosp::RING}}; }
+    uint32_t snap_extra() const { return 0u; }
+    void set_snap_extra(uint32_t v) { (void)v; }
     hosp::Params params() const {
         hosp::Params p{};
         p.state = state; p.mt = mt; p.ring = ring; p.ringtt = ringtt; p.n = n; p.env0 = env0; p.mode = cfg.autoreset_mode; p.max_steps = cfg.max_episode_length;
@@ -1018,6 +1022,9 @@ int cge_hospital_info(cge_hospital *h, int32_t field_id, double *out, void *stre
     return CGE_OK;
 }
 
+size_t cge_hospital_snapshot_bytes(const cge_hospital *h) { return h ? snapshot_bytes(h) : 0; }
+int cge_hospital_snapshot_get(cge_hospital *h, void *host_buf, void *stream) { return snapshot_get(h, host_buf, as_stream(stream)); }
+int cge_hospital_snapshot_set(cge_hospital *h, const void *host_buf, void *stream) { return snapshot_set(h, host_buf, as_stream(stream)); }
 size_t cge_hospital_device_bytes(const cge_hospital *h) { return h ? h->device_bytes : 0; }
 const char *cge_hospital_last_error(const cge_hospital *h) { return h ? h->last_error.c_str() : "null handle"; }
 

@@ -708,6 +708,10 @@ struct cge_manufacturing : HandleBase {
     uint4 *state = nullptr;
     double *pq = nullptr, *comp = nullptr, *hist = nullptr;
     uint16_t *pm = nullptr, *pnext = nullptr;
+    static constexpr uint32_t snap_tag = 4u;
+    std::vector<std::pair<void *, size_t>> blobs() const { return {{state, (size_t)mfg::COLS * n * sizeof(uint4)}, {pq, (size_t)mfg::CAP * n * 8}, {pm, (size_t)mfg::CAP * n * 2}, {pnext, (size_t)mfg::CAP * n * 2}, {comp, (size_t)20 * n * 8}, {hist, (size_t)100 * n * 8}}; }
+    uint32_t snap_extra() const { return 0u; }
+    void set_snap_extra(uint32_t v) { (void)v; }
     mfg::Params params() const {
         mfg::Params p{};
         p.state = state; p.pq = pq; p.pm = pm; p.pnext = pnext; p.comp = comp; p.hist = hist;
@@ -822,6 +826,9 @@ int cge_manufacturing_info(cge_manufacturing *h, int32_t field_id, double *out, 
     return CGE_OK;
 }
 
+size_t cge_manufacturing_snapshot_bytes(const cge_manufacturing *h) { return h ? snapshot_bytes(h) : 0; }
+int cge_manufacturing_snapshot_get(cge_manufacturing *h, void *host_buf, void *stream) { return snapshot_get(h, host_buf, as_stream(stream)); }
+int cge_manufacturing_snapshot_set(cge_manufacturing *h, const void *host_buf, void *stream) { return snapshot_set(h, host_buf, as_stream(stream)); }
 size_t cge_manufacturing_device_bytes(const cge_manufacturing *h) { return h ? h->device_bytes : 0; }
 const char *cge_manufacturing_last_error(const cge_manufacturing *h) { return h ? h->last_error.c_str() : "null handle"; }
 

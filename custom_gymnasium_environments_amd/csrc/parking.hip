@@ -179,6 +179,7 @@ __device__ __forceinline__ uint32_t generate_customer(uint32_t hour, LdsDraws<DW
 
 __device__ __forceinline__ bool env_step(Env &e, int32_t max_steps, int32_t a, LdsDraws<DW> &d, double &reward) {   // :110-159
     if (e.t > 0 && e.t % 60u == 0) e.changes = 0;
+    d.ensure(10);                                          // wave-convergent top-up (see LdsDraws::ensure)
     const uint32_t hour = e.t / 60u;
     static constexpr int RATE[24] = {3, 2, 2, 2, 2, 4, 8, 12, 15, 10, 8, 8, 12, 12, 8, 8, 10, 15, 18, 15, 12, 8, 6, 4};   // config.py:19-47
     double prob = 0.05;
@@ -425,6 +426,10 @@ struct cge_parking : HandleBase {
     cge_parking_config cfg{};
     uint4 *state = nullptr;
     uint32_t *mt = nullptr;
+    static constexpr uint32_t snap_tag = 1u;
+    std::vector<std::pair<void *, size_t>> blobs() const { return {{state, (size_t)parking::COLS * n * sizeof(uint4)}, {mt, (size_t)n * MT_STRIDE * 4}}; }
+    uint32_t snap_extra() const { return 0u; }
+    void set_snap_extra(uint32_t v) { (void)v; }
     parking::Params params() const {
         parking::Params p{};
         p.state = state; p.mt = mt; p.n = n; p.env0 = env0; p.mode = cfg.autoreset_mode; p.max_steps = cfg.max_steps;
@@ -549,6 +554,9 @@ int cge_parking_info64(cge_parking *h, int32_t field_id, double *out, void *stre
     return CGE_OK;
 }
 
+size_t cge_parking_snapshot_bytes(const cge_parking *h) { return h ? snapshot_bytes(h) : 0; }
+int cge_parking_snapshot_get(cge_parking *h, void *host_buf, void *stream) { return snapshot_get(h, host_buf, as_stream(stream)); }
+int cge_parking_snapshot_set(cge_parking *h, const void *host_buf, void *stream) { return snapshot_set(h, host_buf, as_stream(stream)); }
 size_t cge_parking_device_bytes(const cge_parking *h) { return h ? h->device_bytes : 0; }
 const char *cge_parking_last_error(const cge_parking *h) { return h ? h->last_error.c_str() : "null handle"; }
 

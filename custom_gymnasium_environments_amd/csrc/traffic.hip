@@ -169,6 +169,7 @@ __device__ __forceinline__ void spawn(Env &e, const Cfg &c, LdsDraws<DW> &d) {
 // one reference step() (:168-203); returns terminated, reward in float64
 __device__ __forceinline__ bool env_step(Env &e, const Cfg &c, const uint32_t (&a)[NI], LdsDraws<DW> &d, double &reward) {
     e.timestep += 1;
+    d.ensure(12);                                                                      // typical step: 1-2 light timers + a spawn with 1-4 hops
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         uint32_t phase = e.light[i] & 3u, timer = e.light[i] >> 2;

@@ -115,6 +115,23 @@ class DeviceVectorEnv(VectorEnvBase):
     def device_bytes(self):
         return int(self._fn("device_bytes")(self._h))
 
+    def snapshot(self):
+        """Whole-batch checkpoint as an opaque uint8 array (env types without a canonical per-env `get_state` record).
+        Restores only into an env created with the same num_envs and config; synchronises the stream."""
+        if not hasattr(self._lib, f"{self._abi}_snapshot_bytes"):
+            raise NotImplementedError(f"{self._abi}: use get_state()/set_state()")
+        import numpy as np
+        buf = np.zeros(int(self._fn("snapshot_bytes")(self._h)), np.uint8)
+        self._check(self._fn("snapshot_get")(self._h, buf.ctypes.data, self._stream()), "snapshot_get")
+        return buf
+
+    def restore(self, buf):
+        import numpy as np
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        if buf.shape != (int(self._fn("snapshot_bytes")(self._h)),):
+            raise ValueError("not a snapshot of an env of this type and size")
+        self._check(self._fn("snapshot_set")(self._h, buf.ctypes.data, self._stream()), "snapshot_set")
+
     def close_extras(self, **kwargs):
         if getattr(self, "_h", None):
             self._fn("destroy")(self._h)

@@ -298,6 +298,11 @@ int cge_parking_rollout(cge_parking *h, int32_t k_steps, const int32_t *actions,
                         void *stream);
 int cge_parking_info(cge_parking *h, int32_t field_id, int32_t index, int32_t *out, void *stream);
 int cge_parking_info64(cge_parking *h, int32_t field_id, double *out, void *stream);
+/* whole-handle checkpoint (host memory, opaque: 32-byte header + the device arrays in device layout); restores only
+ * into a handle created with the same n_envs and config; both calls synchronise `stream` */
+size_t cge_parking_snapshot_bytes(const cge_parking *h);
+int cge_parking_snapshot_get(cge_parking *h, void *host_buf, void *stream);
+int cge_parking_snapshot_set(cge_parking *h, const void *host_buf, void *stream);
 size_t cge_parking_device_bytes(const cge_parking *h);
 const char *cge_parking_last_error(const cge_parking *h);
 
@@ -341,6 +346,11 @@ int cge_climate_rollout(cge_climate *h, int32_t k_steps, const float *ac_temp, c
                         float *reward_traj_out, uint8_t *terminated_traj_out, double *reward_sum_out,
                         int32_t *done_count_out, void *stream);
 int cge_climate_info(cge_climate *h, int32_t field_id, double *out, void *stream);
+/* whole-handle checkpoint (host memory, opaque: 32-byte header + the device arrays in device layout); restores only
+ * into a handle created with the same n_envs and config; both calls synchronise `stream` */
+size_t cge_climate_snapshot_bytes(const cge_climate *h);
+int cge_climate_snapshot_get(cge_climate *h, void *host_buf, void *stream);
+int cge_climate_snapshot_set(cge_climate *h, const void *host_buf, void *stream);
 size_t cge_climate_device_bytes(const cge_climate *h);
 const char *cge_climate_last_error(const cge_climate *h);
 
@@ -377,6 +387,11 @@ int cge_fleet_rollout(cge_fleet *h, int32_t k_steps, const int32_t *actions, uin
                       float *obs_out, int64_t obs_step_stride, float *reward_traj_out, uint8_t *terminated_traj_out,
                       double *reward_sum_out, int32_t *done_count_out, void *stream);
 int cge_fleet_info(cge_fleet *h, int32_t field_id, double *out, void *stream);
+/* whole-handle checkpoint (host memory, opaque: 32-byte header + the device arrays in device layout); restores only
+ * into a handle created with the same n_envs and config; both calls synchronise `stream` */
+size_t cge_fleet_snapshot_bytes(const cge_fleet *h);
+int cge_fleet_snapshot_get(cge_fleet *h, void *host_buf, void *stream);
+int cge_fleet_snapshot_set(cge_fleet *h, const void *host_buf, void *stream);
 size_t cge_fleet_device_bytes(const cge_fleet *h);
 const char *cge_fleet_last_error(const cge_fleet *h);
 
@@ -414,6 +429,11 @@ int cge_manufacturing_rollout(cge_manufacturing *h, int32_t k_steps, const int32
                               float *obs_out, int64_t obs_step_stride, float *reward_traj_out, uint8_t *terminated_traj_out,
                               double *reward_sum_out, int32_t *done_count_out, void *stream);
 int cge_manufacturing_info(cge_manufacturing *h, int32_t field_id, double *out, void *stream);
+/* whole-handle checkpoint (host memory, opaque: 32-byte header + the device arrays in device layout); restores only
+ * into a handle created with the same n_envs and config; both calls synchronise `stream` */
+size_t cge_manufacturing_snapshot_bytes(const cge_manufacturing *h);
+int cge_manufacturing_snapshot_get(cge_manufacturing *h, void *host_buf, void *stream);
+int cge_manufacturing_snapshot_set(cge_manufacturing *h, const void *host_buf, void *stream);
 size_t cge_manufacturing_device_bytes(const cge_manufacturing *h);
 const char *cge_manufacturing_last_error(const cge_manufacturing *h);
 
@@ -452,6 +472,11 @@ int cge_hospital_rollout(cge_hospital *h, int32_t k_steps, const int32_t *action
                          float *obs_out, int64_t obs_step_stride, float *reward_traj_out, uint8_t *terminated_traj_out,
                          double *reward_sum_out, int32_t *done_count_out, void *stream);
 int cge_hospital_info(cge_hospital *h, int32_t field_id, double *out, void *stream);
+/* whole-handle checkpoint (host memory, opaque: 32-byte header + the device arrays in device layout); restores only
+ * into a handle created with the same n_envs and config; both calls synchronise `stream` */
+size_t cge_hospital_snapshot_bytes(const cge_hospital *h);
+int cge_hospital_snapshot_get(cge_hospital *h, void *host_buf, void *stream);
+int cge_hospital_snapshot_set(cge_hospital *h, const void *host_buf, void *stream);
 size_t cge_hospital_device_bytes(const cge_hospital *h);
 const char *cge_hospital_last_error(const cge_hospital *h);
 
