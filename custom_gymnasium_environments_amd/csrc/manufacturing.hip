@@ -478,20 +478,31 @@ __device__ __forceinline__ void type_means(Env &e, const Tab &tb, bool live, dou
     const uint32_t smin = wave_min(live ? e.lo : (uint32_t)CAP), smax = wave_max(live ? e.nprod : 0u);
     uint64_t jc = 0;
     uint32_t first_alive = e.nprod;
-#pragma unroll 2
-    for (uint32_t s = smin; s < smax; ++s) {
-        const bool in = live && s >= e.lo && s < e.nprod;
-        const uint32_t m = in ? tb.pm[(int64_t)s * tb.n] : 0u;
-        const double q = in ? tb.pq[(int64_t)s * tb.n] : 0.0;
-        if (in && (m & M_ALIVE)) {
-            first_alive = s < first_alive ? s : first_alive;
-            const uint32_t t = m & 7u, nt = fld9(e.nT, t), j = fld9(jc, t);
-            jc += 1ull << (9u * t);
-            if (nt <= 128u) {
-                const uint32_t nfull = nt & ~7u;
-                double *a = acc_lane + t * 9u;
-                if (j < nfull) { if (j < 8u) a[j] = q; else a[j & 7u] += q; }
-                else { const double res = j == nfull ? (nfull ? combine8(a) : 0.0) : a[8]; a[8] = res + q; }
+    // 8 slots per round trip: the loads are unconditional (every slot row exists) and issued before the first use
+#pragma unroll 1
+    for (uint32_t s0 = smin; s0 < smax; s0 += 8u) {
+        uint32_t mm[8];
+        double qq[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t sl = s0 + u < (uint32_t)CAP ? s0 + u : (uint32_t)CAP - 1u;
+            mm[u] = tb.pm[(int64_t)sl * tb.n];
+            qq[u] = tb.pq[(int64_t)sl * tb.n];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t s = s0 + u, m = mm[u];
+            const double q = qq[u];
+            if (live && s >= e.lo && s < e.nprod && (m & M_ALIVE)) {
+                first_alive = s < first_alive ? s : first_alive;
+                const uint32_t t = m & 7u, nt = fld9(e.nT, t), j = fld9(jc, t);
+                jc += 1ull << (9u * t);
+                if (nt <= 128u) {
+                    const uint32_t nfull = nt & ~7u;
+                    double *a = acc_lane + t * 9u;
+                    if (j < nfull) { if (j < 8u) a[j] = q; else a[j & 7u] += q; }
+                    else { const double res = j == nfull ? (nfull ? combine8(a) : 0.0) : a[8]; a[8] = res + q; }
+                }
             }
         }
     }
