@@ -34,6 +34,7 @@ constexpr int bitlen(int n) {
 }
 
 enum : uint32_t { F_NEEDS_RESET = 1u, F_BOARD_FULL = 2u, F_FOOD_VALID = 4u };
+constexpr int WRITERS = 64;       // lanes of the rollout kernel's obs writer (see rollout_kernel)
 constexpr int FOOD_WINDOW = 8;   // default MT words fetched per round trip by _place_food (mean use: 3.2 for G=10)
 
 template <int G>
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void step_kernel(Params p) {
 // only wait for their own loads; two LDS-only barriers per step hand the tile back and forth:
 //   B1(t) rows hold obs(t) -> writer reads them | compute does transition(t+1) in registers | B2(t) rows may change.
 template <int G, int BLOCK, int MINW, int FW>
-__global__ __launch_bounds__(BLOCK + 64, MINW) void rollout_kernel(Params p) {
+__global__ __launch_bounds__(BLOCK + WRITERS, MINW) void rollout_kernel(Params p) {
     using L = Lay<G>;
     __shared__ uint4 tile4[BLOCK * L::OBS_DW / 4];
     uint32_t *tile = reinterpret_cast<uint32_t *>(tile4);
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(BLOCK + 64, MINW) void rollout_kernel(Params p) {
         const uint32_t w = threadIdx.x - BLOCK;
         for (int t = 0; t < p.k_steps; ++t) {
             lds_barrier();                                     // B1(t)
-            store_tile<64, BLOCK * L::CELLS>(tile, p.obs + (int64_t)t * p.obs_step_stride + first * L::CELLS, (uint32_t)(live * L::CELLS), w);
+            store_tile<WRITERS, BLOCK * L::CELLS>(tile, p.obs + (int64_t)t * p.obs_step_stride + first * L::CELLS, (uint32_t)(live * L::CELLS), w);
             lds_barrier();                                     // B2(t): LDS reads done (lgkmcnt), the stores drain on their own
         }
         return;
@@ -626,7 +627,7 @@ void set_variant(Ops &o) {
         hipLaunchKernelGGL((step_kernel<G, BLOCK, MINW, FW>), dim3((unsigned)((p.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, p);
     };
     o.rollout = [](const Params &p, hipStream_t s) {
-        hipLaunchKernelGGL((rollout_kernel<G, BLOCK, MINW, FW>), dim3((unsigned)((p.n + BLOCK - 1) / BLOCK)), dim3(BLOCK + 64), 0, s, p);
+        hipLaunchKernelGGL((rollout_kernel<G, BLOCK, MINW, FW>), dim3((unsigned)((p.n + BLOCK - 1) / BLOCK)), dim3(BLOCK + WRITERS), 0, s, p);
     };
 }
 
