@@ -286,7 +286,7 @@ def main():
         if len(names) > 1:
             out["roofline_per_env_type"] = hb["roofline"]
         out["api_step" if other == "step" else "fused_rollout"] = block(other)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:            # the CPU port is timed at N=1 only
             out["cpu_baseline"] = cpu_baseline(names[0] if len(names) == 1 else "snake")
         print(json.dumps(out), flush=True)
     for e in envs.values():
