@@ -216,6 +216,10 @@ struct LdsDrawsCall {
         d.flush();
         pos = d.pos; pretw = d.pretw; cur = 0; filled = false;
     }
+    __device__ __forceinline__ void fill() {                   // unconditional (re)fill through the same call
+        const uint2 r = refill(row, blk, pos, pretw, cur, filled);
+        pos = r.x; pretw = r.y; cur = 0; filled = true;
+    }
     __device__ __forceinline__ uint32_t next() {
         if (!filled || cur == (uint32_t)W) {
             const uint2 r = refill(row, blk, pos, pretw, cur, filled);

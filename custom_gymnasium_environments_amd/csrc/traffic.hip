@@ -129,7 +129,7 @@ struct Env {
 };
 
 // _spawn_vehicles :222-249 + generate_vehicle_route utils.py:174-193 (called with nveh < max_vehicles)
-__device__ __forceinline__ void spawn(Env &e, const Cfg &c, LdsDraws<DW> &d) {
+__device__ __forceinline__ void spawn(Env &e, const Cfg &c, LdsDrawsCall<DW> &d) {
     if (!(d.random53() < c.spawn_rate)) return;
     const uint32_t start = d.randbelow(9u, 4);                      // random.randint(0, 8)
     const uint32_t hops = 1u + d.randbelow(4u, 3);                  // randint(2, 5) - 1
@@ -167,7 +167,7 @@ __device__ __forceinline__ void spawn(Env &e, const Cfg &c, LdsDraws<DW> &d) {
 }
 
 // one reference step() (:168-203); returns terminated, reward in float64
-__device__ __forceinline__ bool env_step(Env &e, const Cfg &c, const uint32_t (&a)[NI], LdsDraws<DW> &d, double &reward) {
+__device__ __forceinline__ bool env_step(Env &e, const Cfg &c, const uint32_t (&a)[NI], LdsDrawsCall<DW> &d, double &reward) {
     e.timestep += 1;
     d.ensure(12);                                                                      // typical step: 1-2 light timers + a spawn with 1-4 hops
 #pragma unroll
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
     const int64_t nrows = p.n - i0 < 64 ? p.n - i0 : 64;
     Env e;
     e.load(p.state, p.n, li);
-    LdsDraws<DW> d(draws + (threadIdx.x & 63u) * DROW, p.mt + li * MT_STRIDE, e.mt_pos, e.mt_pretw);
+    LdsDrawsCall<DW> d(draws + (threadIdx.x & 63u) * DROW, p.mt + li * MT_STRIDE, e.mt_pos, e.mt_pretw);
     const uint64_t key = ROLLOUT ? hash_env_key(p.a_seed, (uint64_t)(p.env0 + li)) : 0;
     double rsum = 0.0;
     int32_t dcount = 0;

@@ -72,7 +72,8 @@ class DeviceVectorEnv(VectorEnvBase):
         return getattr(self._lib, f"{self._abi}_{name}")
 
     def _check(self, status, what):
-        _native.check(status, self._h, self._fn("last_error"), f"{self._abi}_{what}")
+        if status:                                             # hot path: no lookups or string formatting on success
+            _native.check(status, self._h, self._fn("last_error"), f"{self._abi}_{what}")
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
