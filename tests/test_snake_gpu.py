@@ -232,3 +232,30 @@ def test_million_env_config_properties_and_sampled_parity(cge, oracle):
     oh, rh, dh = half.rollout(T, action_seed=123)
     assert torch.equal(oh, obs[n // 2:]) and torch.equal(rh, rs[n // 2:]) and torch.equal(dh, dc[n // 2:])
     env.close(); half.close()
+
+
+@pytest.mark.parametrize("mode", ["NextStep", "SameStep", "Disabled"])
+@pytest.mark.parametrize("grid,n", [(6, 200), (8, 333), (12, 257), (16, 130), (20, 191)])
+def test_rollout_trajectory_equals_stepping_the_oracle(cge, oracle, mode, grid, n):
+    """The fused rollout (writer wave, incremental LDS obs rows, cooperative food placement) for every supported grid:
+    each step's obs / reward / terminated of a [K, N, G, G] trajectory equals the oracle stepped with the same actions."""
+    code = {"NextStep": oracle.NEXT_STEP, "SameStep": oracle.SAME_STEP, "Disabled": oracle.DISABLED}[mode]
+    K = 120
+    env = cge.SnakeVectorEnv(n, grid_size=grid, autoreset_mode=mode, env_index0=3)
+    o = oracle.SnakeOracle(n, grid, code)
+    o.seed(np.arange(n, dtype=np.uint64) + np.uint64(3 + 17))
+    env.reset(seed=17); o.reset()
+    acts = np.random.default_rng(grid).integers(0, 4, (K, n)).astype(np.int32)
+    obs, rt, tt, rs, dc = env.rollout(K, actions=torch.from_numpy(acts).cuda(), trajectory=True, per_step=True)
+    obs, rt, tt = _np(obs), _np(rt), _np(tt)
+    for t in range(K):
+        oo, ro, teo, tro = o.step(acts[t])
+        assert np.array_equal(obs[t], oo), (t, np.argwhere(obs[t] != oo)[:5])
+        assert np.array_equal(rt[t], ro) and np.array_equal(tt[t], teo.astype(bool)), t
+    # and once more without observations: same rewards, state carried on
+    o2 = oracle.SnakeOracle(n, grid, code)
+    o2.seed(np.arange(n, dtype=np.uint64) + np.uint64(3 + 17)); o2.reset()
+    env.reset(seed=17)
+    _, rs2, dc2 = env.rollout(K, actions=torch.from_numpy(acts).cuda(), want_obs=False)
+    assert np.array_equal(_np(rs2), _np(rs)) and np.array_equal(_np(dc2), _np(dc))
+    env.close()
