@@ -178,12 +178,20 @@ def main():
             sys.exit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                      "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         args.gpus = world
+    # CGE_BENCH_REHEARSAL=1: rehearse the N>1 control flow on a box with fewer GPUs than ranks (ranks share devices, gloo
+    # instead of RCCL).  Only for checking the launch / barrier / reduction logic; its numbers mean nothing.
+    rehearsal = os.environ.get("CGE_BENCH_REHEARSAL") == "1" and torch.cuda.device_count() < world
+    if rehearsal:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import custom_gymnasium_environments_amd as cge
     wl = WORKLOADS[args.workload]
@@ -247,7 +255,7 @@ def main():
         assert envs["snake"].invalid_action_count() == 0
 
     def reduce_max(x):
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearsal else dev)
         if dist is not None:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
