@@ -66,6 +66,9 @@ WORKLOADS = {
     "fleet_131k": dict(env="fleet", n=1 << 17, desc="fleet_management_env, 131,072 parallel envs per GPU"),
     "manufacturing_131k": dict(env="manufacturing", n=1 << 17, desc="smart_manufacturing_env, 131,072 parallel envs per GPU"),
     "hospital_131k": dict(env="hospital", n=1 << 17, desc="hospital_management_env, 131,072 parallel envs per GPU"),
+    "hetero_split_131k": dict(env="hetero_split", n=1 << 17,
+                              desc="heterogeneous batch, placement A: every env type x 131,072, the types dealt round-robin over the GPUs "
+                                   "(one type per GPU at N=8), results identical to placement B because seeds follow the global env index"),
     "hetero_131k": dict(env="hetero", n=1 << 17,
                         desc="heterogeneous batch: every implemented env type x 131,072, co-resident on each GPU, one HIP stream per type"),
 }
@@ -197,8 +200,14 @@ def main():
     wl = WORKLOADS[args.workload]
     n, K, W = wl["n"], args.steps, args.warmup
     dev = torch.device("cuda", local_rank)
-    names = sorted(ENVS) if wl["env"] == "hetero" else [wl["env"]]
-    envs = {nm: make_env(cge, nm, n, dev, rank * n) for nm in names}
+    if wl["env"] == "hetero":
+        names = sorted(ENVS)
+    elif wl["env"] == "hetero_split":                               # placement A: type k lives on rank k % world, whole (131,072 envs)
+        names = [nm for k, nm in enumerate(sorted(ENVS)) if k % world == rank]
+    else:
+        names = [wl["env"]]
+    split = wl["env"] == "hetero_split"
+    envs = {nm: make_env(cge, nm, n, dev, 0 if split else rank * n) for nm in names}
     if len(names) > 1:
         streams = {nm: torch.cuda.Stream(device=dev) for nm in names}
     else:
@@ -263,7 +272,7 @@ def main():
     walls = {p: reduce_max(results[p][0]) for p in results}
     if rank == 0:
         head, other = args.path, ("step" if args.path == "rollout" else "rollout")
-        total_envs = n * len(names) * world
+        total_envs = n * len(ENVS) if split else n * len(names) * world
 
         def block(path):
             wall, gpu_ms = walls[path], results[path][1]
@@ -281,7 +290,7 @@ def main():
         out = {
             "metric": "env steps/sec (whole node) at 1M parallel envs; achieved HBM GB/s vs peak",
             "value": hb["value"], "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": hb["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": hb["ms_per_step"], "higher_is_better": True, "scaling": "strong" if split else "weak", "vs_baseline": None,
             "dtype": ENVS[names[0]]["dtype"] if len(names) == 1 else "mixed", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {wl['desc']}", "envs_per_gpu": n * len(names), "env_types": names,
                        "path": (("rollout: K (step, dense-reset) launch pairs queued by one C-ABI call, obs written to HBM every step, device-side action hash"
@@ -289,7 +298,7 @@ def main():
                                  "fused rollout: the K steps in one launch per GPU, obs written to HBM every step, device-side action hash")
                                 if head == "rollout" else "K C-ABI step() calls through the VectorEnv facade, HBM-resident actions"),
                        "autoreset": "SameStep", "parallelism": f"env-sharded x{world}, no data-path collective"},
-            "roofline": hb["roofline"] if len(names) == 1 else hb["roofline"]["snake"],
+            "roofline": hb["roofline"] if len(names) == 1 else hb["roofline"].get("snake", hb["roofline"][names[0]]),
         }
         if len(names) > 1:
             out["roofline_per_env_type"] = hb["roofline"]
