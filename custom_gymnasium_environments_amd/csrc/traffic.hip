@@ -32,8 +32,8 @@ constexpr int NQ = 36;
 constexpr int OBS = 130;
 constexpr int CW = 26;             // obs dwords per staged chunk (130 = 5 x 26)
 constexpr int ROW = 27;            // LDS row stride, odd
-constexpr int DW = 16;             // MT words per draw-queue fill
-constexpr int DROW = 17;
+constexpr int DW = 16;             // MT words per draw-queue fill: one step() call
+constexpr int DWR = 48;            // fused rollout: a window lasts several steps, refilled wave-convergently (ensure)
 constexpr int BLOCK = 64;
 constexpr int COLS = 15;           // uint4 columns per env (58 of 60 dwords used)
 enum { NS_GREEN = 0, NS_YELLOW = 1, EW_GREEN = 2, EW_YELLOW = 3 };
@@ -129,7 +129,8 @@ struct Env {
 };
 
 // _spawn_vehicles :222-249 + generate_vehicle_route utils.py:174-193 (called with nveh < max_vehicles)
-__device__ __forceinline__ void spawn(Env &e, const Cfg &c, LdsDrawsCall<DW> &d) {
+template <class DRAWS>
+__device__ __forceinline__ void spawn(Env &e, const Cfg &c, DRAWS &d) {
     if (!(d.random53() < c.spawn_rate)) return;
     const uint32_t start = d.randbelow(9u, 4);                      // random.randint(0, 8)
     const uint32_t hops = 1u + d.randbelow(4u, 3);                  // randint(2, 5) - 1
@@ -167,7 +168,8 @@ __device__ __forceinline__ void spawn(Env &e, const Cfg &c, LdsDrawsCall<DW> &d)
 }
 
 // one reference step() (:168-203); returns terminated, reward in float64
-__device__ __forceinline__ bool env_step(Env &e, const Cfg &c, const uint32_t (&a)[NI], LdsDrawsCall<DW> &d, double &reward) {
+template <class DRAWS>
+__device__ __forceinline__ bool env_step(Env &e, const Cfg &c, const uint32_t (&a)[NI], DRAWS &d, double &reward) {
     e.timestep += 1;
     d.ensure(12);                                                                      // typical step: 1-2 light timers + a spawn with 1-4 hops
 #pragma unroll
@@ -286,6 +288,7 @@ __device__ __forceinline__ void observe(const Env &e, int64_t nrows, float *__re
 template <bool ROLLOUT>
 __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
     __shared__ uint32_t tile[64 * ROW];
+    constexpr int W = ROLLOUT ? DWR : DW, DROW = W + 1;
     __shared__ uint32_t draws[64 * DROW];
     const int64_t i0 = (int64_t)blockIdx.x * BLOCK;
     const int64_t i = i0 + threadIdx.x;
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
     const int64_t nrows = p.n - i0 < 64 ? p.n - i0 : 64;
     Env e;
     e.load(p.state, p.n, li);
-    LdsDrawsCall<DW> d(draws + (threadIdx.x & 63u) * DROW, p.mt + li * MT_STRIDE, e.mt_pos, e.mt_pretw);
+    LdsDrawsCall<W> d(draws + (threadIdx.x & 63u) * DROW, p.mt + li * MT_STRIDE, e.mt_pos, e.mt_pretw);
     const uint64_t key = ROLLOUT ? hash_env_key(p.a_seed, (uint64_t)(p.env0 + li)) : 0;
     double rsum = 0.0;
     int32_t dcount = 0;
@@ -316,9 +319,9 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
 #pragma unroll
                     for (int j = 0; j < NI; ++j) a[j] = hash_action_from_key(key, (uint64_t)(p.t0 + t), 3u, (uint32_t)j);
                 }
-                if (e.nveh < (uint32_t)p.cfg.max_vehicles) d.fill();      // a spawn attempt always draws: fetch the window now
+                if (!ROLLOUT && e.nveh < (uint32_t)p.cfg.max_vehicles) d.fill();      // a spawn attempt always draws: fetch the window now
                 term = env_step(e, p.cfg, a, d, reward);
-                d.flush();
+                if (!ROLLOUT) d.flush();                          // a rollout keeps its window across steps
                 if (term) {
                     e.episodes += 1;
                     if (p.mode == CGE_AUTORESET_SAME_STEP) reset_now = true;
@@ -344,6 +347,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
         }
     }
     if (live) {
+        if (ROLLOUT) d.flush();                                   // the rollout's window is written back once, here
         e.mt_pos = d.pos; e.mt_pretw = d.pretw;
         e.store(p.state, p.n, i);
         if (ROLLOUT) {
