@@ -1,11 +1,11 @@
 """A/B timing of snake kernel variants in ONE process (interleaved rounds, HIP-event timed).
-usage: python tools_ab.py [variant ids ...]"""
+usage: python tools/ab.py [variant ids ...]"""
 import os
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import custom_gymnasium_environments_amd as cge
 
 N = 1 << 20

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_profile.sh <tag> <bench args...>   (run on the GPU box from the repo root)
+# usage: tools/profile.sh <tag> <bench args...>   (run on the GPU box from the repo root)
 # Writes rocprofv3 kernel stats and PMC passes (each in its own run) under gpurun_out/prof_<tag>/.
 set -o pipefail
 TAG=$1; shift
@@ -12,5 +12,5 @@ for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WA
   N=$(echo $C | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$N -- python3 $R/bench.py "$@" --no-cpu-baseline > $OUT/pmc_$N.log 2>&1 || echo "pmc $C failed" >> $OUT/errors.log
 done
-python3 $R/tools_profile_summary.py $OUT > $OUT/summary.txt 2>&1
+python3 $R/tools/profile_summary.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
