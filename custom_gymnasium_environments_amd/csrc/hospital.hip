@@ -331,16 +331,17 @@ __device__ __forceinline__ void update_queue(Misc &m, const Ring &rg, Draws &D, 
 __device__ __forceinline__ void flush_rows(const uint32_t *tile, int ncols, int col0, int64_t nrows, float *__restrict__ dst, unsigned long long rowmask) {
     const uint32_t lane = threadIdx.x & 63u;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    uint32_t r = 0, c = lane;
-    while (c >= (uint32_t)ncols) { c -= ncols; r += 1u; }
-    const uint32_t dr = 64u / (uint32_t)ncols, dc = 64u % (uint32_t)ncols;
+    // one row at a time (wave-uniform: rows outside the mask cost a scalar branch), each lane 1-3 columns of it
 #pragma unroll 1
-    for (int m = 0; m < ncols; ++m) {
-        const uint32_t gc = (uint32_t)col0 + c;
-        if ((int64_t)r < nrows && ((rowmask >> r) & 1ull) && !(gc >= 45u && gc <= 50u))
-            reinterpret_cast<uint32_t *>(dst)[(int64_t)r * OBS + gc] = tile[r * TILE + c];
-        c += dc; r += dr;
-        if (c >= (uint32_t)ncols) { c -= ncols; r += 1u; }
+    for (int r = 0; r < (int)nrows; ++r) {
+        if (!((rowmask >> r) & 1ull)) continue;
+        uint32_t *drow = reinterpret_cast<uint32_t *>(dst) + (int64_t)r * OBS + col0;
+        const uint32_t *trow = tile + r * TILE;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const uint32_t c = lane + 64u * q, gc = (uint32_t)col0 + c;
+            if (c < (uint32_t)ncols && !(gc >= 45u && gc <= 50u)) drow[c] = trow[c];
+        }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
