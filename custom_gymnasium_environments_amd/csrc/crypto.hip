@@ -104,7 +104,8 @@ __device__ __forceinline__ double vol_mult(uint32_t r) { return r == BULL ? 1.2 
 __device__ __forceinline__ double base_trend(uint32_t r) { return r == BULL ? 0.001 : r == BEAR ? -0.001 : r == SIDEWAYS ? 0.0 : r == CRASH ? -0.005 : 0.002; }   // :202-208
 
 // _update_market_regime :166-186, draws from the serial P stream (1 % of steps)
-__device__ __forceinline__ void update_regime(Env &e, MtStream &sp) {
+template <class STREAM>
+__device__ __forceinline__ void update_regime(Env &e, STREAM &sp) {
     const uint32_t pick = sp.randbelow(2u, 2);   // random.choice of the two successors
     const uint32_t r = e.regime;
     const uint32_t nx0 = r == BULL ? SIDEWAYS : r == BEAR ? SIDEWAYS : r == SIDEWAYS ? BULL : r == CRASH ? RECOVERY : BULL;
@@ -117,7 +118,8 @@ __device__ __forceinline__ void update_regime(Env &e, MtStream &sp) {
 }
 
 // legacy_gauss (polar method) from the serial L stream
-__device__ __forceinline__ double gauss_serial(Env &e, MtStream &sl) {
+template <class STREAM>
+__device__ __forceinline__ double gauss_serial(Env &e, STREAM &sl) {
     if (e.has_gauss) {
         e.has_gauss = 0;
         const double g = e.gauss;
@@ -151,10 +153,16 @@ __device__ __forceinline__ double price_update(Env &e, const Cfg &c, double curr
     return np_;
 }
 
-// reset :301-340 — rare (once per episode), every draw through the serial streams.  Candle k of the
-// fresh history goes to slot (phase + k) % 50: the env adopts the batch-wide ring phase.
-__device__ __forceinline__ void do_reset(Env &e, const Params &p, int64_t i, int phase) {
-    MtStream sp(p.mtP + i * MT_STRIDE, e.ppos, e.ppretw), sl(p.mtL + i * MT_STRIDE, e.lpos, e.lpretw);
+// reset :301-340 — once per episode: the 50-candle history is re-simulated (~700 draws over both streams).  The draws come
+// from LDS-parked windows that borrow the lane's row of the obs tile (idle at this point: 32 words of the CPython stream +
+// 16 of the NumPy-legacy one, 48 <= 51 dwords): through the serial MtStream every draw was its own memory round trip, a
+// ~270-us chain that every wave with one finishing env paid in that step (and 19.8 ms for a full 1M-env reset()).
+// Candle k of the fresh history goes to slot (phase + k) % 50: the env adopts the batch-wide ring phase.
+constexpr int RW_P = 32, RW_L = 16;
+static_assert(RW_P + RW_L <= ROW, "the reset's draw windows live in the lane's obs-tile row");
+__device__ __forceinline__ void do_reset(Env &e, const Params &p, int64_t i, int phase, uint32_t *lds_row) {
+    LdsDrawsCall<RW_P> sp(lds_row, p.mtP + i * MT_STRIDE, e.ppos, e.ppretw);
+    LdsDrawsCall<RW_L> sl(lds_row + RW_P, p.mtL + i * MT_STRIDE, e.lpos, e.lpretw);
     e.cash = p.cfg.initial_balance;
     e.cash_kind = 0;
     e.holdings = 0.0;
@@ -164,6 +172,8 @@ __device__ __forceinline__ void do_reset(Env &e, const Params &p, int64_t i, int
     int slot = phase;
 #pragma unroll 1
     for (int k = 0; k < HLEN; ++k) {
+        sp.ensure(14);                                         // 10 words per candle + a regime change (refills converge across the lanes that reset)
+        sl.ensure(8);
         const double volume = 0.5 + (2.0 - 0.5) * sp.random53();
         if (sp.random53() < 0.01) update_regime(e, sp);
         const double g = gauss_serial(e, sl);
@@ -176,6 +186,7 @@ __device__ __forceinline__ void do_reset(Env &e, const Params &p, int64_t i, int
         slot = slot + 1 == HLEN ? 0 : slot + 1;
     }
     e.close = price;
+    sp.flush(); sl.flush();
     e.ppos = sp.pos; e.ppretw = sp.pretw; e.lpos = sl.pos; e.lpretw = sl.pretw;
 }
 
@@ -523,7 +534,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
         float *obs_t = p.obs ? p.obs + (int64_t)t * p.obs_step_stride + i0 * OBS : nullptr;
 #pragma unroll 1
         for (int pass = (fin_mask && p.final_obs) ? 0 : 1; pass < 2; ++pass) {
-            if (pass == 1 && reset_now) do_reset(e, p, i, next_phase);
+            if (pass == 1 && reset_now) do_reset(e, p, i, next_phase, tile + (threadIdx.x & 63u) * ROW);
             float *dst = pass == 0 ? p.final_obs + i0 * OBS : obs_t;
             if (dst) observe(e, p, i0, i, live, next_phase, dst, pass == 0 ? fin_mask : ~0ull, tile);
         }
@@ -558,7 +569,7 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(Params p) {
     Env e;
     e.load(p.scal, p.n, live ? i : i0);
     if (live && (!p.mask || p.mask[i])) {
-        do_reset(e, p, i, p.phase);
+        do_reset(e, p, i, p.phase, tile + (threadIdx.x & 63u) * ROW);
         e.store(p.scal, p.n, i);
     }
     if (p.obs) observe(e, p, i0, i, live, p.phase, p.obs + i0 * OBS, ~0ull, tile);
