@@ -2,25 +2,26 @@
 import ctypes as C
 
 import numpy as np
-import torch
 
 from . import _native
-from ._spaces import Box, MultiDiscrete, batch_space
-from .vector_env import DeviceVectorEnv
+from ._spaces import Box, Discrete, MultiDiscrete, batch_space  # noqa: F401
+from .vector_env import FlagsVectorEnv
 
 INFO_FIELDS = {"timestep": 0, "missed_deadlines": 1, "completed_deliveries": 2, "num_requests": 3, "weather_effect": 4,
                "total_reward": 5, "episodes": 6, "needs_reset": 7, "fuel0": 8, "fuel1": 9, "fuel2": 10}
 OBS_DIM = 76   # what _get_observation() returns (:555-593); the declared space says 87 (:151-154)
 
 
-class FleetVectorEnv(DeviceVectorEnv):
-    """N independent FleetManagementEnv instances (3 vehicles on a 25x25 grid, 8-12 deliveries) stepped by one HIP
-    kernel launch.  Actions `MultiDiscrete([8]*3)` (0 stay, 1-4 move, 5 pick up, 6 drop off, 7 refuel), obs
-    float32 (76,).  Both `terminated` (:537-553) and `truncated` (timestep >= 800) are reported; auto-reset
-    triggers on either.  `reset(seed=s)` seeds env i's NumPy-legacy and CPython streams with s + env_index0 + i
-    (:187-189).  Bit-exact with the reference."""
+class FleetVectorEnv(FlagsVectorEnv):
+    """N independent FleetManagementEnv instances (3 vehicles on a 25x25 grid, 8-12 deliveries) stepped on the GPU.  Actions
+    `MultiDiscrete([8]*3)` (0 stay, 1-4 move, 5 pick up, 6 drop off, 7 refuel), obs float32 (76,).  Both `terminated`
+    (:537-553) and `truncated` (timestep >= 800) are reported; auto-reset triggers on either.  `reset(seed=s)` seeds env i's
+    NumPy-legacy and CPython streams with s + env_index0 + i (:187-189).  Bit-exact with the reference."""
 
     _abi = "cge_fleet"
+    _obs_dim = OBS_DIM
+    _action_shape = (3,)
+    INFO_FIELDS = INFO_FIELDS
     metadata = {"render_modes": []}
 
     def __init__(self, num_envs, device="cuda:0", autoreset_mode="NextStep", env_index0=0, max_timesteps=800, reuse_buffers=False,
@@ -30,67 +31,8 @@ class FleetVectorEnv(DeviceVectorEnv):
         self.single_observation_space = Box(-1.0, 25.0, (OBS_DIM,), np.float32)
         self.action_space = batch_space(self.single_action_space, self.num_envs)
         self.observation_space = batch_space(self.single_observation_space, self.num_envs)
-        self.info_fields = tuple(info_fields)
         cfg = _native.FleetConfig(int(max_timesteps), self._mode_code)
         h = C.c_void_p()
-        _native.check(self._lib.cge_fleet_create(C.byref(cfg), self.num_envs, self._dev_index, self.env_index0, C.byref(h)),
-                      what="cge_fleet_create")
+        _native.check(self._fn("create")(C.byref(cfg), self.num_envs, self._dev_index, self.env_index0, C.byref(h)), what="cge_fleet_create")
         self._h = h
-        self._obs_shape = (self.num_envs, OBS_DIM)
-
-    def reset(self, *, seed=None, options=None):
-        self._seed_native(seed)
-        mask = None
-        if options and options.get("reset_mask") is not None:
-            mask = self._as_device(options["reset_mask"], torch.uint8, (self.num_envs,), "reset_mask")
-        obs = self._out("obs", self._obs_shape, torch.float32)
-        self._check(self._lib.cge_fleet_reset(self._h, mask.data_ptr() if mask is not None else None, obs.data_ptr(),
-                                              self._stream()), "reset")
-        return obs, self._infos()
-
-    def step(self, actions):
-        a = self._as_device(actions, torch.int32, (self.num_envs, 3), "actions")
-        obs = self._out("obs", self._obs_shape, torch.float32)
-        rew = self._out("reward", (self.num_envs,), torch.float32)
-        term = self._out("terminated", (self.num_envs,), torch.bool)
-        trunc = self._out("truncated", (self.num_envs,), torch.bool)
-        same = self._mode_code == _native.AUTORESET_SAME_STEP
-        fin = self._out("final_obs", self._obs_shape, torch.float32) if same else None
-        self._check(self._lib.cge_fleet_step(self._h, a.data_ptr(), obs.data_ptr(), rew.data_ptr(), term.data_ptr(), trunc.data_ptr(),
-                                             fin.data_ptr() if same else None, self._stream()), "step")
-        infos = self._infos()
-        if same:
-            infos["final_obs"] = fin
-            infos["_final_obs"] = term | trunc
-        return obs, rew, term, trunc, infos
-
-    def rollout(self, k_steps, actions=None, action_seed=0, t0=0, trajectory=False, want_obs=True, per_step=False):
-        """k fused steps; with per_step=True the flags trajectory holds terminated | truncated << 1 (uint8)."""
-        k = int(k_steps)
-        a = None if actions is None else self._as_device(actions, torch.int32, (k, self.num_envs, 3), "actions")
-        obs, stride = None, 0
-        if want_obs:
-            if trajectory:
-                obs = self._out("traj", (k,) + self._obs_shape, torch.float32)
-                stride = self.num_envs * OBS_DIM
-            else:
-                obs = self._out("obs", self._obs_shape, torch.float32)
-        rs = self._out("reward_sum", (self.num_envs,), torch.float64)
-        dc = self._out("done_count", (self.num_envs,), torch.int32)
-        rt = tt = None
-        if per_step:
-            rt = self._out("reward_traj", (k, self.num_envs), torch.float32)
-            tt = self._out("flags_traj", (k, self.num_envs), torch.uint8)
-        self._check(self._lib.cge_fleet_rollout(self._h, k, a.data_ptr() if a is not None else None, int(action_seed), int(t0),
-                                                obs.data_ptr() if obs is not None else None, stride,
-                                                rt.data_ptr() if per_step else None, tt.data_ptr() if per_step else None,
-                                                rs.data_ptr(), dc.data_ptr(), self._stream()), "rollout")
-        return (obs, rt, tt, rs, dc) if per_step else (obs, rs, dc)
-
-    def info(self, field):
-        out = torch.empty(self.num_envs, dtype=torch.float64, device=self.device)
-        self._check(self._lib.cge_fleet_info(self._h, INFO_FIELDS[field], out.data_ptr(), self._stream()), "info")
-        return out
-
-    def _infos(self):
-        return {f: self.info(f) for f in self.info_fields}
+        self._finish_init(info_fields)

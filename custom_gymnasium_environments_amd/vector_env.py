@@ -137,3 +137,75 @@ class DeviceVectorEnv(VectorEnvBase):
         if getattr(self, "_h", None):
             self._fn("destroy")(self._h)
             self._h = None
+
+
+class FlagsVectorEnv(DeviceVectorEnv):
+    """Shared façade of the env types whose C ABI has the same shape: int32 actions of a fixed per-env shape, float32
+    observations, both `terminated` and `truncated` reported, float64 info fields (fleet, manufacturing, hospital).
+    A subclass sets `_abi`, `_obs_dim`, `_action_shape`, `INFO_FIELDS`, builds the spaces and creates the native handle."""
+
+    _obs_dim = None
+    _action_shape = ()
+    INFO_FIELDS = {}
+
+    def _finish_init(self, info_fields):
+        self.info_fields = tuple(info_fields)
+        self._obs_shape = (self.num_envs, self._obs_dim)
+
+    def reset(self, *, seed=None, options=None):
+        self._seed_native(seed)
+        mask = None
+        if options and options.get("reset_mask") is not None:
+            mask = self._as_device(options["reset_mask"], torch.uint8, (self.num_envs,), "reset_mask")
+        obs = self._out("obs", self._obs_shape, torch.float32)
+        self._check(self._fn("reset")(self._h, mask.data_ptr() if mask is not None else None, obs.data_ptr(), self._stream()), "reset")
+        return obs, self._infos()
+
+    def step(self, actions):
+        a = self._as_device(actions, torch.int32, (self.num_envs,) + self._action_shape, "actions")
+        obs = self._out("obs", self._obs_shape, torch.float32)
+        rew = self._out("reward", (self.num_envs,), torch.float32)
+        term = self._out("terminated", (self.num_envs,), torch.bool)
+        trunc = self._out("truncated", (self.num_envs,), torch.bool)
+        same = self._mode_code == _native.AUTORESET_SAME_STEP
+        fin = self._out("final_obs", self._obs_shape, torch.float32) if same else None
+        self._check(self._fn("step")(self._h, a.data_ptr(), obs.data_ptr(), rew.data_ptr(), term.data_ptr(), trunc.data_ptr(),
+                                     fin.data_ptr() if same else None, self._stream()), "step")
+        infos = self._infos()
+        if same:
+            infos["final_obs"] = fin
+            infos["_final_obs"] = term | trunc
+        return obs, rew, term, trunc, infos
+
+    def rollout(self, k_steps, actions=None, action_seed=0, t0=0, trajectory=False, want_obs=True, per_step=False):
+        """k env steps queued by one C-ABI call (actions: None -> counter-hash actions, or int32 [k, N, ...]).  Returns
+        (obs, reward_sum, done_count); with per_step=True (obs, reward[k, N], flags[k, N], reward_sum, done_count) where
+        flags = terminated | truncated << 1 (uint8).  obs is [k, N, obs_dim] if trajectory else the last step's."""
+        k = int(k_steps)
+        a = None if actions is None else self._as_device(actions, torch.int32, (k, self.num_envs) + self._action_shape, "actions")
+        obs, stride = None, 0
+        if want_obs:
+            if trajectory:
+                obs = self._out("traj", (k,) + self._obs_shape, torch.float32)
+                stride = self.num_envs * self._obs_dim
+            else:
+                obs = self._out("obs", self._obs_shape, torch.float32)
+        rs = self._out("reward_sum", (self.num_envs,), torch.float64)
+        dc = self._out("done_count", (self.num_envs,), torch.int32)
+        rt = tt = None
+        if per_step:
+            rt = self._out("reward_traj", (k, self.num_envs), torch.float32)
+            tt = self._out("flags_traj", (k, self.num_envs), torch.uint8)
+        self._check(self._fn("rollout")(self._h, k, a.data_ptr() if a is not None else None, int(action_seed), int(t0),
+                                        obs.data_ptr() if obs is not None else None, stride,
+                                        rt.data_ptr() if per_step else None, tt.data_ptr() if per_step else None,
+                                        rs.data_ptr(), dc.data_ptr(), self._stream()), "rollout")
+        return (obs, rt, tt, rs, dc) if per_step else (obs, rs, dc)
+
+    def info(self, field):
+        out = torch.empty(self.num_envs, dtype=torch.float64, device=self.device)
+        self._check(self._fn("info")(self._h, self.INFO_FIELDS[field], out.data_ptr(), self._stream()), "info")
+        return out
+
+    def _infos(self):
+        return {f: self.info(f) for f in self.info_fields}
