@@ -24,9 +24,12 @@ def test_header_declares_the_full_per_env_surface():
     assert "cge_snake_error_count" in names
     for fn in ["create", "destroy", "seed", "reset", "step", "rollout", "info", "info64", "last_error", "device_bytes"]:
         assert f"cge_parking_{fn}" in names, fn
-    for fn in ["create", "destroy", "seed", "reset", "step", "rollout", "info", "last_error", "device_bytes"]:
-        assert f"cge_climate_{fn}" in names, fn
-        assert f"cge_fleet_{fn}" in names, fn
+    for env in ["climate", "fleet", "manufacturing", "hospital"]:
+        for fn in ["create", "destroy", "seed", "reset", "step", "rollout", "info", "last_error", "device_bytes"]:
+            assert f"cge_{env}_{fn}" in names, (env, fn)
+    for env in ["parking", "climate", "fleet", "manufacturing", "hospital"]:      # whole-handle checkpoint / resume
+        for fn in ["snapshot_bytes", "snapshot_get", "snapshot_set"]:
+            assert f"cge_{env}_{fn}" in names, (env, fn)
 
 
 def test_library_exports_every_declared_symbol():
@@ -56,6 +59,11 @@ def test_no_cpu_fallback_and_loud_failure():
         cge.SnakeVectorEnv(8, grid_size=10)
     with pytest.raises(cge.NativeLibraryError):
         cge.SnakeVectorEnv(8, grid_size=10, device="cpu")
+    for name in ["Crypto", "Traffic", "Parking", "Climate", "Fleet", "Manufacturing", "Hospital"]:     # every env type: no silent CPU path
+        with pytest.raises(cge.NativeLibraryError):
+            getattr(cge, name + "VectorEnv")(8)
+        with pytest.raises(cge.NativeLibraryError):
+            getattr(cge, name + "VectorEnv")(8, device="cpu")
 
 
 def test_product_never_imports_the_oracle():
