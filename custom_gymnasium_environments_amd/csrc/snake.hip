@@ -170,6 +170,18 @@ struct Env {
         flags |= F_FOOD_VALID;
     }
 
+    // _place_food() one draw at a time on the lane's own stream: for paths too rare to earn a window (an env that eats on the
+    // very step its time limit fires, in SameStep mode, needs the post-eat food AND the reset food in one step)
+    __device__ __forceinline__ void place_food_serial(uint32_t *__restrict__ blk) {
+        MtStream s(blk, mt_pos, mt_pretw);
+        for (;;) {
+            const uint32_t r = s.randbelow((uint32_t)G, L::KBITS), c = s.randbelow((uint32_t)G, L::KBITS);
+            if (!occupied(r * G + c)) { food = r * G + c; break; }
+        }
+        mt_pos = s.pos; mt_pretw = s.pretw;
+        flags |= F_FOOD_VALID;
+    }
+
     // snake_env.py:49-65 without the trailing _place_food()
     __device__ __forceinline__ void reset_body() {
 #pragma unroll
@@ -348,6 +360,9 @@ __device__ __forceinline__ uint32_t transition(Env<G> &e, const Params &p, int64
         if (term) {
             e.episodes += 1;
             if (p.mode == CGE_AUTORESET_SAME_STEP) {
+                // time limit on a step that also ate: the reference places the new food (snake_env.py:104) BEFORE it tests
+                // steps >= max_steps (:113), so the terminal obs shows it and the reset below draws a second one
+                if (need_food && e.can_place_food()) e.place_food_serial(p.mt + i * MT_STRIDE);
                 if (p.final_obs) {   // terminal observation, rare lanes only: direct row store
                     uint32_t *frow = reinterpret_cast<uint32_t *>(p.final_obs + i * L::CELLS);
                     e.write_obs_body(frow);
@@ -887,6 +902,11 @@ int cge_snake_set_state(cge_snake *h, const void *host_buf, void *stream) {
         const uint16_t *body = (const uint16_t *)(p + 32 + MT_N * 4);
         if (hdr[0] < 1 || hdr[0] > cells || hdr[1] < 0 || hdr[1] > 3 || hdr[7] < 0 || hdr[7] > MT_N)
             return h->fail(CGE_ERR_INVALID_ARG, "cge_snake_set_state: malformed record");
+        const int G = h->cfg.grid_size;
+        const bool no_food = hdr[2] == -1 && hdr[3] == -1;
+        if ((!no_food && (hdr[2] < 0 || hdr[2] >= G || hdr[3] < 0 || hdr[3] >= G)) || hdr[4] < 0 || hdr[4] > cells || hdr[5] < 0 ||
+            hdr[5] > h->ops.max_steps_limit || (hdr[6] != 0 && hdr[6] != 1))
+            return h->fail(CGE_ERR_INVALID_ARG, "cge_snake_set_state: food / score / steps / needs_reset out of range");
         for (int k = 0; k < hdr[0]; ++k)
             if (body[k] >= cells) return h->fail(CGE_ERR_INVALID_ARG, "cge_snake_set_state: body cell out of range");
         h->ops.encode(hdr, body, raw.data());

@@ -150,6 +150,10 @@ def _declare(L):
     L.orc_manufacturing_info.argtypes = [vp, i32, vp]
 
 
+    for _nm in ("snake", "crypto", "traffic", "parking", "climate", "fleet", "hospital", "manufacturing"):
+        getattr(L, f"orc_{_nm}_set_max_steps").argtypes = [vp, i32]
+
+
 NEXT_STEP, SAME_STEP, DISABLED = 0, 1, 2
 
 
@@ -215,11 +219,13 @@ def hash_action(a_seed, env, t, n, j=0):
 class SnakeOracle:
     """Batch of independent SnakeEnvClassic restatements (oracle/orc_snake.c)."""
 
-    def __init__(self, n, grid=10, mode=SAME_STEP):
+    def __init__(self, n, grid=10, mode=SAME_STEP, max_steps=None):
         self.n, self.grid, self.mode = int(n), int(grid), int(mode)
         self.h = lib().orc_snake_create(self.n, self.grid, self.mode)
         if not self.h:
             raise ValueError("orc_snake_create failed")
+        if max_steps is not None:
+            lib().orc_snake_set_max_steps(self.h, int(max_steps))
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -281,12 +287,14 @@ CRYPTO_INFO = {"portfolio_value": 0, "cash": 1, "holdings": 2, "current_price": 
 class CryptoOracle:
     """Batch of independent CryptoTradingEnv restatements (oracle/orc_crypto.c)."""
 
-    def __init__(self, n, action_type="discrete", mode=SAME_STEP):
+    def __init__(self, n, action_type="discrete", mode=SAME_STEP, max_steps=None):
         self.n, self.mode = int(n), int(mode)
         self.continuous = action_type == "continuous"
         self.h = lib().orc_crypto_create(self.n, int(self.continuous), self.mode)
         if not self.h:
             raise ValueError("orc_crypto_create failed")
+        if max_steps is not None:
+            lib().orc_crypto_set_max_steps(self.h, int(max_steps))
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -354,11 +362,13 @@ TRAFFIC_INFO = {"timestep": 0, "num_vehicles": 1, "light_phase": 2, "light_timer
 class TrafficOracle:
     """Batch of independent TrafficManagementEnv restatements (oracle/orc_traffic.c)."""
 
-    def __init__(self, n, mode=SAME_STEP):
+    def __init__(self, n, mode=SAME_STEP, max_steps=None):
         self.n, self.mode = int(n), int(mode)
         self.h = lib().orc_traffic_create(self.n, self.mode)
         if not self.h:
             raise ValueError("orc_traffic_create failed")
+        if max_steps is not None:
+            lib().orc_traffic_set_max_steps(self.h, int(max_steps))
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -429,11 +439,13 @@ class _SimpleOracle:
     _nact = None
     _adim = 1
 
-    def __init__(self, n, mode=SAME_STEP):
+    def __init__(self, n, mode=SAME_STEP, max_steps=None):
         self.n, self.mode = int(n), int(mode)
         self.h = getattr(lib(), f"orc_{self._name}_create")(self.n, self.mode)
         if not self.h:
             raise ValueError("create failed")
+        if max_steps is not None:                          # the env type's time limit (episode_minutes, max_timesteps, ...)
+            getattr(lib(), f"orc_{self._name}_set_max_steps")(self.h, int(max_steps))
 
     def __del__(self):
         if getattr(self, "h", None):

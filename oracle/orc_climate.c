@@ -168,3 +168,7 @@ void orc_climate_info(const orc_climate *h, int field, double *out) {
         out[i] = v;
     }
 }
+
+/* Time-limit override for the short-horizon parity tests (the reference's limit is a constructor constant /
+ * config value; the device ABI takes it in its config struct).  Call before reset(). */
+void orc_climate_set_max_steps(orc_climate *h, int v) { h->episode_minutes = v; }

@@ -425,3 +425,7 @@ void orc_crypto_set_state(orc_crypto *h, const void *buf) {
         memcpy(e->hist, p + 96 + 2 * 2496, HLEN * 40);
     }
 }
+
+/* Time-limit override for the short-horizon parity tests (the reference's limit is a constructor constant /
+ * config value; the device ABI takes it in its config struct).  Call before reset(). */
+void orc_crypto_set_max_steps(orc_crypto *h, int v) { h->c.max_steps = v; }

@@ -267,3 +267,7 @@ void orc_fleet_info(const orc_fleet *h, int field, double *out) {
         out[i] = v;
     }
 }
+
+/* Time-limit override for the short-horizon parity tests (the reference's limit is a constructor constant /
+ * config value; the device ABI takes it in its config struct).  Call before reset(). */
+void orc_fleet_set_max_steps(orc_fleet *h, int v) { h->max_steps = v; }

@@ -362,3 +362,7 @@ void orc_hospital_info(const orc_hospital *h, int field, double *out) {
         out[i] = v;
     }
 }
+
+/* Time-limit override for the short-horizon parity tests (the reference's limit is a constructor constant /
+ * config value; the device ABI takes it in its config struct).  Call before reset(). */
+void orc_hospital_set_max_steps(orc_hospital *h, int v) { h->max_steps = v; }

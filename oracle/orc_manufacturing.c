@@ -47,7 +47,7 @@ typedef struct {
     int needs_reset, episodes, overflow;
 } menv;
 
-typedef struct { int64_t n; int mode; menv *e; } orc_manufacturing;
+typedef struct { int64_t n; int mode, max_steps; menv *e; } orc_manufacturing;
 
 /* NumPy pairwise summation (loops_utils.h.src pairwise_sum), any n */
 static double np_sum(const double *a, int n) {
@@ -117,7 +117,7 @@ static void write_obs(const menv *e, float *obs) {                         /* :1
 static double recent_mean(const double *a, int n, int last) { int m = n < last ? n : last; return np_mean(a + n - m, m); }
 
 /* returns terminated | truncated << 1; *reward is the (integer-valued) step reward */
-static int env_step(menv *e, int action, double *reward_out) {             /* :252-301 */
+static int env_step(const orc_manufacturing *h, menv *e, int action, double *reward_out) {             /* :252-301 */
     int reward = 0;
     e->timestep += 1;
     /* _process_action :303-359 */
@@ -219,9 +219,9 @@ static int env_step(menv *e, int action, double *reward_out) {             /* :2
         if (rq > 0.9) reward += 20; else if (rq < 0.6) reward -= 30;
     }
     /* _check_termination :555-578 */
-    int term = all_met || broken >= 3 || e->timestep >= 1500;
+    int term = all_met || broken >= 3 || e->timestep >= h->max_steps;   /* 1500 (:282) */
     if (!term && e->nhist >= 100 && np_mean(e->hist + e->nhist - 100, 100) < 0.6) term = 1;
-    int trunc = e->timestep >= 1500;
+    int trunc = e->timestep >= h->max_steps;                          /* :569 */
     /* _update_supply_chain :580-595 */
     if (!e->disruption && orc_pcg_double(&e->g) < 0.01) { e->disruption = 1; e->disruption_cd = (int)orc_pcg_integers(&e->g, 20, 50); }
     if (e->disruption) { e->disruption_cd -= 1; if (e->disruption_cd <= 0) e->disruption = 0; }
@@ -234,7 +234,7 @@ static int env_step(menv *e, int action, double *reward_out) {             /* :2
 orc_manufacturing *orc_manufacturing_create(int64_t n, int mode) {
     if (n <= 0 || mode < 0 || mode > 2) return NULL;
     orc_manufacturing *h = (orc_manufacturing *)calloc(1, sizeof(*h));
-    h->n = n; h->mode = mode;
+    h->n = n; h->mode = mode; h->max_steps = 1500;
     h->e = (menv *)calloc((size_t)n, sizeof(menv));
     for (int64_t i = 0; i < n; ++i) { orc_pcg_seed(&h->e[i].g, (uint64_t)i); h->e[i].thr[0] = 0.70; h->e[i].thr[1] = 0.80; h->e[i].thr[2] = 0.85; h->e[i].raw = 250; }
     return h;
@@ -261,7 +261,7 @@ void orc_manufacturing_step(orc_manufacturing *h, const int32_t *actions, float 
             continue;
         }
         double r;
-        int f = env_step(e, actions[i], &r);
+        int f = env_step(h, e, actions[i], &r);
         reward[i] = (float)r; if (reward64) reward64[i] = r;
         terminated[i] = (uint8_t)(f & 1); truncated[i] = (uint8_t)(f >> 1);
         if (f) e->episodes += 1;
@@ -284,7 +284,7 @@ void orc_manufacturing_rollout(orc_manufacturing *h, int k_steps, uint64_t a_see
         for (int t = 0; t < k_steps; ++t) {
             if (h->mode == 0 && e->needs_reset) { env_reset(e); continue; }
             double r;
-            int f = env_step(e, (int)orc_hash_action(a_seed, (uint64_t)(env0 + i), (uint64_t)(t0 + t), 25, 0), &r);
+            int f = env_step(h, e, (int)orc_hash_action(a_seed, (uint64_t)(env0 + i), (uint64_t)(t0 + t), 25, 0), &r);
             rs += r;
             if (f) { ++dc; e->episodes += 1; if (h->mode == 1) env_reset(e); else if (h->mode == 0) e->needs_reset = 1; }
         }
@@ -313,3 +313,7 @@ void orc_manufacturing_info(const orc_manufacturing *h, int field, double *out) 
         out[i] = v;
     }
 }
+
+/* Time-limit override for the short-horizon parity tests (the reference's limit is a constructor constant /
+ * config value; the device ABI takes it in its config struct).  Call before reset(). */
+void orc_manufacturing_set_max_steps(orc_manufacturing *h, int v) { h->max_steps = v; }

@@ -260,3 +260,7 @@ void orc_parking_info(const orc_parking *h, int field, int idx, int32_t *out) {
 void orc_parking_info64(const orc_parking *h, int field, double *out) {
     for (int64_t i = 0; i < h->n; ++i) out[i] = field == 0 ? h->e[i].revenue : h->e[i].satisfaction_sum;
 }
+
+/* Time-limit override for the short-horizon parity tests (the reference's limit is a constructor constant /
+ * config value; the device ABI takes it in its config struct).  Call before reset(). */
+void orc_parking_set_max_steps(orc_parking *h, int v) { h->max_steps = v; }

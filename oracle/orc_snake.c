@@ -249,3 +249,7 @@ void orc_snake_set_state(orc_snake *h, const void *buf) {
         e->board_full = 0;
     }
 }
+
+/* Time-limit override for the short-horizon parity tests (the reference's limit is a constructor constant /
+ * config value; the device ABI takes it in its config struct).  Call before reset(). */
+void orc_snake_set_max_steps(orc_snake *h, int v) { h->max_steps = v; }

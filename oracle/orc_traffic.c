@@ -288,3 +288,7 @@ void orc_traffic_set_state(orc_traffic *h, const void *buf) {
         memcpy(e->P.mt, w + 144, 2496);
     }
 }
+
+/* Time-limit override for the short-horizon parity tests (the reference's limit is a constructor constant /
+ * config value; the device ABI takes it in its config struct).  Call before reset(). */
+void orc_traffic_set_max_steps(orc_traffic *h, int v) { h->max_steps = v; }

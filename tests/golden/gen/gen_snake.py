@@ -6,7 +6,7 @@ Protocols:
     auto-reset = `env.reset()` (no seed) right after a terminal step, stream continues.
   * KAT-S1 (config 1): random.seed(0); reset(seed=0); 10,000 actions from
     np.random.default_rng(123).integers(0,4,10000); reset() after each done.
-Outputs: tests/golden/snake_g10_hash.npz, snake_g10_greedy.npz, snake_g20_greedy.npz, snake_kat.json
+Outputs: tests/golden/snake_g10_hash.npz, snake_g10_greedy.npz, snake_g20_greedy.npz, snake_g10_short.npz, snake_kat.json
 """
 import json
 import os
@@ -21,9 +21,11 @@ common.add_reference_dir("snake_env_classic")
 from snake_env import SnakeEnvClassic  # noqa: E402  (reference code)
 
 
-def run_env(grid, seed, T, policy, a_seed, env_index, eps=0.1):
+def run_env(grid, seed, T, policy, a_seed, env_index, eps=0.1, max_steps=None):
     random.seed(seed)
     env = SnakeEnvClassic(grid_size=grid)
+    if max_steps is not None:
+        env.max_steps = max_steps          # the reference's own attribute (snake_env.py:47), read at :113
     obs, info = env.reset()
     obs0 = obs.copy()
     rng = np.random.default_rng([a_seed, env_index])
@@ -73,7 +75,7 @@ def run_env(grid, seed, T, policy, a_seed, env_index, eps=0.1):
     return obs0, A, O, R, TE, TR, SC, LEN, resets
 
 
-def make(name, grid, n_envs, T, policy, seed0, a_seed, eps=0.1):
+def make(name, grid, n_envs, T, policy, seed0, a_seed, eps=0.1, max_steps=None):
     obs0 = np.zeros((n_envs, grid, grid), np.int8)
     A = np.zeros((n_envs, T), np.int32)
     O = np.zeros((n_envs, T, grid, grid), np.int8)
@@ -84,7 +86,7 @@ def make(name, grid, n_envs, T, policy, seed0, a_seed, eps=0.1):
     LEN = np.zeros((n_envs, T), np.int32)
     ridx, robs = [], []
     for i in range(n_envs):
-        o0, a, o, r, te, tr, sc, ln, resets = run_env(grid, seed0 + i, T, policy, a_seed, i, eps)
+        o0, a, o, r, te, tr, sc, ln, resets = run_env(grid, seed0 + i, T, policy, a_seed, i, eps, max_steps)
         obs0[i], A[i], O[i], R[i], TE[i], TR[i], SC[i], LEN[i] = o0, a, o, r, te, tr, sc, ln
         for t, ob in resets:
             ridx.append((i, t))
@@ -92,7 +94,7 @@ def make(name, grid, n_envs, T, policy, seed0, a_seed, eps=0.1):
     out = os.path.join(common.GOLDEN, name + ".npz")
     np.savez_compressed(
         out, grid=np.int32(grid), seed0=np.int64(seed0), a_seed=np.int64(a_seed),
-        policy=np.array(policy), obs0=obs0, actions=A, obs=O, reward=R, terminated=TE,
+        policy=np.array(policy), max_steps=np.int32(1000 if max_steps is None else max_steps), obs0=obs0, actions=A, obs=O, reward=R, terminated=TE,
         truncated=TR, score=SC, length=LEN,
         reset_index=np.array(ridx, np.int32).reshape(-1, 2),
         reset_obs=np.array(robs, np.int8).reshape(-1, grid, grid),
@@ -133,3 +135,5 @@ if __name__ == "__main__":
     make("snake_g10_hash", 10, 64, 1000, "hash", seed0=0, a_seed=123)
     make("snake_g10_greedy", 10, 32, 1500, "greedy", seed0=1000, a_seed=7, eps=0.05)
     make("snake_g20_greedy", 20, 8, 1500, "greedy", seed0=5000, a_seed=9, eps=0.03)
+    # short horizon: the time limit (snake_env.py:113-114) fires every 9 steps, often on a step that also eats (:101-104)
+    make("snake_g10_short", 10, 64, 300, "greedy", seed0=7000, a_seed=11, eps=0.05, max_steps=9)

@@ -1,0 +1,124 @@
+"""BASELINE config 5 in its co-resident form: the eight env types x 131,072 instances live TOGETHER on one
+device, each on its own HIP stream, stepping concurrently.  Because seeds and the synthetic action hash follow the GLOBAL env
+index, the result of every type must (a) equal the oracle on sampled slices, (b) equal the same type run alone on the device
+(co-residency changes nothing), and (c) equal what a placement-B shard computes — a 16,384-env handle at env_index0 = r*16,384,
+which is what rank r of 8 hosts per type — so placements A and B are the same numbers."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TYPES = [("Snake", dict(grid_size=10), "SnakeOracle", (10,)), ("Crypto", dict(action_type="discrete"), "CryptoOracle", ("discrete",)),
+         ("Traffic", {}, "TrafficOracle", ()), ("Parking", {}, "ParkingOracle", ()), ("Climate", {}, "ClimateOracle", ()),
+         ("Fleet", {}, "FleetOracle", ()), ("Manufacturing", {}, "ManufacturingOracle", ()), ("Hospital", {}, "HospitalOracle", ())]
+N, K, SEED, ASEED = 1 << 17, 200, 0, 123
+
+
+def _np(t):
+    return t.cpu().numpy()
+
+
+def _obs_equal(name, dev, ref):
+    if name != "Crypto":
+        return np.array_equal(dev, ref)
+    d, r = dev.astype(np.float64), ref.astype(np.float64)
+    ok = (np.abs(d - r) <= 2e-6 + 4e-7 * np.abs(r)).all(axis=1)          # crypto's stated tolerance (tests/test_crypto_gpu.py)
+    return int((~ok).sum()) <= 1
+
+
+def test_eight_types_coresident_on_eight_streams(oracle):
+    import custom_gymnasium_environments_amd as cge
+    dev = torch.device("cuda", 0)
+    envs, streams = {}, {}
+    for name, kw, _, _ in TYPES:
+        envs[name] = getattr(cge, name + "VectorEnv")(N, autoreset_mode="SameStep", reuse_buffers=True, **kw)
+        streams[name] = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    for name in envs:                                            # every handle live before any of them steps
+        with torch.cuda.stream(streams[name]):
+            envs[name].reset(seed=SEED)
+    out = {}
+    for half in range(2):                                        # two rounds of concurrent launches: 2 x 100 fused steps per type
+        for name in envs:
+            with torch.cuda.stream(streams[name]):
+                out[name] = envs[name].rollout(K // 2, action_seed=ASEED, t0=half * (K // 2))
+    torch.cuda.synchronize()
+    co = {name: tuple(t.clone() for t in out[name]) for name in envs}
+    for e in envs.values():
+        e.close()
+    for name, kw, oname, oargs in TYPES:
+        obs_co, rs_co, dc_co = co[name]
+        # (a) oracle on the first and last 512 envs (second half's sums: the oracle is advanced through the first half)
+        for lo in (0, N - 512):
+            o = getattr(oracle, oname)(512, *oargs, oracle.SAME_STEP)
+            o.seed(np.arange(lo, lo + 512, dtype=np.uint64) + np.uint64(SEED)); o.reset()
+            o.rollout(K // 2, ASEED, t0=0, env0=lo)
+            oo, ro, do = o.rollout(K // 2, ASEED, t0=K // 2, env0=lo)
+            assert _obs_equal(name, _np(obs_co[lo:lo + 512]), oo), (name, lo)
+            assert np.array_equal(_np(dc_co[lo:lo + 512]), do), (name, lo)
+        # (b) the same type alone on the device, default stream
+        solo = getattr(cge, name + "VectorEnv")(N, autoreset_mode="SameStep", reuse_buffers=True, **kw)
+        solo.reset(seed=SEED)
+        solo.rollout(K // 2, action_seed=ASEED, t0=0)
+        obs_s, rs_s, dc_s = solo.rollout(K // 2, action_seed=ASEED, t0=K // 2)
+        assert torch.equal(obs_s, obs_co) and torch.equal(rs_s, rs_co) and torch.equal(dc_s, dc_co), name
+        solo.close()
+        # (c) placement B's shard of this type on ranks 0 and 7 of 8: 16,384 envs at env_index0 = r * 16,384
+        for r in (0, 7):
+            m = N // 8
+            shard = getattr(cge, name + "VectorEnv")(m, autoreset_mode="SameStep", env_index0=r * m, **kw)
+            shard.reset(seed=SEED)
+            shard.rollout(K // 2, action_seed=ASEED, t0=0)
+            obs_b, rs_b, dc_b = shard.rollout(K // 2, action_seed=ASEED, t0=K // 2)
+            assert torch.equal(obs_b, obs_co[r * m:(r + 1) * m]) and torch.equal(rs_b, rs_co[r * m:(r + 1) * m]), (name, r)
+            assert torch.equal(dc_b, dc_co[r * m:(r + 1) * m]), (name, r)
+            shard.close()
+
+
+def _state_words(env, cols):
+    """snapshot -> (buffer, uint32 view [cols, N, 4] of the SoA state: word w of env i is view[w // 4, i, w % 4])"""
+    buf = env.snapshot()
+    return buf, buf[32:32 + cols * env.num_envs * 16].view(np.uint32).reshape(cols, env.num_envs, 4)
+
+
+def test_hospital_overflow_flag_is_raised_not_silent():
+    """hospital.hip q_push: a patient id beyond the 12-bit record field (or a full ring) sets the sticky `overflow` info flag and
+    drops the push.  No episode the dynamics can produce gets there, so the state is injected: next_patient_id = 4094."""
+    import custom_gymnasium_environments_amd as cge
+    n, victim = 130, 77
+    env = cge.HospitalVectorEnv(n, autoreset_mode="Disabled")
+    env.reset(seed=4)
+    assert int(env.info("overflow").sum()) == 0
+    buf, w = _state_words(env, 48)
+    assert int(w[0, victim, 3] & 4095) == int(env.info("next_patient_id")[victim])
+    w[0, victim, 3] = (w[0, victim, 3] & ~np.uint32(4095)) | np.uint32(4094)
+    env.restore(buf)
+    assert int(env.info("next_patient_id")[victim]) == 4094
+    for t in range(40):
+        env.step(torch.full((n,), t % 35, dtype=torch.int32, device="cuda"))
+    flag = env.info("overflow").cpu().numpy()
+    assert flag[victim] == 1 and flag.sum() == 1
+    assert int(env.info("next_patient_id")[victim]) == 4095      # the id field never wrapped
+    env.close()
+
+
+def test_manufacturing_overflow_flag_is_raised_not_silent():
+    """manufacturing.hip _start_production: the per-episode product table has 320 rows (material bounds an episode to 312
+    starts); a start beyond it sets the sticky `overflow` flag instead of writing past the table.  Injected state: 319 products
+    already started and gone (nprod = lo = 319), then two more starts."""
+    import custom_gymnasium_environments_amd as cge
+    n, victim = 70, 33
+    env = cge.ManufacturingVectorEnv(n, autoreset_mode="Disabled")
+    env.reset(seed=4)
+    buf, w = _state_words(env, 21)
+    assert int(w[3, victim, 3]) == 0                               # nprod | lo << 10 | ncomp << 20 after a reset
+    w[3, victim, 3] = np.uint32(319 | (319 << 10))
+    env.restore(buf)
+    assert int(env.info("product_ids")[victim]) == 319
+    for t in range(3):
+        env.step(torch.zeros(n, dtype=torch.int32, device="cuda"))   # action 0: start a type-A product
+    flag = env.info("overflow").cpu().numpy()
+    assert flag[victim] == 1 and flag.sum() == 1
+    assert int(env.info("product_ids")[victim]) == 320
+    env.close()

@@ -9,9 +9,41 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-ENVS = [("Snake", dict(grid_size=10), "SnakeOracle", (10,)), ("Traffic", {}, "TrafficOracle", ()), ("Parking", {}, "ParkingOracle", ()),
+ENVS = [("Snake", dict(grid_size=10), "SnakeOracle", (10,)), ("Crypto", dict(action_type="discrete"), "CryptoOracle", ("discrete",)),
+        ("Traffic", {}, "TrafficOracle", ()), ("Parking", {}, "ParkingOracle", ()),
         ("Climate", {}, "ClimateOracle", ()), ("Fleet", {}, "FleetOracle", ()), ("Manufacturing", {}, "ManufacturingOracle", ()),
         ("Hospital", {}, "HospitalOracle", ())]
+
+# Crypto is the one float-state env with a stated tolerance (tests/test_crypto_gpu.py): obs |d| <= 2e-6 + 4e-7|x| (~3 float32 ulp),
+# reward sums |d| <= 1e-3 + 1e-7|x|; an env whose float64 trajectory left the CPU's (last place of the device log feeding the
+# psychology loop) fails its whole row — measured: none; at most ONE such env is tolerated per test and the count is printed.
+C_RTOL, C_ATOL = 4e-7, 2e-6
+
+
+def _rows_ok(name, dev, ref):
+    """per-env bool: observation rows equal (bit-exact; crypto: within the stated tolerance)"""
+    if len(dev) == 0:
+        return np.ones(0, bool)
+    dev, ref = dev.reshape(len(dev), -1), ref.reshape(len(ref), -1)
+    if name != "Crypto":
+        return (dev.view(np.uint8 if dev.dtype == np.int8 else np.uint32) == ref.view(np.uint8 if ref.dtype == np.int8 else np.uint32)).all(axis=1)
+    d, r = dev.astype(np.float64), ref.astype(np.float64)
+    return (np.abs(d - r) <= C_ATOL + C_RTOL * np.abs(r)).all(axis=1)
+
+
+def _assert_match(name, dev, ref, what=""):
+    """dev / ref = (obs, reward_sum, done_count) of a rollout (numpy)."""
+    ok = _rows_ok(name, dev[0], ref[0])
+    if name != "Crypto":
+        assert ok.all(), (what, np.argwhere(~ok)[:5])
+        assert np.array_equal(dev[1].astype(np.float64), ref[1].astype(np.float64)), what
+        assert np.array_equal(dev[2], ref[2]), what
+        return
+    bad = int((~ok).sum())
+    print(f"crypto {what}: {bad}/{len(ok)} envs outside the obs tolerance")
+    assert bad <= 1, (what, np.argwhere(~ok)[:5])
+    assert np.allclose(dev[1][ok], ref[1][ok], rtol=1e-7, atol=1e-3), what
+    assert np.array_equal(dev[2][ok], ref[2][ok]), what
 
 
 @pytest.mark.parametrize("name,kw,oname,oargs", ENVS)
@@ -22,10 +54,9 @@ def test_ragged_batches_match_oracle(oracle, name, kw, oname, oargs, n):
     o = getattr(oracle, oname)(n, *oargs, oracle.SAME_STEP)
     o.seed(np.arange(n, dtype=np.uint64) + np.uint64(5 + 77))
     od, _ = env.reset(seed=77)
-    assert np.array_equal(od.cpu().numpy(), o.reset())
+    assert _rows_ok(name, od.cpu().numpy(), o.reset()).all()
     obs, rs, dc = env.rollout(150, action_seed=9)
-    oo, ro, do = o.rollout(150, 9, env0=5)
-    assert np.array_equal(obs.cpu().numpy(), oo) and np.array_equal(rs.cpu().numpy(), ro.astype(rs.cpu().numpy().dtype)) and np.array_equal(dc.cpu().numpy(), do)
+    _assert_match(name, (obs.cpu().numpy(), rs.cpu().numpy(), dc.cpu().numpy()), o.rollout(150, 9, env0=5), f"ragged n={n}")
     env.close()
 
 
@@ -67,33 +98,108 @@ def test_bad_arguments_are_status_codes():
     env.close()
 
 
-TRAJ = [("Traffic", "TrafficOracle", 3, (9,)), ("Parking", "ParkingOracle", 8, ()), ("Fleet", "FleetOracle", 8, (3,)),
-        ("Manufacturing", "ManufacturingOracle", 25, ()), ("Hospital", "HospitalOracle", 35, ())]
+# (name, ctor kwargs incl. a SHORT time limit, oracle class, oracle args, limit, n_actions, action shape): the limit makes every
+# env type end episodes inside a short run — by its time limit as well as by its own termination rules — in every autoreset mode
+SHORT = [("Snake", dict(grid_size=10, max_steps=7), "SnakeOracle", (10,), 7, 4, ()),
+         ("Crypto", dict(action_type="discrete", max_steps=13), "CryptoOracle", ("discrete",), 13, 5, ()),
+         ("Traffic", dict(max_steps=11), "TrafficOracle", (), 11, 3, (9,)),
+         ("Parking", dict(max_steps=17), "ParkingOracle", (), 17, 8, ()),
+         ("Climate", dict(episode_minutes=9), "ClimateOracle", (), 9, None, None),
+         ("Fleet", dict(max_timesteps=15), "FleetOracle", (), 15, 8, (3,)),
+         ("Manufacturing", dict(max_steps=19), "ManufacturingOracle", (), 19, 25, ()),
+         ("Hospital", dict(max_episode_length=12), "HospitalOracle", (), 12, 35, ())]
+MODES = {"NextStep": 0, "SameStep": 1, "Disabled": 2}
+
+
+def _actions(name, rng, lead, nact, ashape):
+    if name == "Climate":
+        return rng.uniform(10, 38, lead + (1,)).astype(np.float32), rng.integers(0, 2, lead + (4,)).astype(np.int8)
+    return rng.integers(0, nact, lead + ashape).astype(np.int32)
+
+
+def _dev(a):
+    return tuple(torch.from_numpy(x).cuda() for x in a) if isinstance(a, tuple) else torch.from_numpy(a).cuda()
+
+
+def _at(a, t):
+    return tuple(x[t] for x in a) if isinstance(a, tuple) else a[t]
+
+
+def _orc_step(o, a, want_final=False):
+    return o.step(*a, want_final=want_final) if isinstance(a, tuple) else o.step(a, want_final=want_final)
 
 
 @pytest.mark.parametrize("mode", ["NextStep", "SameStep"])
-@pytest.mark.parametrize("name,oname,nact,ashape", TRAJ)
-def test_rollout_trajectory_equals_stepping_the_oracle(oracle, name, oname, nact, ashape, mode):
+@pytest.mark.parametrize("name,kw,oname,oargs,limit,nact,ashape", SHORT)
+def test_rollout_trajectory_equals_stepping_the_oracle(oracle, name, kw, oname, oargs, limit, nact, ashape, mode):
     """rollout(trajectory=True, per_step=True) with explicit actions: every step's obs, reward and flags equal the oracle
-    stepped with the same actions (the obs_step_stride / per-step output paths of the fused kernels)."""
+    stepped with the same actions (the obs_step_stride / per-step output paths of the fused kernels), with the DEFAULT time
+    limit and with a short one (episodes end and auto-reset inside the trajectory)."""
     import custom_gymnasium_environments_amd as cge
-    code = {"NextStep": oracle.NEXT_STEP, "SameStep": oracle.SAME_STEP}[mode]
     n, K = 150, 160
-    env = getattr(cge, name + "VectorEnv")(n, autoreset_mode=mode, env_index0=2)
-    o = getattr(oracle, oname)(n, code)
-    o.seed(np.arange(n, dtype=np.uint64) + np.uint64(2 + 41))
-    env.reset(seed=41); o.reset()
-    acts = np.random.default_rng(nact).integers(0, nact, (K, n) + ashape).astype(np.int32)
-    obs, rt, tt, rs, dc = env.rollout(K, actions=torch.from_numpy(acts).cuda(), trajectory=True, per_step=True)
-    obs, rt, tt = obs.cpu().numpy(), rt.cpu().numpy(), tt.cpu().numpy()
-    for t in range(K):
-        oo, ro, teo, tro = o.step(acts[t])
-        assert np.array_equal(obs[t].view(np.uint32), oo.view(np.uint32)), (t, np.argwhere(obs[t] != oo)[:5])
-        assert np.array_equal(rt[t], ro), t
-        if tt.dtype == np.bool_:                                   # envs that never truncate report terminated only
-            assert np.array_equal(tt[t], teo.astype(bool)) and not tro.any(), t
-        else:                                                      # terminated | truncated << 1
-            assert np.array_equal(tt[t].astype(np.uint8), teo.astype(np.uint8) | (tro.astype(np.uint8) << 1)), t
+    for short in (False, True):
+        ekw = dict(kw) if short else {k: v for k, v in kw.items() if k in ("grid_size", "action_type")}
+        env = getattr(cge, name + "VectorEnv")(n, autoreset_mode=mode, env_index0=2, **ekw)
+        o = getattr(oracle, oname)(n, *oargs, MODES[mode], max_steps=limit if short else None)
+        o.seed(np.arange(n, dtype=np.uint64) + np.uint64(2 + 41))
+        env.reset(seed=41); o.reset()
+        acts = _actions(name, np.random.default_rng(7), (K, n), nact, ashape)
+        obs, rt, tt, rs, dc = env.rollout(K, actions=_dev(acts), trajectory=True, per_step=True)
+        obs, rt, tt = obs.cpu().numpy(), rt.cpu().numpy(), tt.cpu().numpy()
+        ndone = 0
+        for t in range(K):
+            oo, ro, teo, tro = _orc_step(o, _at(acts, t))
+            ok = _rows_ok(name, obs[t], oo)
+            assert ok.all(), (short, t, np.argwhere(~ok)[:5])
+            if name == "Crypto":
+                assert np.allclose(rt[t], ro, rtol=1e-6, atol=1e-3), (short, t)
+            else:
+                assert np.array_equal(rt[t], ro), (short, t)
+            if tt.dtype == np.bool_:                                   # envs that never truncate report terminated only
+                assert np.array_equal(tt[t], teo.astype(bool)) and not tro.any(), (short, t)
+            else:                                                      # terminated | truncated << 1
+                assert np.array_equal(tt[t].astype(np.uint8), teo.astype(np.uint8) | (tro.astype(np.uint8) << 1)), (short, t)
+            ndone += int((teo | tro).sum())
+        assert not short or ndone >= n * (K // (limit + 1) - 1)           # the limit really fired, many times per env
+        env.close()
+
+
+@pytest.mark.parametrize("mode", ["NextStep", "SameStep", "Disabled"])
+@pytest.mark.parametrize("name,kw,oname,oargs,limit,nact,ashape", SHORT)
+def test_short_time_limit_step_api_all_modes(oracle, name, kw, oname, oargs, limit, nact, ashape, mode):
+    """step() with a short time limit, every autoreset mode: obs, reward, both flags and (SameStep) the final_obs rows equal
+    the oracle's; then a fused hash-action rollout on top (the in-kernel auto-reset at the limit).  Covers the config
+    fields max_steps / episode_minutes / max_timesteps / max_episode_length, which the default-horizon tests never vary."""
+    import custom_gymnasium_environments_amd as cge
+    n, T = 257, 4 * limit + 5
+    env = getattr(cge, name + "VectorEnv")(n, autoreset_mode=mode, env_index0=3, **kw)
+    o = getattr(oracle, oname)(n, *oargs, MODES[mode], max_steps=limit)
+    o.seed(np.arange(n, dtype=np.uint64) + np.uint64(3 + 17))
+    od, _ = env.reset(seed=17)
+    assert _rows_ok(name, od.cpu().numpy(), o.reset()).all()
+    rng = np.random.default_rng(limit)
+    same = mode == "SameStep"
+    for t in range(T):
+        a = _actions(name, rng, (n,), nact, ashape)
+        od, rd, ted, trd, info = env.step(_dev(a))
+        res = _orc_step(o, a, want_final=same)
+        oo, ro, teo, tro = res[:4]
+        ok = _rows_ok(name, od.cpu().numpy(), oo)
+        assert ok.all(), (t, np.argwhere(~ok)[:5])
+        if name == "Crypto":
+            assert np.allclose(rd.cpu().numpy(), ro, rtol=1e-6, atol=1e-3), t
+        else:
+            assert np.array_equal(rd.cpu().numpy(), ro), t
+        assert np.array_equal(ted.cpu().numpy(), teo.astype(bool)) and np.array_equal(trd.cpu().numpy(), tro.astype(bool)), t
+        if same:
+            done = (teo | tro).astype(bool)
+            assert np.array_equal(info["_final_obs"].cpu().numpy(), done), t
+            assert _rows_ok(name, info["final_obs"].cpu().numpy()[done], res[4][done]).all(), t
+    if mode != "Disabled":
+        obs, rs, dc = env.rollout(6 * limit, action_seed=21, t0=T)
+        ref = o.rollout(6 * limit, 21, t0=T, env0=3)
+        _assert_match(name, (obs.cpu().numpy(), rs.cpu().numpy(), dc.cpu().numpy()), ref, "short-limit rollout")
+        assert ref[2].min() >= 3
     env.close()
 
 
@@ -109,15 +215,16 @@ def test_partial_reset_mask_matches_oracle(oracle, name, kw, oname, oargs):
     mask = np.random.default_rng(2).random(n) < 0.35
     od, _ = env.reset(options={"reset_mask": torch.from_numpy(mask.astype(np.uint8)).cuda()})
     oo = o.reset(mask.astype(np.uint8))
-    assert np.array_equal(od.cpu().numpy(), oo), np.argwhere(od.cpu().numpy() != oo)[:5]
+    ok = _rows_ok(name, od.cpu().numpy(), oo)
+    assert ok.all(), np.argwhere(~ok)[:5]
     obs, rs, dc = env.rollout(60, action_seed=6, t0=90)
-    o2, r2, d2 = o.rollout(60, 6, t0=90)
-    assert np.array_equal(obs.cpu().numpy(), o2) and np.array_equal(dc.cpu().numpy(), d2)
+    _assert_match(name, (obs.cpu().numpy(), rs.cpu().numpy(), dc.cpu().numpy()), o.rollout(60, 6, t0=90), "after a masked reset")
     env.close()
 
 
 @pytest.mark.parametrize("name,kw,oname,oargs,big", [
     ("Snake", dict(grid_size=10), "SnakeOracle", (10,), True), ("Traffic", {}, "TrafficOracle", (), True),
+    ("Crypto", dict(action_type="discrete"), "CryptoOracle", ("discrete",), False),      # np.random.seed takes 32 bits
     ("Parking", {}, "ParkingOracle", (), True), ("Hospital", {}, "HospitalOracle", (), True),
     ("Climate", {}, "ClimateOracle", (), True), ("Manufacturing", {}, "ManufacturingOracle", (), True),
     ("Fleet", {}, "FleetOracle", (), False)])
@@ -134,10 +241,9 @@ def test_per_env_seed_lists(oracle, name, kw, oname, oargs, big):
     o = getattr(oracle, oname)(n, *oargs, oracle.SAME_STEP)
     o.seed(seeds)
     od, _ = env.reset(seed=[int(s) for s in seeds])
-    assert np.array_equal(od.cpu().numpy(), o.reset())
+    assert _rows_ok(name, od.cpu().numpy(), o.reset()).all()
     obs, rs, dc = env.rollout(80, action_seed=2)
-    oo, ro, do = o.rollout(80, 2)
-    assert np.array_equal(obs.cpu().numpy(), oo) and np.array_equal(dc.cpu().numpy(), do)
+    _assert_match(name, (obs.cpu().numpy(), rs.cpu().numpy(), dc.cpu().numpy()), o.rollout(80, 2), "per-env seeds")
     env.close()
 
 
@@ -153,8 +259,6 @@ def test_multi_episode_soak(oracle, name, kw, oname, oargs):
     o.seed(np.arange(n, dtype=np.uint64) + np.uint64(11 + 9)); env.reset(seed=9); o.reset()
     for seg in range(4):                                            # four calls: the cursor / state hand-over between launches too
         obs, rs, dc = env.rollout(T // 4, action_seed=13, t0=seg * (T // 4))
-        oo, ro, do = o.rollout(T // 4, 13, t0=seg * (T // 4), env0=11)
-        assert np.array_equal(obs.cpu().numpy(), oo), (seg, np.argwhere(obs.cpu().numpy() != oo)[:5])
-        assert np.array_equal(dc.cpu().numpy(), do) and np.array_equal(rs.cpu().numpy().astype(np.float64), ro.astype(np.float64)), seg
+        _assert_match(name, (obs.cpu().numpy(), rs.cpu().numpy(), dc.cpu().numpy()), o.rollout(T // 4, 13, t0=seg * (T // 4), env0=11), f"soak segment {seg}")
     assert dc.sum() > 0
     env.close()

@@ -12,7 +12,7 @@ def _replay(oracle, fx, mode):
     grid = int(fx["grid"])
     A = fx["actions"]
     n, T = A.shape
-    o = oracle.SnakeOracle(n, grid, mode)
+    o = oracle.SnakeOracle(n, grid, mode, max_steps=int(fx["max_steps"]))
     o.seed(np.arange(n, dtype=np.uint64) + np.uint64(int(fx["seed0"])))
     obs0 = o.reset()
     assert np.array_equal(obs0, fx["obs0"])
@@ -20,7 +20,8 @@ def _replay(oracle, fx, mode):
     return o, A, n, T, reset_at
 
 
-@pytest.mark.parametrize("name", ["snake_g10_hash.npz", "snake_g10_greedy.npz", "snake_g20_greedy.npz"])
+# snake_g10_short: max_steps=9, so the time limit (snake_env.py:113-114) often fires on a step that also eats (:101-104, 228 times)
+@pytest.mark.parametrize("name", ["snake_g10_hash.npz", "snake_g10_greedy.npz", "snake_g20_greedy.npz", "snake_g10_short.npz"])
 def test_same_step_autoreset_matches_reference(oracle, name):
     fx = golden(name)
     o, A, n, T, reset_at = _replay(oracle, fx, oracle.SAME_STEP)
@@ -40,8 +41,9 @@ def test_same_step_autoreset_matches_reference(oracle, name):
         assert np.array_equal(o.info(1)[~done], fx["length"][:, t][~done])
 
 
-def test_next_step_autoreset_matches_reference(oracle):
-    fx = golden("snake_g10_hash.npz")
+@pytest.mark.parametrize("name", ["snake_g10_hash.npz", "snake_g10_short.npz"])
+def test_next_step_autoreset_matches_reference(oracle, name):
+    fx = golden(name)
     o, A, n, T, reset_at = _replay(oracle, fx, oracle.NEXT_STEP)
     O, R, TE = fx["obs"], fx["reward"], fx["terminated"]
     # in NEXT_STEP mode an env consumes one extra step() per episode; keep a per-env cursor

@@ -22,13 +22,14 @@ def _np(t):
     return t.cpu().numpy()
 
 
-@pytest.mark.parametrize("name", ["snake_g10_hash.npz", "snake_g10_greedy.npz", "snake_g20_greedy.npz"])
+# snake_g10_short: max_steps=9 — the time limit often fires on a step that also eats (two food placements in one SameStep step)
+@pytest.mark.parametrize("name", ["snake_g10_hash.npz", "snake_g10_greedy.npz", "snake_g20_greedy.npz", "snake_g10_short.npz"])
 def test_same_step_matches_reference_fixture(cge, name):
     fx = golden(name)
     grid = int(fx["grid"])
     A = fx["actions"]
     n, T = A.shape
-    env = cge.SnakeVectorEnv(n, grid_size=grid, autoreset_mode="SameStep")
+    env = cge.SnakeVectorEnv(n, grid_size=grid, autoreset_mode="SameStep", max_steps=int(fx["max_steps"]))
     obs, _ = env.reset(seed=int(fx["seed0"]))
     assert np.array_equal(_np(obs), fx["obs0"])
     reset_at = {(int(i), int(t)): k for k, (i, t) in enumerate(fx["reset_index"])}
