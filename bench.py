@@ -8,21 +8,30 @@ instance on the GPU, the full observation / reward / flags written to HBM.  Defa
 configs[1]: SnakeEnv 10x10, 1,048,576 parallel envs per GPU (weak scaling: per-GPU batch fixed, global env
 indices sharded contiguously, no collective on the data path).  Two paths are measured in every run:
 
-  rollout (headline `value`)  the K timed steps fused in ONE launch per GPU — the K-steps-per-launch entry point
-                              SURVEY.md section 7 / BASELINE.md section 3 prescribe for the roofline target: env state
-                              stays in registers, the observation is still written to HBM every step, actions come
-                              from the device-side counter hash (cge_hash_action);
+  rollout (headline `value`)  the K timed steps fused, kc steps per launch (kc = K unless the [kc, N, obs] trajectory would
+                              exceed --traj-gib): env state stays in registers, and EVERY step's observation, reward and
+                              flag is written to its own place in HBM — a [kc, N, *obs] trajectory plus [kc, N] reward /
+                              flag arrays, tens of GB, so no byte is absorbed by rewriting a cache-resident buffer; actions
+                              come from the device-side counter hash (cge_hash_action);
   step   (`api_step` block)   K separate C-ABI step() calls through the VectorEnv facade with HBM-resident
                               actions — what a gymnasium.vector consumer calls.
 
-`--path step` makes the API path the headline instead.  Prints ONE JSON line on rank 0 carrying `roofline` for
-the dominant kernel (algorithmic bytes of SURVEY 8d / HIP-event time on the launch stream; `traffic` = HBM bytes
-per launch from the committed rocprofv3 PMC passes, profiles/traffic.json) and `cpu_baseline` (the oracle's C
-port of the reference on this box's host cores: reported, not the target).
+`--path step` makes the API path the headline instead.  `--gpus N` with N > 1 and no launcher environment starts the N ranks
+itself (fresh child processes, before anything touches the GPU) and relays rank 0's line.  Prints ONE JSON line on rank 0
+carrying `roofline` for the dominant kernel and `cpu_baseline` (the oracle's C port of the reference on this box's host
+cores: reported, not the target).  roofline fields:
+  achieved     bytes the timed kernel is OBLIGED to move per launch (`algorithmic_bytes_per_env_step` x env-steps per launch)
+               / average launch time (HIP events on the launch stream); step(): SURVEY 8d's per-step figure; fused rollout:
+               the same figure minus the state that legitimately stays in registers and the action read
+  traffic      HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/traffic.json,
+               2*FETCH_SIZE + WRITE_SIZE per env-step x env-steps per launch); frac_moved = traffic / time / peak
+  peak         8 TB/s (spec); peak_measured = this box's device-to-device copy bandwidth measured in this run
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -34,27 +43,34 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
-# algorithmic bytes per env-step (secondary envs: obs + actions + reward/flags + 2 x state + RNG)
+# Bytes per env-step.  algo = SURVEY.md 8d's figure for one step() call (secondary envs: obs + actions + reward /
+# flags + 2 x state + RNG).  The fused rollout is priced on what IT must move: obs + reward (4) + flag (1) + stream (generator
+# words and tables that live in HBM even inside a fused launch) + 2 x the state that is NOT register-resident, plus the resident
+# record once per launch (2 x resident / kc); it reads no actions (device-side hash).
 ENVS = {
-    "snake":   dict(algo=145,  n_act=4, act_shape=(),   dtype="i8",   step_kernel="cge::snake::step_kernel<10, 256, 1, 8>",
-                    roll_kernel="cge::snake::rollout_kernel<10, 256, 1, 8>", ref_py="3.4e5-4.2e5 steps/s/process"),
-    "crypto":  dict(algo=2346, n_act=5, act_shape=(),   dtype="f64",  step_kernel="cge::crypto::step_kernel<false>",
-                    roll_kernel="cge::crypto::step_kernel<true>", ref_py="1.64e3-1.68e3 steps/s/process"),
-    "traffic": dict(algo=1134, n_act=3, act_shape=(9,), dtype="int32", step_kernel="cge::traffic::step_kernel<false>",
-                    roll_kernel="cge::traffic::step_kernel<true>", ref_py="1.75e3-1.90e3 steps/s/process"),
-    "parking": dict(algo=662,  n_act=8, act_shape=(),   dtype="f64",  step_kernel="cge::parking::step_kernel<false>",
-                    roll_kernel="cge::parking::step_kernel<true>", ref_py="2.66e4 steps/s/process"),
-    "climate": dict(algo=218,  n_act=None, act_shape=None, dtype="f64", step_kernel="cge::climate::step_kernel<false>",
-                    roll_kernel="cge::climate::step_kernel<true>", ref_py="1.27e4 steps/s/process"),
-    "fleet":   dict(algo=642,  n_act=8, act_shape=(3,), dtype="f64",  step_kernel="cge::fleet::step_kernel + cge::fleet::dense_kernel",
+    "snake":   dict(algo=145,  obs=100, state=48, resident=48, stream=0, n_act=4, act_shape=(),   dtype="i8",
+                    step_kernel="cge::snake::step_kernel<10, 256, 1, 8>", roll_kernel="cge::snake::rollout_kernel<10, 256, 1, 8>",
+                    ref_py="3.4e5-4.2e5 steps/s/process"),
+    "crypto":  dict(algo=2346, obs=1044, state=64, resident=64, stream=1164, n_act=5, act_shape=(),   dtype="f64",
+                    step_kernel="cge::crypto::step_kernel<false>", roll_kernel="cge::crypto::step_kernel<true>", ref_py="1.64e3-1.68e3 steps/s/process"),
+    "traffic": dict(algo=1134, obs=520, state=240, resident=240, stream=60, n_act=3, act_shape=(9,), dtype="int32",
+                    step_kernel="cge::traffic::step_kernel<false>", roll_kernel="cge::traffic::step_kernel<true>", ref_py="1.75e3-1.90e3 steps/s/process"),
+    "parking": dict(algo=662,  obs=52, state=288, resident=288, stream=24, n_act=8, act_shape=(),   dtype="f64",
+                    step_kernel="cge::parking::step_kernel<false>", roll_kernel="cge::parking::step_kernel<true>", ref_py="2.66e4 steps/s/process"),
+    "climate": dict(algo=218,  obs=36, state=80, resident=80, stream=0, n_act=None, act_shape=None, dtype="f64",
+                    step_kernel="cge::climate::step_kernel<false>", roll_kernel="cge::climate::step_kernel<true>", ref_py="1.27e4 steps/s/process"),
+    # fleet's rollout is K (step, dense) launch pairs: the record goes through HBM every step
+    "fleet":   dict(algo=642,  obs=304, state=160, resident=0, stream=0, n_act=8, act_shape=(3,), dtype="f64",
+                    step_kernel="cge::fleet::step_kernel + cge::fleet::dense_kernel",
                     roll_kernel="cge::fleet::step_kernel + cge::fleet::dense_kernel", launches_per_step=True, ref_py="2.01e4 steps/s/process"),
+    # 972 obs + 2 x 768 state + action/reward/flags + ~70 MT19937 words read and written per step (2 x 280); only the 96-byte
+    # MISC group stays in registers across fused steps, the doctor / nurse / bed / equipment groups are re-loaded per step
+    "hospital": dict(algo=3078, obs=972, state=768, resident=96, stream=560, n_act=35, act_shape=(), dtype="f64",
+                     step_kernel="cge::hosp::step_kernel<false>", roll_kernel="cge::hosp::step_kernel<true>", ref_py="not in BASELINE.md"),
     # 292 obs + 2 x 336 state + action/reward/flags; plus 10 bytes (quality f64 + meta u16) per product in the system, which the
     # per-type np.mean of the observation has to read every step: added from the measured mean occupancy (algo_per_product)
-    # 972 obs + 2 x 768 state + action/reward/flags + ~70 MT19937 words read and written per step (2 x 280)
-    "hospital": dict(algo=3078, n_act=35, act_shape=(), dtype="f64", step_kernel="cge::hosp::step_kernel<false>",
-                     roll_kernel="cge::hosp::step_kernel<true>", ref_py="not in BASELINE.md"),
-    "manufacturing": dict(algo=974, algo_per_product=10, n_act=25, act_shape=(), dtype="f64", step_kernel="cge::mfg::step_kernel<false>",
-                          roll_kernel="cge::mfg::step_kernel<true>", ref_py="not in BASELINE.md"),
+    "manufacturing": dict(algo=974, algo_per_product=10, obs=292, state=336, resident=336, stream=0, n_act=25, act_shape=(), dtype="f64",
+                          step_kernel="cge::mfg::step_kernel<false>", roll_kernel="cge::mfg::step_kernel<true>", ref_py="not in BASELINE.md"),
 }
 WORKLOADS = {
     "snake_1m": dict(env="snake", n=1 << 20, desc="SnakeEnv 10x10, 1,048,576 parallel envs per GPU, random actions, fused auto-reset"),
@@ -72,6 +88,16 @@ WORKLOADS = {
     "hetero_131k": dict(env="hetero", n=1 << 17,
                         desc="heterogeneous batch: every implemented env type x 131,072, co-resident on each GPU, one HIP stream per type"),
 }
+
+
+def roll_algo(name, kc, occupancy=0.0):
+    s = ENVS[name]
+    return (s["obs"] + 4 + 1 + s["stream"] + 2 * (s["state"] - s["resident"]) + 2.0 * s["resident"] / max(kc, 1)
+            + s.get("algo_per_product", 0) * occupancy)
+
+
+def step_algo(name, occupancy=0.0):
+    return ENVS[name]["algo"] + ENVS[name].get("algo_per_product", 0) * occupancy
 
 
 def make_env(cge, name, n, dev, env0):
@@ -93,6 +119,8 @@ def make_actions(name, steps, n, dev):
 
 
 def act_at(name, actions, t):
+    if actions is None:                                  # dry run
+        return None
     return (actions[0][t], actions[1][t]) if name == "climate" else actions[t]
 
 
@@ -146,21 +174,119 @@ def cpu_baseline(name, budget_s=12.0):
 
 
 def pmc_traffic(kernel):
+    """bytes per env-step of `kernel` from the committed PMC passes (tools/profile.sh -> profiles/traffic.json), or None"""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            return json.load(f).get(kernel)
-    except (OSError, ValueError):
+            rec = json.load(f).get(kernel)
+        return float(rec["bytes_per_env_step"]) if isinstance(rec, dict) else None
+    except (OSError, ValueError, KeyError, TypeError):
         return None
 
 
-def roofline(name, kernel, gpu_ms, launches, steps_per_launch, n, occupancy=0.0):
-    algo = ENVS[name]["algo"] + ENVS[name].get("algo_per_product", 0) * occupancy
+def measure_copy_bandwidth(dev):
+    """The second roofline denominator SURVEY 8d asks for: this box's device-to-device copy bandwidth (bytes read + bytes
+    written per second) and its pure-store rate, measured here with torch on 2-GiB buffers."""
+    x = torch.empty(1 << 29, dtype=torch.float32, device=dev)
+    y = torch.empty_like(x)
+
+    def t(fn, reps=8):
+        fn()
+        torch.cuda.synchronize(dev)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize(dev)
+        return a.elapsed_time(b) / reps * 1e-3
+    gb = x.numel() * 4 / 1e9
+    out = {"copy_GBs": 2 * gb / t(lambda: y.copy_(x)), "fill_GBs": gb / t(lambda: x.fill_(1.0))}
+    del x, y
+    torch.cuda.empty_cache()
+    return out
+
+
+def roofline(name, path, kernel, gpu_ms, launches, steps_per_launch, n, occupancy, measured):
+    algo = roll_algo(name, steps_per_launch, occupancy) if path == "rollout" and not ENVS[name].get("launches_per_step") else \
+        (roll_algo(name, 1, occupancy) if path == "rollout" else step_algo(name, occupancy))
     launch_s = gpu_ms * 1e-3 / launches
-    achieved = algo * n * steps_per_launch / launch_s / 1e9
-    return {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic(kernel) if steps_per_launch == 1 else None, "algorithmic_bytes_per_env_step": algo,
-            "env_steps_per_launch": n * steps_per_launch, "avg_launch_us": launch_s * 1e6,
-            "timing": "HIP events on the launch stream over the timed region"}
+    env_steps = n * steps_per_launch
+    achieved = algo * env_steps / launch_s / 1e9
+    per_step = pmc_traffic(kernel)
+    r = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+         "traffic": per_step * env_steps if per_step is not None else None,
+         "traffic_bytes_per_env_step": per_step,
+         "frac_moved": (per_step * env_steps / launch_s / 1e9 / HBM_PEAK_GBS) if per_step is not None else None,
+         "traffic_over_algorithmic": (per_step / algo) if per_step is not None else None,
+         "algorithmic_bytes_per_env_step": algo, "env_steps_per_launch": env_steps, "avg_launch_us": launch_s * 1e6,
+         "timing": "HIP events on the launch stream over the timed region",
+         "algorithmic_note": ("fused rollout: obs + reward + flag + generator/table stream + non-resident state, resident record once per launch"
+                              if path == "rollout" else "SURVEY 8d per-step figure")}
+    if measured:
+        r["peak_measured"] = measured["copy_GBs"]
+        r["frac_of_measured"] = achieved / measured["copy_GBs"]
+        r["peak_measured_note"] = (f"device-to-device copy_ of 2 GiB on this box (read + written bytes / s); pure fill_ "
+                                   f"{measured['fill_GBs']:.0f} GB/s")
+    return r
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: the parent starts the ranks itself, as fresh processes, before it makes any GPU call
+def self_launch(n_ranks):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
+    out0 = procs[0].communicate()[0]
+    rcs = [procs[0].returncode]
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:           # rank 0 is done and a sibling is not: end exactly that child
+            p.kill()
+            rcs.append(p.wait())
+    lines = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    for ln in (out0 or "").splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if any(rcs) or not lines:
+        sys.stderr.write(f"bench.py: rank exit codes {rcs}\n")
+        sys.exit(max([abs(rc) for rc in rcs if rc] + [1]))
+    print(lines[-1], flush=True)
+    sys.exit(0)
+
+
+class _DryEnv:
+    """CGE_BENCH_DRYRUN=1 stand-in for an env handle: no device, no work.  It exists so the N > 1 control flow (self-launch,
+    rendezvous, barriers, max-over-ranks, rank-0 JSON) can be exercised by a CPU test; a dry run's numbers mean nothing and
+    its line says so."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def reset(self, seed=None):
+        return None
+
+    def rollout(self, k, **kw):
+        time.sleep(1e-4 * k)
+
+    def step(self, a):
+        time.sleep(1e-4)
+
+    def info(self, f):
+        return torch.zeros(1)
+
+    def invalid_action_count(self):
+        return 0
+
+    def close(self):
+        pass
 
 
 def main():
@@ -170,23 +296,30 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="snake_1m", choices=sorted(WORKLOADS))
     ap.add_argument("--path", default="rollout", choices=["rollout", "step"])
+    ap.add_argument("--traj-gib", type=float, default=24.0, help="cap on the per-env-type trajectory buffer of the rollout leg")
+    ap.add_argument("--manifest", default=None, help="write {kernel: env-steps launched} here (tools/profile.sh uses it to turn PMC bytes into bytes per env-step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args.gpus)                       # never returns
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                     "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
-        args.gpus = world
+    args.gpus = world
+    dry = os.environ.get("CGE_BENCH_DRYRUN") == "1"
     # CGE_BENCH_REHEARSAL=1: rehearse the N>1 control flow on a box with fewer GPUs than ranks (ranks share devices, gloo
     # instead of RCCL).  Only for checking the launch / barrier / reduction logic; its numbers mean nothing.
-    rehearsal = os.environ.get("CGE_BENCH_REHEARSAL") == "1" and torch.cuda.device_count() < world
-    if rehearsal:
-        local_rank = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
+    rehearsal = dry or (os.environ.get("CGE_BENCH_REHEARSAL") == "1" and torch.cuda.device_count() < world)
+    if not dry:
+        if torch.cuda.device_count() == 0:
+            sys.exit("bench.py needs an MI355X (no HIP device visible); there is no CPU path")
+        if rehearsal:
+            local_rank = local_rank % torch.cuda.device_count()
+        elif local_rank >= torch.cuda.device_count():
+            sys.exit(f"rank {rank}: --gpus {world} but only {torch.cuda.device_count()} device(s) visible")
+        torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -196,10 +329,9 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    import custom_gymnasium_environments_amd as cge
     wl = WORKLOADS[args.workload]
     n, K, W = wl["n"], args.steps, args.warmup
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cpu") if dry else torch.device("cuda", local_rank)
     if wl["env"] == "hetero":
         names = sorted(ENVS)
     elif wl["env"] == "hetero_split":                               # placement A: type k lives on rank k % world, whole (131,072 envs)
@@ -207,31 +339,65 @@ def main():
     else:
         names = [wl["env"]]
     split = wl["env"] == "hetero_split"
-    envs = {nm: make_env(cge, nm, n, dev, 0 if split else rank * n) for nm in names}
-    if len(names) > 1:
-        streams = {nm: torch.cuda.Stream(device=dev) for nm in names}
+    if dry:
+        envs = {nm: _DryEnv(n) for nm in names}
+        streams = {nm: None for nm in names}
     else:
-        streams = {names[0]: torch.cuda.current_stream(dev)}
+        import custom_gymnasium_environments_amd as cge
+        envs = {nm: make_env(cge, nm, n, dev, 0 if split else rank * n) for nm in names}
+        if len(names) > 1:
+            streams = {nm: torch.cuda.Stream(device=dev) for nm in names}
+        else:
+            streams = {names[0]: torch.cuda.current_stream(dev)}
     for e in envs.values():
         e.reset(seed=0)
-    torch.cuda.synchronize()
+
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
 
     def barrier():
-        torch.cuda.synchronize()
+        sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
-    def run_rollout(k, t0):
+    class on_stream:                                     # `with on_stream(nm):` = torch.cuda.stream(...) or nothing in a dry run
+        def __init__(self, nm):
+            self.cm = None if dry else torch.cuda.stream(streams[nm])
+
+        def __enter__(self):
+            return self.cm.__enter__() if self.cm else None
+
+        def __exit__(self, *a):
+            return self.cm.__exit__(*a) if self.cm else False
+
+    # rollout leg: kc steps per launch, every step's obs / reward / flag to its own place in a [kc, N, ...] trajectory
+    budget = args.traj_gib * (1 << 30) / (1 if len(names) == 1 else 4)
+    kc = {nm: max(1, min(K, int(budget // (n * ENVS[nm]["obs"])))) for nm in names}
+    launched = {}                                        # kernel name -> env-steps launched (for --manifest)
+
+    def count(nm, path, steps):
+        kern = ENVS[nm]["roll_kernel" if path == "rollout" else "step_kernel"]
+        launched[kern] = launched.get(kern, 0) + n * steps
+
+    def run_rollout(k_total, t0):
         for nm in names:
-            with torch.cuda.stream(streams[nm]):
-                envs[nm].rollout(k, action_seed=123, t0=t0)
+            with on_stream(nm):
+                done = 0
+                while done < k_total:
+                    k = min(kc[nm], k_total - done)
+                    envs[nm].rollout(k, action_seed=123, t0=t0 + done, trajectory=True, per_step=True)
+                    done += k
+                count(nm, "rollout", k_total)
 
     def run_steps(actions, lo, hi):
         for t in range(lo, hi):
             for nm in names:
-                with torch.cuda.stream(streams[nm]):
+                with on_stream(nm):
                     envs[nm].step(act_at(nm, actions[nm], t))
+        for nm in names:
+            count(nm, "step", hi - lo)
 
     occupancy = {}
 
@@ -241,27 +407,39 @@ def main():
     def timed(fn, tag=None):
         before = mean_occupancy()
         barrier()
-        evs = {nm: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for nm in names}
+        evs = {}
+        if not dry:
+            evs = {nm: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for nm in names}
         t0 = time.perf_counter()
-        for nm in names:
+        for nm in evs:
             evs[nm][0].record(streams[nm])          # on the stream the kernels are launched on
         fn()
-        for nm in names:
+        for nm in evs:
             evs[nm][1].record(streams[nm])
         barrier()
         wall = time.perf_counter() - t0
         after = mean_occupancy()
         occupancy[tag] = {nm: 0.5 * (before[nm] + after[nm]) for nm in before}
-        return wall, {nm: evs[nm][0].elapsed_time(evs[nm][1]) for nm in names}
+        return wall, {nm: (evs[nm][0].elapsed_time(evs[nm][1]) if evs else wall * 1e3) for nm in names}
 
+    sync()
     results = {}
-    run_rollout(max(W, 1), 0)                                        # fused rollout: K steps in one launch per env type
-    results["rollout"] = timed(lambda: run_rollout(K, W), "rollout")
-    actions = {nm: make_actions(nm, K + W, n, dev) for nm in names}  # API path: K step() calls, HBM-resident actions
+    run_rollout(max(W, 1), 0)                                        # warm-up (also allocates the trajectory buffers)
+    results["rollout"] = timed(lambda: run_rollout(K, max(W, 1)), "rollout")
+    if not dry:
+        for e in envs.values():                                      # the trajectory buffers are not needed by the API leg
+            e._bufs.pop("traj", None)
+        torch.cuda.empty_cache()
+    actions = {nm: (None if dry else make_actions(nm, K + W, n, dev)) for nm in names}  # API path: K step() calls, HBM-resident actions
     run_steps(actions, 0, W)
     results["step"] = timed(lambda: run_steps(actions, W, W + K), "step")
     if "snake" in envs:
         assert envs["snake"].invalid_action_count() == 0
+    measured = None
+    if not dry and rank == 0:
+        del actions
+        torch.cuda.empty_cache()
+        measured = measure_copy_bandwidth(dev)
 
     def reduce_max(x):
         t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearsal else dev)
@@ -282,7 +460,8 @@ def main():
                 kern = ENVS[nm]["roll_kernel" if path == "rollout" else "step_kernel"]
                 # fleet's rollout is K (step, dense) launch pairs, not one fused launch: price it per pair
                 fused = path == "rollout" and not ENVS[nm].get("launches_per_step")
-                rl[nm] = roofline(nm, kern, gpu_ms[nm], 1 if fused else K, K if fused else 1, n, occupancy[path].get(nm, 0.0))
+                launches = -(-K // kc[nm]) if fused else K
+                rl[nm] = roofline(nm, path, kern, gpu_ms[nm], launches, K / launches, n, occupancy[path].get(nm, 0.0), measured)
             b["roofline"] = rl[names[0]] if len(names) == 1 else rl
             return b
 
@@ -293,19 +472,27 @@ def main():
             "ms_per_step": hb["ms_per_step"], "higher_is_better": True, "scaling": "strong" if split else "weak", "vs_baseline": None,
             "dtype": ENVS[names[0]]["dtype"] if len(names) == 1 else "mixed", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {wl['desc']}", "envs_per_gpu": n * len(names), "env_types": names,
-                       "path": (("rollout: K (step, dense-reset) launch pairs queued by one C-ABI call, obs written to HBM every step, device-side action hash"
+                       "path": (("rollout: K (step, dense-reset) launch pairs queued by one C-ABI call, every step's obs / reward / flag written to "
+                                 "its own slot of a [K, N, ...] trajectory in HBM, device-side action hash"
                                  if all(ENVS[nm].get("launches_per_step") for nm in names) else
-                                 "fused rollout: the K steps in one launch per GPU, obs written to HBM every step, device-side action hash")
+                                 f"fused rollout: {kc[names[0]]} steps per launch, every step's obs / reward / flag written to its own slot of a "
+                                 f"[{kc[names[0]]}, N, ...] trajectory in HBM, device-side action hash")
                                 if head == "rollout" else "K C-ABI step() calls through the VectorEnv facade, HBM-resident actions"),
                        "autoreset": "SameStep", "parallelism": f"env-sharded x{world}, no data-path collective"},
             "roofline": hb["roofline"] if len(names) == 1 else hb["roofline"].get("snake", hb["roofline"][names[0]]),
         }
+        if dry:
+            out["data"] = "DRY RUN (CGE_BENCH_DRYRUN=1): no device work, numbers are meaningless"
+            out["roofline"] = None
         if len(names) > 1:
             out["roofline_per_env_type"] = hb["roofline"]
         out["api_step" if other == "step" else "fused_rollout"] = block(other)
-        if not args.no_cpu_baseline and world == 1:            # the CPU port is timed at N=1 only
+        if not args.no_cpu_baseline and world == 1 and not dry:            # the CPU port is timed at N=1 only
             out["cpu_baseline"] = cpu_baseline(names[0] if len(names) == 1 else "snake")
         print(json.dumps(out), flush=True)
+        if args.manifest:
+            with open(args.manifest, "w") as f:
+                json.dump(launched, f, indent=1)
     for e in envs.values():
         e.close()
     if dist is not None:

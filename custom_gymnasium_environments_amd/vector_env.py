@@ -83,9 +83,13 @@ class DeviceVectorEnv(VectorEnvBase):
         reuse_buffers=True, one persistent buffer per output that the next call overwrites."""
         if self._reuse:
             t = self._bufs.get(key)
-            if t is None:
+            if t is not None and tuple(t.shape) == tuple(shape) and t.dtype == dtype:
+                return t
+            numel = int(np.prod(shape))
+            if t is None or t.dtype != dtype or t.numel() < numel:           # first use, or a larger request (e.g. a longer rollout)
                 t = self._bufs[key] = torch.empty(shape, dtype=dtype, device=self.device)
-            return t
+                return t
+            return t.view(-1)[:numel].view(shape)                            # a shorter rollout reuses the front of the buffer
         return torch.empty(shape, dtype=dtype, device=self.device)
 
     def _as_device(self, x, dtype, shape, what):
