@@ -74,6 +74,7 @@ SIGNATURES = {
     "cge_snake_set_state": (C.c_int, [_vp, _vp, _vp]),
     "cge_snake_error_count": (_i64, [_vp, _vp]),
     "cge_snake_device_bytes": (_sz, [_vp]),
+    "cge_snake_episode_stats": (C.c_int, [_vp, _vp, _vp]),
     "cge_snake_last_error": (C.c_char_p, [_vp]),
     "cge_crypto_default_config": (None, [C.POINTER(CryptoConfig)]),
     "cge_crypto_create": (C.c_int, [C.POINTER(CryptoConfig), _i64, C.c_int, _i64, C.POINTER(_vp)]),
@@ -87,6 +88,7 @@ SIGNATURES = {
     "cge_crypto_get_state": (C.c_int, [_vp, _vp, _vp]),
     "cge_crypto_set_state": (C.c_int, [_vp, _vp, _vp]),
     "cge_crypto_device_bytes": (_sz, [_vp]),
+    "cge_crypto_episode_stats": (C.c_int, [_vp, _vp, _vp]),
     "cge_crypto_last_error": (C.c_char_p, [_vp]),
     "cge_traffic_default_config": (None, [C.POINTER(TrafficConfig)]),
     "cge_traffic_create": (C.c_int, [C.POINTER(TrafficConfig), _i64, C.c_int, _i64, C.POINTER(_vp)]),
@@ -101,6 +103,7 @@ SIGNATURES = {
     "cge_traffic_get_state": (C.c_int, [_vp, _vp, _vp]),
     "cge_traffic_set_state": (C.c_int, [_vp, _vp, _vp]),
     "cge_traffic_device_bytes": (_sz, [_vp]),
+    "cge_traffic_episode_stats": (C.c_int, [_vp, _vp, _vp]),
     "cge_traffic_last_error": (C.c_char_p, [_vp]),
     "cge_parking_create": (C.c_int, [C.POINTER(ParkingConfig), _i64, C.c_int, _i64, C.POINTER(_vp)]),
     "cge_parking_destroy": (C.c_int, [_vp]),
@@ -114,6 +117,7 @@ SIGNATURES = {
     "cge_parking_snapshot_get": (C.c_int, [_vp, _vp, _vp]),
     "cge_parking_snapshot_set": (C.c_int, [_vp, _vp, _vp]),
     "cge_parking_device_bytes": (_sz, [_vp]),
+    "cge_parking_episode_stats": (C.c_int, [_vp, _vp, _vp]),
     "cge_parking_last_error": (C.c_char_p, [_vp]),
     "cge_climate_create": (C.c_int, [C.POINTER(ClimateConfig), _i64, C.c_int, _i64, C.POINTER(_vp)]),
     "cge_climate_destroy": (C.c_int, [_vp]),
@@ -126,6 +130,7 @@ SIGNATURES = {
     "cge_climate_snapshot_get": (C.c_int, [_vp, _vp, _vp]),
     "cge_climate_snapshot_set": (C.c_int, [_vp, _vp, _vp]),
     "cge_climate_device_bytes": (_sz, [_vp]),
+    "cge_climate_episode_stats": (C.c_int, [_vp, _vp, _vp]),
     "cge_climate_last_error": (C.c_char_p, [_vp]),
     "cge_fleet_create": (C.c_int, [C.POINTER(FleetConfig), _i64, C.c_int, _i64, C.POINTER(_vp)]),
     "cge_fleet_destroy": (C.c_int, [_vp]),
@@ -138,6 +143,7 @@ SIGNATURES = {
     "cge_fleet_snapshot_get": (C.c_int, [_vp, _vp, _vp]),
     "cge_fleet_snapshot_set": (C.c_int, [_vp, _vp, _vp]),
     "cge_fleet_device_bytes": (_sz, [_vp]),
+    "cge_fleet_episode_stats": (C.c_int, [_vp, _vp, _vp]),
     "cge_fleet_last_error": (C.c_char_p, [_vp]),
     "cge_manufacturing_create": (C.c_int, [C.POINTER(ManufacturingConfig), _i64, C.c_int, _i64, C.POINTER(_vp)]),
     "cge_manufacturing_destroy": (C.c_int, [_vp]),
@@ -150,6 +156,7 @@ SIGNATURES = {
     "cge_manufacturing_snapshot_get": (C.c_int, [_vp, _vp, _vp]),
     "cge_manufacturing_snapshot_set": (C.c_int, [_vp, _vp, _vp]),
     "cge_manufacturing_device_bytes": (_sz, [_vp]),
+    "cge_manufacturing_episode_stats": (C.c_int, [_vp, _vp, _vp]),
     "cge_manufacturing_last_error": (C.c_char_p, [_vp]),
     "cge_hospital_create": (C.c_int, [C.POINTER(HospitalConfig), _i64, C.c_int, _i64, C.POINTER(_vp)]),
     "cge_hospital_destroy": (C.c_int, [_vp]),
@@ -162,6 +169,7 @@ SIGNATURES = {
     "cge_hospital_snapshot_get": (C.c_int, [_vp, _vp, _vp]),
     "cge_hospital_snapshot_set": (C.c_int, [_vp, _vp, _vp]),
     "cge_hospital_device_bytes": (_sz, [_vp]),
+    "cge_hospital_episode_stats": (C.c_int, [_vp, _vp, _vp]),
     "cge_hospital_last_error": (C.c_char_p, [_vp]),
 }
 

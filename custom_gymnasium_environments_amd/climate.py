@@ -26,7 +26,7 @@ class ClimateVectorEnv(DeviceVectorEnv):
     metadata = {"render_modes": []}
 
     def __init__(self, num_envs, device="cuda:0", autoreset_mode="NextStep", env_index0=0, max_occupancy=8, episode_minutes=1440,
-                 reuse_buffers=False, info_fields=()):
+                 reuse_buffers=False, info_fields=(), record_episode_statistics=False):
         self._init_common(num_envs, device, autoreset_mode, env_index0, reuse_buffers)
         lo = np.array([0.0, 0, 0.0, 10.0, 16.0, 0, 0, 0, 0]); hi = np.array([50.0, max_occupancy, 23.99, 50.0, 32.0, 1, 1, 1, 1])
         self.single_observation_space = Box(lo, hi, (OBS_DIM,), np.float32)
@@ -40,6 +40,7 @@ class ClimateVectorEnv(DeviceVectorEnv):
                       what="cge_climate_create")
         self._h = h
         self._obs_shape = (self.num_envs, OBS_DIM)
+        self.record_episode_statistics(record_episode_statistics)
 
     def _split(self, actions, k=None):
         ac, li = (actions["ac_temp"], actions["lights"]) if isinstance(actions, dict) else actions
@@ -75,7 +76,7 @@ class ClimateVectorEnv(DeviceVectorEnv):
         if same:
             infos["final_obs"] = fin
             infos["_final_obs"] = term
-        return obs, rew, term, trunc, infos
+        return obs, rew, term, trunc, self._episode_infos(infos, term)
 
     def rollout(self, k_steps, actions=None, action_seed=0, t0=0, trajectory=False, want_obs=True, per_step=False):
         k = int(k_steps)

@@ -32,7 +32,7 @@ class CryptoVectorEnv(DeviceVectorEnv):
     metadata = {"render_modes": []}
 
     def __init__(self, num_envs, action_type="discrete", device="cuda:0", autoreset_mode="NextStep", env_index0=0,
-                 config=None, max_steps=1000, reuse_buffers=False, info_fields=()):
+                 config=None, max_steps=1000, reuse_buffers=False, info_fields=(), record_episode_statistics=False):
         self._init_common(num_envs, device, autoreset_mode, env_index0, reuse_buffers)
         if action_type not in ("discrete", "continuous"):
             raise ValueError("action_type must be 'discrete' or 'continuous'")
@@ -60,6 +60,7 @@ class CryptoVectorEnv(DeviceVectorEnv):
                       what="cge_crypto_create")
         self._h = h
         self._obs_shape = (self.num_envs, OBS_DIM)
+        self.record_episode_statistics(record_episode_statistics)
 
     def _actions(self, actions, k=None):
         shape = (self.num_envs, 2) if self.continuous else (self.num_envs,)
@@ -93,7 +94,7 @@ class CryptoVectorEnv(DeviceVectorEnv):
         if same:
             infos["final_obs"] = fin
             infos["_final_obs"] = term
-        return obs, rew, term, trunc, infos
+        return obs, rew, term, trunc, self._episode_infos(infos, term)
 
     def rollout(self, k_steps, actions=None, action_seed=0, t0=0, trajectory=False, want_obs=True, per_step=False):
         """k fused step()s in one launch; see SnakeVectorEnv.rollout.  reward_sum is float64."""

@@ -19,6 +19,8 @@ struct HandleBase {
     int64_t env0 = 0;
     std::string last_error;
     size_t device_bytes = 0;
+    double *ep_ret = nullptr;      // episode-statistics outputs registered by <env>_episode_stats (caller-owned device buffers)
+    int32_t *ep_len = nullptr;
 
     int fail(int status, const char *what, hipError_t e = hipSuccess) {
         char buf[512];

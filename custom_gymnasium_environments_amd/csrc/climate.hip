@@ -38,6 +38,8 @@ struct Params {
     int64_t t0, obs_step_stride;
     double *reward_sum;
     int32_t *done_count;
+    double *ep_ret;       // episode statistics (cge_climate_episode_stats), nullable
+    int32_t *ep_len;
 };
 
 __device__ __forceinline__ double mk_double(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
@@ -175,6 +177,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
                 term = env_step(e, p.max_occ, p.max_steps, ac, lights, reward);
                 if (term) {
                     e.episodes += 1;
+                    if (p.ep_ret) p.ep_ret[i] = e.total_reward;            // env.py:108 accumulates it, reset() zeroes it
+                    if (p.ep_len) p.ep_len[i] = (int32_t)e.step;
                     if (p.mode == CGE_AUTORESET_SAME_STEP) reset_now = true;
                     else if (p.mode == CGE_AUTORESET_NEXT_STEP) e.needs_reset = 1;
                 }
@@ -263,6 +267,7 @@ struct cge_climate : HandleBase {
     climate::Params params() const {
         climate::Params p{};
         p.state = state; p.n = n; p.env0 = env0; p.mode = cfg.autoreset_mode; p.max_occ = cfg.max_occupancy; p.max_steps = cfg.episode_minutes;
+        p.ep_ret = ep_ret; p.ep_len = ep_len;
         return p;
     }
     unsigned blocks() const { return (unsigned)((n + climate::BLOCK - 1) / climate::BLOCK); }
@@ -376,6 +381,12 @@ size_t cge_climate_snapshot_bytes(const cge_climate *h) { return h ? snapshot_by
 int cge_climate_snapshot_get(cge_climate *h, void *host_buf, void *stream) { return snapshot_get(h, host_buf, as_stream(stream)); }
 int cge_climate_snapshot_set(cge_climate *h, const void *host_buf, void *stream) { return snapshot_set(h, host_buf, as_stream(stream)); }
 size_t cge_climate_device_bytes(const cge_climate *h) { return h ? h->device_bytes : 0; }
+int cge_climate_episode_stats(cge_climate *h, double *return_out, int32_t *length_out) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    h->ep_ret = return_out; h->ep_len = length_out;
+    return CGE_OK;
+}
+
 const char *cge_climate_last_error(const cge_climate *h) { return h ? h->last_error.c_str() : "null handle"; }
 
 }  // extern "C"

@@ -66,6 +66,8 @@ struct Params {
     int64_t t0, obs_step_stride;
     double *reward_sum;
     int32_t *done_count;
+    double *ep_ret;       // episode statistics (cge_crypto_episode_stats), nullable
+    int32_t *ep_len;
 };
 
 __device__ __forceinline__ double mk_double(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
@@ -74,7 +76,8 @@ __device__ __forceinline__ double clipd(double x, double lo, double hi) { return
 
 struct Env {
     double cash, holdings, close, psych, trend, gauss;
-    uint32_t step, regime, has_gauss, cash_kind, needs_reset, episodes;
+    double ep_return;                      // float64 sum of the running episode's rewards, step order
+    uint32_t step, regime, has_gauss, cash_kind, needs_reset, episodes;   // episodes: 19 bits (saturates at 524,287)
     uint32_t ppos, ppretw, lpos, lpretw;
 
     __device__ __forceinline__ void load(const uint4 *__restrict__ s, int64_t n, int64_t i) {
@@ -86,7 +89,8 @@ struct Env {
         cash_kind = (d.x >> 20) & 3u; needs_reset = (d.x >> 22) & 1u;
         ppos = d.y & 1023u; ppretw = (d.y & 1024u) ? (uint32_t)MT_N : 0u;
         lpos = (d.y >> 11) & 1023u; lpretw = (d.y & (1u << 21)) ? (uint32_t)MT_N : 0u;
-        episodes = d.z;
+        episodes = (d.x >> 23) | ((d.y >> 22) << 9);
+        ep_return = mk_double(d.z, d.w);
     }
     __device__ __forceinline__ void store(uint4 *__restrict__ s, int64_t n, int64_t i) const {
         s[i] = make_uint4((uint32_t)__double2loint(cash), (uint32_t)__double2hiint(cash),
@@ -95,8 +99,10 @@ struct Env {
                               (uint32_t)__double2loint(psych), (uint32_t)__double2hiint(psych));
         s[2 * n + i] = make_uint4((uint32_t)__double2loint(trend), (uint32_t)__double2hiint(trend),
                                   (uint32_t)__double2loint(gauss), (uint32_t)__double2hiint(gauss));
-        s[3 * n + i] = make_uint4(step | (regime << 16) | (has_gauss << 19) | (cash_kind << 20) | (needs_reset << 22),
-                                  ppos | (ppretw ? 1024u : 0u) | (lpos << 11) | (lpretw ? (1u << 21) : 0u), episodes, 0u);
+        const uint32_t ep = episodes < 0x7FFFFu ? episodes : 0x7FFFFu;
+        s[3 * n + i] = make_uint4(step | (regime << 16) | (has_gauss << 19) | (cash_kind << 20) | (needs_reset << 22) | ((ep & 511u) << 23),
+                                  ppos | (ppretw ? 1024u : 0u) | (lpos << 11) | (lpretw ? (1u << 21) : 0u) | ((ep >> 9) << 22),
+                                  (uint32_t)__double2loint(ep_return), (uint32_t)__double2hiint(ep_return));
     }
 };
 
@@ -168,6 +174,7 @@ __device__ __forceinline__ void do_reset(Env &e, const Params &p, int64_t i, int
     e.holdings = 0.0;
     e.step = 0;
     e.needs_reset = 0;
+    e.ep_return = 0.0;
     double price = 50000.0;
     int slot = phase;
 #pragma unroll 1
@@ -522,8 +529,11 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
                                   : (int32_t)hash_action_from_key(key, (uint64_t)(p.t0 + t), 5u, 0u);
                 }
                 term = env_step(e, p, i, phase, a, ab, as, reward);
+                e.ep_return += reward;
                 if (term) {
                     e.episodes += 1;
+                    if (p.ep_ret) p.ep_ret[i] = e.ep_return;
+                    if (p.ep_len) p.ep_len[i] = (int32_t)e.step;
                     if (p.mode == CGE_AUTORESET_SAME_STEP) reset_now = true;
                     else if (p.mode == CGE_AUTORESET_NEXT_STEP) e.needs_reset = 1;
                 }
@@ -583,7 +593,7 @@ __global__ __launch_bounds__(256) void init_kernel(uint4 *scal, int64_t n, doubl
     e.load(scal, n, i);
     if (!rewind_only) {
         e.cash = initial_balance; e.holdings = 0.0; e.close = 50000.0; e.psych = 0.5; e.trend = 0.0; e.gauss = 0.0;
-        e.step = 0; e.regime = SIDEWAYS; e.cash_kind = 0; e.needs_reset = 0; e.episodes = 0;
+        e.step = 0; e.regime = SIDEWAYS; e.cash_kind = 0; e.needs_reset = 0; e.episodes = 0; e.ep_return = 0.0;
     }
     e.has_gauss = 0;            // np.random.seed() drops the cached gaussian
     e.gauss = 0.0;
@@ -633,6 +643,7 @@ struct cge_crypto : HandleBase {
         p.cfg = crypto::Cfg{cfg.initial_balance, cfg.trading_fee_rate, cfg.slippage_rate, cfg.min_price, cfg.max_price,
                             cfg.volatility_base, cfg.market_psychology_factor, cfg.max_steps, cfg.action_type};
         p.mode = cfg.autoreset_mode; p.phase = phase;
+        p.ep_ret = ep_ret; p.ep_len = ep_len;
         return p;
     }
     unsigned blocks() const { return (unsigned)((n + crypto::BLOCK - 1) / crypto::BLOCK); }
@@ -797,8 +808,8 @@ int cge_crypto_get_state(cge_crypto *h, void *host_buf, void *stream) {
         const uint4 a = sc[i], b = sc[n + i], c = sc[2 * n + i], d = sc[3 * n + i];
         auto dbl = [](uint32_t lo, uint32_t hi) { uint64_t u = ((uint64_t)hi << 32) | lo; double x; memcpy(&x, &u, 8); return x; };
         int32_t hd[12] = {(int32_t)((d.x >> 16) & 7u), (int32_t)(d.x & 0xffffu), (int32_t)((d.x >> 22) & 1u), (int32_t)((d.x >> 20) & 3u),
-                          0, 0, (int32_t)((d.x >> 19) & 1u), (int32_t)d.z, 0, 0, 0, 0};
-        double scv[6] = {dbl(a.x, a.y), dbl(a.z, a.w), dbl(b.z, b.w), dbl(c.x, c.y), dbl(c.z, c.w), 0.0};
+                          0, 0, (int32_t)((d.x >> 19) & 1u), (int32_t)((d.x >> 23) | ((d.y >> 22) << 9)), 0, 0, 0, 0};
+        double scv[6] = {dbl(a.x, a.y), dbl(a.z, a.w), dbl(b.z, b.w), dbl(c.x, c.y), dbl(c.z, c.w), dbl(d.z, d.w)};   // [5]: episode return so far
         export_mt(&mp[(size_t)i * MT_STRIDE], d.y & 1023u, (d.y & 1024u) ? MT_N : 0, (uint32_t *)(p + 96), &hd[4]);
         export_mt(&ml[(size_t)i * MT_STRIDE], (d.y >> 11) & 1023u, (d.y & (1u << 21)) ? MT_N : 0, (uint32_t *)(p + 96 + MT_N * 4), &hd[5]);
         memcpy(p, hd, 48);
@@ -839,9 +850,10 @@ int cge_crypto_set_state(cge_crypto *h, const void *host_buf, void *stream) {
         sc[i] = make_uint4(lo(scv[0]), hi(scv[0]), lo(scv[1]), hi(scv[1]));
         sc[n + i] = make_uint4(lo(close), hi(close), lo(scv[2]), hi(scv[2]));
         sc[2 * n + i] = make_uint4(lo(scv[3]), hi(scv[3]), lo(scv[4]), hi(scv[4]));
+        const uint32_t ep = (uint32_t)hd[7] < 0x7FFFFu ? (uint32_t)hd[7] : 0x7FFFFu;
         sc[3 * n + i] = make_uint4((uint32_t)hd[1] | ((uint32_t)hd[0] << 16) | ((uint32_t)(hd[6] & 1) << 19) | ((uint32_t)(hd[3] & 3) << 20) |
-                                       ((uint32_t)(hd[2] & 1) << 22),
-                                   ppos | ppre | (lpos << 11) | lpre, (uint32_t)hd[7], 0u);
+                                       ((uint32_t)(hd[2] & 1) << 22) | ((ep & 511u) << 23),
+                                   ppos | ppre | (lpos << 11) | lpre | ((ep >> 9) << 22), lo(scv[5]), hi(scv[5]));
         memcpy(&mp[(size_t)i * MT_STRIDE], p + 96, MT_N * 4);
         memcpy(&ml[(size_t)i * MT_STRIDE], p + 96 + MT_N * 4, MT_N * 4);
         for (int k = 0; k < crypto::HLEN; ++k) {
@@ -860,6 +872,12 @@ int cge_crypto_set_state(cge_crypto *h, const void *host_buf, void *stream) {
 }
 
 size_t cge_crypto_device_bytes(const cge_crypto *h) { return h ? h->device_bytes : 0; }
+int cge_crypto_episode_stats(cge_crypto *h, double *return_out, int32_t *length_out) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    h->ep_ret = return_out; h->ep_len = length_out;
+    return CGE_OK;
+}
+
 const char *cge_crypto_last_error(const cge_crypto *h) { return h ? h->last_error.c_str() : "null handle"; }
 
 }  // extern "C"

@@ -51,6 +51,8 @@ struct Params {
     int64_t t0, obs_step_stride;
     double *reward_sum;
     int32_t *done_count;
+    double *ep_ret;       // episode statistics (cge_fleet_episode_stats), nullable
+    int32_t *ep_len;
     int32_t t_index, accumulate;
     uint32_t *work_count;      // [2] alternating counters of the deferred-work list
     uint64_t *work_list;       // [n] entries: env index << 3 | W_* flags
@@ -374,6 +376,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
             flags = env_step(e, p.max_steps, a0, a1, a2, work, reward);
             if (flags) {
                 e.episodes += 1;
+                if (p.ep_ret) p.ep_ret[i] = e.total_reward;                // fleet_env.py accumulates it in step(), reset() zeroes it
+                if (p.ep_len) p.ep_len[i] = (int32_t)e.timestep;
                 if (p.mode == CGE_AUTORESET_SAME_STEP) work |= W_RESET;
                 else if (p.mode == CGE_AUTORESET_NEXT_STEP) e.needs_reset = 1;
             }
@@ -512,6 +516,7 @@ struct cge_fleet : HandleBase {
         fleet::Params p{};
         p.state = state; p.mtP = mtP; p.mtL = mtL; p.n = n; p.env0 = env0; p.mode = cfg.autoreset_mode; p.max_steps = cfg.max_timesteps;
         p.work_count = work_count; p.work_list = work_list; p.parity = parity;
+        p.ep_ret = ep_ret; p.ep_len = ep_len;
         return p;
     }
     unsigned blocks() const { return (unsigned)((n + fleet::BLOCK - 1) / fleet::BLOCK); }
@@ -649,6 +654,12 @@ size_t cge_fleet_snapshot_bytes(const cge_fleet *h) { return h ? snapshot_bytes(
 int cge_fleet_snapshot_get(cge_fleet *h, void *host_buf, void *stream) { return snapshot_get(h, host_buf, as_stream(stream)); }
 int cge_fleet_snapshot_set(cge_fleet *h, const void *host_buf, void *stream) { return snapshot_set(h, host_buf, as_stream(stream)); }
 size_t cge_fleet_device_bytes(const cge_fleet *h) { return h ? h->device_bytes : 0; }
+int cge_fleet_episode_stats(cge_fleet *h, double *return_out, int32_t *length_out) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    h->ep_ret = return_out; h->ep_len = length_out;
+    return CGE_OK;
+}
+
 const char *cge_fleet_last_error(const cge_fleet *h) { return h ? h->last_error.c_str() : "null handle"; }
 
 }  // extern "C"

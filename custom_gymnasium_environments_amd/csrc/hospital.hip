@@ -65,6 +65,8 @@ struct Params {
     const uint8_t *mask;
     double *reward_sum;
     int32_t *done_count;
+    double *ep_ret;       // episode statistics (cge_hospital_episode_stats), nullable
+    int32_t *ep_len;
 };
 
 __device__ __forceinline__ double mk_double(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
@@ -91,6 +93,7 @@ __device__ __forceinline__ void store_cols(uint4 *__restrict__ s, int64_t n, int
 // ------------------------------------------------------------------ MISC group
 struct Misc {
     uint32_t time, deaths, outbreak, mass, needs_reset, overflow, treated, episodes, total_wait, next_id, pos, pretw, navail;
+    int32_t ep_return;                     // sum of the running episode's (integer) rewards
     double wait[3];
     uint32_t sumarr[3];
     uint32_t qh[6], qc[6], ql[6];          // ring head, count, "late" prefix length
@@ -107,6 +110,7 @@ struct Misc {
         for (int d = 0; d < 3; ++d) { wait[d] = mk_double(r[4 + 2 * d], r[5 + 2 * d]); sumarr[d] = r[10 + d]; ndept[d] = r[19 + d]; }
 #pragma unroll
         for (int k = 0; k < 6; ++k) { qh[k] = r[13 + k] & 1023u; qc[k] = (r[13 + k] >> 10) & 2047u; ql[k] = r[13 + k] >> 21; }
+        ep_return = (int32_t)r[22];
     }
     __device__ __forceinline__ void store(uint4 *s, int64_t n, int64_t i) const {
         uint32_t r[24];
@@ -117,7 +121,7 @@ struct Misc {
         for (int d = 0; d < 3; ++d) { r[4 + 2 * d] = d_lo(wait[d]); r[5 + 2 * d] = d_hi(wait[d]); r[10 + d] = sumarr[d]; r[19 + d] = ndept[d]; }
 #pragma unroll
         for (int k = 0; k < 6; ++k) r[13 + k] = qh[k] | (qc[k] << 10) | (ql[k] << 21);
-        r[22] = 0; r[23] = 0;
+        r[22] = (uint32_t)ep_return; r[23] = 0;
         store_cols<6>(s, n, i, C_MISC, r);
     }
     __device__ __forceinline__ uint32_t qlen(int d3) const { return d3 == 0 ? qc[0] + qc[1] + qc[2] : d3 == 1 ? qc[3] : qc[4] + qc[5]; }
@@ -428,7 +432,7 @@ __device__ __forceinline__ void do_reset(const Params &p, int64_t i, bool mine, 
 #pragma unroll
         for (int k = 0; k < 5; ++k) row[238 - NA + k] = 0.0f;
         // MISC
-        m.time = 0; m.deaths = 0; m.treated = 0; m.total_wait = 0; m.next_id = 0; m.outbreak = 0; m.mass = 0; m.needs_reset = 0; m.navail = NNUR;
+        m.time = 0; m.deaths = 0; m.treated = 0; m.total_wait = 0; m.next_id = 0; m.outbreak = 0; m.mass = 0; m.needs_reset = 0; m.navail = NNUR; m.ep_return = 0;
 #pragma unroll
         for (int d = 0; d < 3; ++d) { m.wait[d] = 0.0; m.sumarr[d] = 0; }
 #pragma unroll
@@ -686,8 +690,11 @@ __device__ __forceinline__ void wave_step(const Params &p, int64_t i, int64_t i0
         row[240 - NA] = (float)((double)m.time / (double)p.max_steps);
         row[241 - NA] = m.outbreak ? 1.0f : 0.0f;
         row[242 - NA] = m.mass ? 1.0f : 0.0f;
+        m.ep_return += reward;                                 // every contribution to this step's reward is in by now
         if (done) {
             m.episodes += 1;
+            if (p.ep_ret) p.ep_ret[i] = (double)m.ep_return;  // integer rewards: exact in float64
+            if (p.ep_len) p.ep_len[i] = (int32_t)m.time;
             if (p.mode == CGE_AUTORESET_NEXT_STEP) m.needs_reset = 1;
         }
     }
@@ -911,6 +918,7 @@ struct cge_hospital : HandleBase {
     hosp::Params params() const {
         hosp::Params p{};
         p.state = state; p.mt = mt; p.ring = ring; p.ringtt = ringtt; p.n = n; p.env0 = env0; p.mode = cfg.autoreset_mode; p.max_steps = cfg.max_episode_length;
+        p.ep_ret = ep_ret; p.ep_len = ep_len;
         return p;
     }
     unsigned blocks() const { return (unsigned)((n + hosp::BLOCK - 1) / hosp::BLOCK); }
@@ -1027,6 +1035,12 @@ size_t cge_hospital_snapshot_bytes(const cge_hospital *h) { return h ? snapshot_
 int cge_hospital_snapshot_get(cge_hospital *h, void *host_buf, void *stream) { return snapshot_get(h, host_buf, as_stream(stream)); }
 int cge_hospital_snapshot_set(cge_hospital *h, const void *host_buf, void *stream) { return snapshot_set(h, host_buf, as_stream(stream)); }
 size_t cge_hospital_device_bytes(const cge_hospital *h) { return h ? h->device_bytes : 0; }
+int cge_hospital_episode_stats(cge_hospital *h, double *return_out, int32_t *length_out) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    h->ep_ret = return_out; h->ep_len = length_out;
+    return CGE_OK;
+}
+
 const char *cge_hospital_last_error(const cge_hospital *h) { return h ? h->last_error.c_str() : "null handle"; }
 
 }  // extern "C"

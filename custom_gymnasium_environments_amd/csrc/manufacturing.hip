@@ -56,6 +56,8 @@ struct Params {
     uint64_t base_seed;
     double *reward_sum;
     int32_t *done_count;
+    double *ep_ret;       // episode statistics (cge_manufacturing_episode_stats), nullable
+    int32_t *ep_len;
 };
 
 __device__ __forceinline__ double mk_double(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
@@ -593,6 +595,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
                 flags = env_step(e, tb, p.max_steps, a, reward);
                 if (flags) {
                     e.episodes += 1;
+                    if (p.ep_ret) p.ep_ret[i] = (double)e.total_reward;    // integer rewards (:291), exact in float64
+                    if (p.ep_len) p.ep_len[i] = (int32_t)e.timestep;
                     if (p.mode == CGE_AUTORESET_SAME_STEP) reset_now = true;
                     else if (p.mode == CGE_AUTORESET_NEXT_STEP) e.needs_reset = 1;
                 }
@@ -727,6 +731,7 @@ struct cge_manufacturing : HandleBase {
         mfg::Params p{};
         p.state = state; p.pq = pq; p.pm = pm; p.pnext = pnext; p.comp = comp; p.hist = hist;
         p.n = n; p.env0 = env0; p.mode = cfg.autoreset_mode; p.max_steps = cfg.max_steps;
+        p.ep_ret = ep_ret; p.ep_len = ep_len;
         return p;
     }
     unsigned blocks() const { return (unsigned)((n + mfg::BLOCK - 1) / mfg::BLOCK); }
@@ -841,6 +846,12 @@ size_t cge_manufacturing_snapshot_bytes(const cge_manufacturing *h) { return h ?
 int cge_manufacturing_snapshot_get(cge_manufacturing *h, void *host_buf, void *stream) { return snapshot_get(h, host_buf, as_stream(stream)); }
 int cge_manufacturing_snapshot_set(cge_manufacturing *h, const void *host_buf, void *stream) { return snapshot_set(h, host_buf, as_stream(stream)); }
 size_t cge_manufacturing_device_bytes(const cge_manufacturing *h) { return h ? h->device_bytes : 0; }
+int cge_manufacturing_episode_stats(cge_manufacturing *h, double *return_out, int32_t *length_out) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    h->ep_ret = return_out; h->ep_len = length_out;
+    return CGE_OK;
+}
+
 const char *cge_manufacturing_last_error(const cge_manufacturing *h) { return h ? h->last_error.c_str() : "null handle"; }
 
 }  // extern "C"

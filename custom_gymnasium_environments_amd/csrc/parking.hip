@@ -50,6 +50,8 @@ struct Params {
     int64_t t0, obs_step_stride;
     double *reward_sum;
     int32_t *done_count;
+    double *ep_ret;       // episode statistics (cge_parking_episode_stats), nullable
+    int32_t *ep_len;
 };
 
 __host__ __device__ __forceinline__ constexpr int zone_of(int k) { return k < 15 ? 0 : k < 35 ? 1 : 2; }
@@ -63,6 +65,7 @@ struct Env {
     int32_t last_change;
     uint32_t total_customers, rejected, satisfied, episodes, total_wait;
     double revenue, satisfaction_sum;
+    double ep_return;       // sum of the running episode's rewards (float64, step order)
 
     __host__ __device__ __forceinline__ void unpack(const uint32_t *raw) {
 #pragma unroll
@@ -79,6 +82,8 @@ struct Env {
         memcpy(&revenue, &u, 8);
         u = ((uint64_t)raw[68] << 32) | raw[67];
         memcpy(&satisfaction_sum, &u, 8);
+        u = ((uint64_t)raw[70] << 32) | raw[69];
+        memcpy(&ep_return, &u, 8);
     }
     __host__ __device__ __forceinline__ void pack(uint32_t *raw) const {
 #pragma unroll
@@ -95,7 +100,9 @@ struct Env {
         raw[65] = (uint32_t)u; raw[66] = (uint32_t)(u >> 32);
         memcpy(&u, &satisfaction_sum, 8);
         raw[67] = (uint32_t)u; raw[68] = (uint32_t)(u >> 32);
-        raw[69] = raw[70] = raw[71] = 0;
+        memcpy(&u, &ep_return, 8);
+        raw[69] = (uint32_t)u; raw[70] = (uint32_t)(u >> 32);
+        raw[71] = 0;
     }
     __device__ __forceinline__ void load(const uint4 *__restrict__ s, int64_t n, int64_t i) {
         uint32_t raw[COLS * 4];
@@ -119,7 +126,7 @@ struct Env {
         for (int k = 0; k < QMAX; ++k) q[k] = 0;
         t = 0; qlen = 0; lv0 = lv1 = lv2 = 1; changes = 0; last_change = -999; needs_reset = 0;
         total_customers = rejected = satisfied = total_wait = 0;
-        revenue = 0.0; satisfaction_sum = 0.0;
+        revenue = 0.0; satisfaction_sum = 0.0; ep_return = 0.0;
     }
     __device__ __forceinline__ double zone_price(uint32_t z) const {   // pricing.py:59-64
         // mask form: a ternary over array elements is folded into "select the address, then load" -> scratch
@@ -337,8 +344,11 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
                 d.fill();                                            // the arrival test draws every step
                 term = env_step(e, p.max_steps, a, d, reward);
                 d.flush();
+                e.ep_return += reward;
                 if (term) {
                     e.episodes += 1;
+                    if (p.ep_ret) p.ep_ret[i] = e.ep_return;
+                    if (p.ep_len) p.ep_len[i] = (int32_t)e.t;
                     if (p.mode == CGE_AUTORESET_SAME_STEP) reset_now = true;
                     else if (p.mode == CGE_AUTORESET_NEXT_STEP) e.needs_reset = 1;
                 }
@@ -433,6 +443,7 @@ struct cge_parking : HandleBase {
     parking::Params params() const {
         parking::Params p{};
         p.state = state; p.mt = mt; p.n = n; p.env0 = env0; p.mode = cfg.autoreset_mode; p.max_steps = cfg.max_steps;
+        p.ep_ret = ep_ret; p.ep_len = ep_len;
         return p;
     }
     unsigned blocks() const { return (unsigned)((n + parking::BLOCK - 1) / parking::BLOCK); }
@@ -558,6 +569,12 @@ size_t cge_parking_snapshot_bytes(const cge_parking *h) { return h ? snapshot_by
 int cge_parking_snapshot_get(cge_parking *h, void *host_buf, void *stream) { return snapshot_get(h, host_buf, as_stream(stream)); }
 int cge_parking_snapshot_set(cge_parking *h, const void *host_buf, void *stream) { return snapshot_set(h, host_buf, as_stream(stream)); }
 size_t cge_parking_device_bytes(const cge_parking *h) { return h ? h->device_bytes : 0; }
+int cge_parking_episode_stats(cge_parking *h, double *return_out, int32_t *length_out) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    h->ep_ret = return_out; h->ep_len = length_out;
+    return CGE_OK;
+}
+
 const char *cge_parking_last_error(const cge_parking *h) { return h ? h->last_error.c_str() : "null handle"; }
 
 }  // extern "C"

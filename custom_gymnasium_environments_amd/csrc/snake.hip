@@ -261,6 +261,8 @@ struct Params {
     int64_t t0, obs_step_stride;
     float *reward_sum;
     int32_t *done_count;
+    double *ep_ret;       // episode statistics (cge_snake_episode_stats), nullable
+    int32_t *ep_len;
     unsigned long long *err_count;
 };
 
@@ -359,6 +361,11 @@ __device__ __forceinline__ uint32_t transition(Env<G> &e, const Params &p, int64
         term = e.move(action, (uint32_t)p.max_steps, reward, need_food);
         if (term) {
             e.episodes += 1;
+            // episode statistics need no accumulator here: every reward is +10 per point of `score`, -10 for the collision that
+            // ends the episode (which is not counted in `steps`, snake_env.py:88-94), 0 otherwise
+            const bool crashed = reward < 0.0f;
+            if (p.ep_ret) p.ep_ret[i] = 10.0 * (double)e.score - (crashed ? 10.0 : 0.0);
+            if (p.ep_len) p.ep_len[i] = (int32_t)e.steps + (crashed ? 1 : 0);
             if (p.mode == CGE_AUTORESET_SAME_STEP) {
                 // time limit on a step that also ate: the reference places the new food (snake_env.py:104) BEFORE it tests
                 // steps >= max_steps (:113), so the terminal obs shows it and the reset below draws a second one
@@ -706,6 +713,7 @@ struct cge_snake : HandleBase {
         snake::Params p{};
         p.state = state; p.mt = mt; p.n = n; p.env0 = env0;
         p.mode = cfg.autoreset_mode; p.max_steps = cfg.max_steps; p.err_count = err;
+        p.ep_ret = ep_ret; p.ep_len = ep_len;
         return p;
     }
 };
@@ -931,6 +939,12 @@ int64_t cge_snake_error_count(cge_snake *h, void *stream) {
 }
 
 size_t cge_snake_device_bytes(const cge_snake *h) { return h ? h->device_bytes : 0; }
+
+int cge_snake_episode_stats(cge_snake *h, double *return_out, int32_t *length_out) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    h->ep_ret = return_out; h->ep_len = length_out;
+    return CGE_OK;
+}
 
 const char *cge_snake_last_error(const cge_snake *h) { return h ? h->last_error.c_str() : "null handle"; }
 

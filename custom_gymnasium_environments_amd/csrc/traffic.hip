@@ -59,6 +59,8 @@ struct Params {
     int64_t t0, obs_step_stride;
     double *reward_sum;
     int32_t *done_count;
+    double *ep_ret;       // episode statistics (cge_traffic_episode_stats), nullable
+    int32_t *ep_len;
 };
 
 struct Env {
@@ -324,6 +326,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
                 if (!ROLLOUT) d.flush();                          // a rollout keeps its window across steps
                 if (term) {
                     e.episodes += 1;
+                    if (p.ep_ret) p.ep_ret[i] = e.total_reward;            // environment.py:189 accumulates it, reset() zeroes it (:150)
+                    if (p.ep_len) p.ep_len[i] = (int32_t)e.timestep;
                     if (p.mode == CGE_AUTORESET_SAME_STEP) reset_now = true;
                     else if (p.mode == CGE_AUTORESET_NEXT_STEP) e.needs_reset = 1;
                 }
@@ -424,6 +428,7 @@ struct cge_traffic : HandleBase {
         p.state = state; p.mt = mt; p.n = n; p.env0 = env0;
         p.cfg = traffic::Cfg{cfg.spawn_rate, cfg.max_vehicles, cfg.max_steps};
         p.mode = cfg.autoreset_mode;
+        p.ep_ret = ep_ret; p.ep_len = ep_len;
         return p;
     }
     unsigned blocks() const { return (unsigned)((n + traffic::BLOCK - 1) / traffic::BLOCK); }
@@ -622,6 +627,12 @@ int cge_traffic_set_state(cge_traffic *h, const void *host_buf, void *stream) {
 }
 
 size_t cge_traffic_device_bytes(const cge_traffic *h) { return h ? h->device_bytes : 0; }
+int cge_traffic_episode_stats(cge_traffic *h, double *return_out, int32_t *length_out) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    h->ep_ret = return_out; h->ep_len = length_out;
+    return CGE_OK;
+}
+
 const char *cge_traffic_last_error(const cge_traffic *h) { return h ? h->last_error.c_str() : "null handle"; }
 
 }  // extern "C"

@@ -25,7 +25,7 @@ class FleetVectorEnv(FlagsVectorEnv):
     metadata = {"render_modes": []}
 
     def __init__(self, num_envs, device="cuda:0", autoreset_mode="NextStep", env_index0=0, max_timesteps=800, reuse_buffers=False,
-                 info_fields=()):
+                 info_fields=(), record_episode_statistics=False):
         self._init_common(num_envs, device, autoreset_mode, env_index0, reuse_buffers)
         self.single_action_space = MultiDiscrete([8, 8, 8])
         self.single_observation_space = Box(-1.0, 25.0, (OBS_DIM,), np.float32)
@@ -36,3 +36,4 @@ class FleetVectorEnv(FlagsVectorEnv):
         _native.check(self._fn("create")(C.byref(cfg), self.num_envs, self._dev_index, self.env_index0, C.byref(h)), what="cge_fleet_create")
         self._h = h
         self._finish_init(info_fields)
+        self.record_episode_statistics(record_episode_statistics)

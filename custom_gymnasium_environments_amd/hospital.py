@@ -27,7 +27,7 @@ class HospitalVectorEnv(FlagsVectorEnv):
     metadata = {"render_modes": []}
 
     def __init__(self, num_envs, device="cuda:0", autoreset_mode="NextStep", env_index0=0, max_episode_length=1440, reuse_buffers=False,
-                 info_fields=()):
+                 info_fields=(), record_episode_statistics=False):
         self._init_common(num_envs, device, autoreset_mode, env_index0, reuse_buffers)
         self.single_action_space = Discrete(35)
         self.single_observation_space = Box(0.0, 1.0, (OBS_DIM,), np.float32)
@@ -38,3 +38,4 @@ class HospitalVectorEnv(FlagsVectorEnv):
         _native.check(self._fn("create")(C.byref(cfg), self.num_envs, self._dev_index, self.env_index0, C.byref(h)), what="cge_hospital_create")
         self._h = h
         self._finish_init(info_fields)
+        self.record_episode_statistics(record_episode_statistics)

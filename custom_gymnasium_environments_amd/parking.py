@@ -25,7 +25,7 @@ class ParkingVectorEnv(DeviceVectorEnv):
     metadata = {"render_modes": []}
 
     def __init__(self, num_envs, device="cuda:0", autoreset_mode="NextStep", env_index0=0, max_steps=1440, reuse_buffers=False,
-                 info_fields=()):
+                 info_fields=(), record_episode_statistics=False):
         self._init_common(num_envs, device, autoreset_mode, env_index0, reuse_buffers)
         self.single_action_space = Discrete(8)
         self.single_observation_space = Box(0.0, 1.0, (OBS_DIM,), np.float32)
@@ -38,6 +38,7 @@ class ParkingVectorEnv(DeviceVectorEnv):
                       what="cge_parking_create")
         self._h = h
         self._obs_shape = (self.num_envs, OBS_DIM)
+        self.record_episode_statistics(record_episode_statistics)
 
     def reset(self, *, seed=None, options=None):
         self._seed_native(seed)
@@ -65,7 +66,7 @@ class ParkingVectorEnv(DeviceVectorEnv):
         if same:
             infos["final_obs"] = fin
             infos["_final_obs"] = term
-        return obs, rew, term, trunc, infos
+        return obs, rew, term, trunc, self._episode_infos(infos, term)
 
     def rollout(self, k_steps, actions=None, action_seed=0, t0=0, trajectory=False, want_obs=True, per_step=False):
         k = int(k_steps)

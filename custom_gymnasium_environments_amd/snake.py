@@ -33,7 +33,7 @@ class SnakeVectorEnv(DeviceVectorEnv):
     metadata = {"render_modes": []}
 
     def __init__(self, num_envs, grid_size=20, device="cuda:0", autoreset_mode="NextStep", env_index0=0,
-                 max_steps=1000, reuse_buffers=False, info_fields=()):
+                 max_steps=1000, reuse_buffers=False, info_fields=(), record_episode_statistics=False):
         self._init_common(num_envs, device, autoreset_mode, env_index0, reuse_buffers)
         self.grid_size = int(grid_size)
         self.max_steps = int(max_steps)
@@ -53,6 +53,7 @@ class SnakeVectorEnv(DeviceVectorEnv):
         _native.check(st, what="cge_snake_create")
         self._h = h
         self._obs_shape = (self.num_envs, self.grid_size, self.grid_size)
+        self.record_episode_statistics(record_episode_statistics)
 
     # ------------------------------------------------------------------ gymnasium API
     def reset(self, *, seed=None, options=None):
@@ -82,7 +83,7 @@ class SnakeVectorEnv(DeviceVectorEnv):
             # rows of final_obs are valid where _final_obs is True (gymnasium's SAME_STEP convention)
             infos["final_obs"] = fin
             infos["_final_obs"] = term
-        return obs, rew, term, trunc, infos
+        return obs, rew, term, trunc, self._episode_infos(infos, term)
 
     def _never_truncated(self):
         t = self._bufs.get("_truncated")

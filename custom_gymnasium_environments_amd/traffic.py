@@ -29,7 +29,7 @@ class TrafficVectorEnv(DeviceVectorEnv):
     metadata = {"render_modes": []}
 
     def __init__(self, num_envs, device="cuda:0", autoreset_mode="NextStep", env_index0=0, grid_size=(5, 5),
-                 num_intersections=9, max_vehicles=50, spawn_rate=0.3, max_steps=1000, reuse_buffers=False, info_fields=()):
+                 num_intersections=9, max_vehicles=50, spawn_rate=0.3, max_steps=1000, reuse_buffers=False, info_fields=(), record_episode_statistics=False):
         self._init_common(num_envs, device, autoreset_mode, env_index0, reuse_buffers)
         cfg = _native.TrafficConfig()
         self._lib.cge_traffic_default_config(C.byref(cfg))
@@ -49,6 +49,7 @@ class TrafficVectorEnv(DeviceVectorEnv):
         _native.check(st, what="cge_traffic_create")
         self._h = h
         self._obs_shape = (self.num_envs, OBS_DIM)
+        self.record_episode_statistics(record_episode_statistics)
 
     def reset(self, *, seed=None, options=None):
         self._seed_native(seed)
@@ -76,7 +77,7 @@ class TrafficVectorEnv(DeviceVectorEnv):
         if same:
             infos["final_obs"] = fin
             infos["_final_obs"] = term
-        return obs, rew, term, trunc, infos
+        return obs, rew, term, trunc, self._episode_infos(infos, term)
 
     def rollout(self, k_steps, actions=None, action_seed=0, t0=0, trajectory=False, want_obs=True, per_step=False):
         """k fused step()s in one launch; see SnakeVectorEnv.rollout.  reward_sum is float64."""

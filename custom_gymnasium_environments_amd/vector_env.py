@@ -65,6 +65,7 @@ class DeviceVectorEnv(VectorEnvBase):
         self._lib = _native.lib()
         self._h = None
         self._bufs = {}
+        self._ep_ret = self._ep_len = None
         self.closed = False
 
     # ------------------------------------------------------------------ native helpers
@@ -119,6 +120,35 @@ class DeviceVectorEnv(VectorEnvBase):
 
     def device_bytes(self):
         return int(self._fn("device_bytes")(self._h))
+
+    # ------------------------------------------------------------------ episode statistics
+    def record_episode_statistics(self, enable=True):
+        """What gymnasium.wrappers.vector.RecordEpisodeStatistics adds around a vector env, computed by the step kernel itself:
+        with it enabled every step()'s infos carries `episode = {"r": float64[N], "l": int32[N]}` and the mask `_episode`
+        (= terminated | truncated); r / l of env i are the return (float64 sum of the episode's rewards in step order) and
+        the length in env steps of the episode that just ended — the numbers the reference's RLlib scripts report as
+        episode_return_mean / episode_len_mean (smart_parking_env/examples/training.py:55).  Entries where `_episode` is False
+        keep the env's previous episode.  Enable it before the episode starts (constructor flag or before reset())."""
+        if enable:
+            self._ep_ret = torch.zeros(self.num_envs, dtype=torch.float64, device=self.device)
+            self._ep_len = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+            self._check(self._fn("episode_stats")(self._h, self._ep_ret.data_ptr(), self._ep_len.data_ptr()), "episode_stats")
+        elif getattr(self, "_ep_ret", None) is not None:
+            torch.cuda.current_stream(self.device).synchronize()          # no kernel may still be writing the buffers
+            self._check(self._fn("episode_stats")(self._h, None, None), "episode_stats")
+            self._ep_ret = self._ep_len = None
+        else:
+            self._ep_ret = self._ep_len = None
+
+    def episode_statistics(self):
+        """(return float64[N], length int32[N]) of each env's last finished episode (also after a rollout()), or None."""
+        return None if self._ep_ret is None else (self._ep_ret, self._ep_len)
+
+    def _episode_infos(self, infos, done):
+        if self._ep_ret is not None:
+            infos["episode"] = {"r": self._ep_ret, "l": self._ep_len}
+            infos["_episode"] = done
+        return infos
 
     def snapshot(self):
         """Whole-batch checkpoint as an opaque uint8 array (env types without a canonical per-env `get_state` record).
@@ -179,6 +209,8 @@ class FlagsVectorEnv(DeviceVectorEnv):
         if same:
             infos["final_obs"] = fin
             infos["_final_obs"] = term | trunc
+        if self._ep_ret is not None:
+            self._episode_infos(infos, term | trunc)
         return obs, rew, term, trunc, infos
 
     def rollout(self, k_steps, actions=None, action_seed=0, t0=0, trajectory=False, want_obs=True, per_step=False):

@@ -14,6 +14,16 @@
  *   <env>_rollout  <->  the `while not done: env.step(a)` loops of the reference's scripts
  *                       (snake_env_classic/example.py:21-32) fused into one launch
  *   <env>_info     <->  the `info` dicts        snake_env.py:63,117
+ *   <env>_episode_stats <-> the per-episode return / length that the reference's training scripts read back from their
+ *                       vector-env wrapper as episode_return_mean / episode_len_mean
+ *                       (smart_parking_env/examples/training.py:55, smartclimate_rl-main/training/train.py): what
+ *                       gymnasium's RecordEpisodeStatistics publishes as infos["episode"] = {"r", "l"}.  Registers two
+ *                       caller-owned DEVICE buffers of n_envs elements (either may be NULL; both NULL unregisters): every later
+ *                       step() / rollout() writes, for each env that finishes an episode in that call and from inside the
+ *                       step kernel itself, the episode's return (float64 sum of its rewards in step order; the accumulator
+ *                       lives in the env's state record) and its length in env steps (a NEXT_STEP reset step is not a step
+ *                       of any episode).  Entries of envs that did not finish are left untouched; the "_episode" mask of a
+ *                       step is terminated | truncated.  A rollout leaves the LAST episode an env finished in it.
  *
  * Conventions
  *   - every function returns CGE_OK (0) or a negative cge_status; nothing throws across the ABI;
@@ -123,6 +133,7 @@ int cge_snake_set_state(cge_snake *h, const void *host_buf, void *stream);
 int64_t cge_snake_error_count(cge_snake *h, void *stream);
 /* bytes of device memory held by the handle (SoA state + RNG streams) */
 size_t cge_snake_device_bytes(const cge_snake *h);
+int cge_snake_episode_stats(cge_snake *h, double *return_out, int32_t *length_out);
 const char *cge_snake_last_error(const cge_snake *h);
 
 /* ------------------------------------------------------------------------------------------ */
@@ -185,13 +196,14 @@ int cge_crypto_rollout(cge_crypto *h, int32_t k_steps, const void *actions, uint
                        void *stream);
 int cge_crypto_info(cge_crypto *h, int32_t field_id, double *out, void *stream);
 /* canonical record (host), identical to the oracle's: int32[12] {regime, step, needs_reset, cash_kind,
- * P_idx, L_idx, has_gauss, episodes, 0,0,0,0}; double[6] {cash, holdings, psych, trend_strength, gauss, 0};
+ * P_idx, L_idx, has_gauss, episodes, 0,0,0,0}; double[6] {cash, holdings, psych, trend_strength, gauss, episode_return_so_far (the oracle writes 0)};
  * uint32 P[624]; uint32 L[624]; double hist[50][5] (O,H,L,C,V, oldest first; O/H/L/V round-trip
  * through float32 on the device). */
 size_t cge_crypto_state_bytes(const cge_crypto *h);
 int cge_crypto_get_state(cge_crypto *h, void *host_buf, void *stream);
 int cge_crypto_set_state(cge_crypto *h, const void *host_buf, void *stream);
 size_t cge_crypto_device_bytes(const cge_crypto *h);
+int cge_crypto_episode_stats(cge_crypto *h, double *return_out, int32_t *length_out);
 const char *cge_crypto_last_error(const cge_crypto *h);
 
 /* ------------------------------------------------------------------------------------------ */
@@ -253,6 +265,7 @@ size_t cge_traffic_state_bytes(const cge_traffic *h);
 int cge_traffic_get_state(cge_traffic *h, void *host_buf, void *stream);
 int cge_traffic_set_state(cge_traffic *h, const void *host_buf, void *stream);
 size_t cge_traffic_device_bytes(const cge_traffic *h);
+int cge_traffic_episode_stats(cge_traffic *h, double *return_out, int32_t *length_out);
 const char *cge_traffic_last_error(const cge_traffic *h);
 
 /* ------------------------------------------------------------------------------------------ */
@@ -304,6 +317,7 @@ size_t cge_parking_snapshot_bytes(const cge_parking *h);
 int cge_parking_snapshot_get(cge_parking *h, void *host_buf, void *stream);
 int cge_parking_snapshot_set(cge_parking *h, const void *host_buf, void *stream);
 size_t cge_parking_device_bytes(const cge_parking *h);
+int cge_parking_episode_stats(cge_parking *h, double *return_out, int32_t *length_out);
 const char *cge_parking_last_error(const cge_parking *h);
 
 /* ------------------------------------------------------------------------------------------ */
@@ -352,6 +366,7 @@ size_t cge_climate_snapshot_bytes(const cge_climate *h);
 int cge_climate_snapshot_get(cge_climate *h, void *host_buf, void *stream);
 int cge_climate_snapshot_set(cge_climate *h, const void *host_buf, void *stream);
 size_t cge_climate_device_bytes(const cge_climate *h);
+int cge_climate_episode_stats(cge_climate *h, double *return_out, int32_t *length_out);
 const char *cge_climate_last_error(const cge_climate *h);
 
 /* ------------------------------------------------------------------------------------------ */
@@ -393,6 +408,7 @@ size_t cge_fleet_snapshot_bytes(const cge_fleet *h);
 int cge_fleet_snapshot_get(cge_fleet *h, void *host_buf, void *stream);
 int cge_fleet_snapshot_set(cge_fleet *h, const void *host_buf, void *stream);
 size_t cge_fleet_device_bytes(const cge_fleet *h);
+int cge_fleet_episode_stats(cge_fleet *h, double *return_out, int32_t *length_out);
 const char *cge_fleet_last_error(const cge_fleet *h);
 
 /* ------------------------------------------------------------------------------------------ */
@@ -435,6 +451,7 @@ size_t cge_manufacturing_snapshot_bytes(const cge_manufacturing *h);
 int cge_manufacturing_snapshot_get(cge_manufacturing *h, void *host_buf, void *stream);
 int cge_manufacturing_snapshot_set(cge_manufacturing *h, const void *host_buf, void *stream);
 size_t cge_manufacturing_device_bytes(const cge_manufacturing *h);
+int cge_manufacturing_episode_stats(cge_manufacturing *h, double *return_out, int32_t *length_out);
 const char *cge_manufacturing_last_error(const cge_manufacturing *h);
 
 /* ------------------------------------------------------------------------------------------ */
@@ -478,6 +495,7 @@ size_t cge_hospital_snapshot_bytes(const cge_hospital *h);
 int cge_hospital_snapshot_get(cge_hospital *h, void *host_buf, void *stream);
 int cge_hospital_snapshot_set(cge_hospital *h, const void *host_buf, void *stream);
 size_t cge_hospital_device_bytes(const cge_hospital *h);
+int cge_hospital_episode_stats(cge_hospital *h, double *return_out, int32_t *length_out);
 const char *cge_hospital_last_error(const cge_hospital *h);
 
 #ifdef __cplusplus

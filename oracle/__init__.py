@@ -148,13 +148,22 @@ def _declare(L):
     L.orc_manufacturing_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.orc_manufacturing_rollout.argtypes = [vp, i32, u64, i64, i64, vp, vp, vp]
     L.orc_manufacturing_info.argtypes = [vp, i32, vp]
-
-
     for _nm in ("snake", "crypto", "traffic", "parking", "climate", "fleet", "hospital", "manufacturing"):
         getattr(L, f"orc_{_nm}_set_max_steps").argtypes = [vp, i32]
+        getattr(L, f"orc_{_nm}_episode_stats").argtypes = [vp, vp, vp]
 
 
 NEXT_STEP, SAME_STEP, DISABLED = 0, 1, 2
+
+
+class _EpisodeStats:
+    """(return float64[n], length int32[n]) of each env's LAST finished episode — what gymnasium's RecordEpisodeStatistics
+    would report in infos["episode"] = {"r", "l"} at the step the episode ended (oracle/orc_epstats.h)."""
+
+    def episode_stats(self):
+        ret, ln = np.zeros(self.n, np.float64), np.zeros(self.n, np.int32)
+        getattr(lib(), f"orc_{self._name}_episode_stats")(self.h, _p(ret), _p(ln))
+        return ret, ln
 
 
 class MT:
@@ -216,8 +225,9 @@ def hash_action(a_seed, env, t, n, j=0):
     return lib().orc_hash_action_export(a_seed, env, t, n, j)
 
 
-class SnakeOracle:
+class SnakeOracle(_EpisodeStats):
     """Batch of independent SnakeEnvClassic restatements (oracle/orc_snake.c)."""
+    _name = "snake"
 
     def __init__(self, n, grid=10, mode=SAME_STEP, max_steps=None):
         self.n, self.grid, self.mode = int(n), int(grid), int(mode)
@@ -284,8 +294,9 @@ CRYPTO_INFO = {"portfolio_value": 0, "cash": 1, "holdings": 2, "current_price": 
                "regime": 5, "step": 6, "trend_strength": 7, "episodes": 8, "needs_reset": 9, "cash_kind": 10}
 
 
-class CryptoOracle:
+class CryptoOracle(_EpisodeStats):
     """Batch of independent CryptoTradingEnv restatements (oracle/orc_crypto.c)."""
+    _name = "crypto"
 
     def __init__(self, n, action_type="discrete", mode=SAME_STEP, max_steps=None):
         self.n, self.mode = int(n), int(mode)
@@ -359,8 +370,9 @@ TRAFFIC_INFO = {"timestep": 0, "num_vehicles": 1, "light_phase": 2, "light_timer
                 "total_waiting_time": 5, "queue_len": 6, "queue_dest": 7, "queue_wait": 8, "episodes": 9, "needs_reset": 10}
 
 
-class TrafficOracle:
+class TrafficOracle(_EpisodeStats):
     """Batch of independent TrafficManagementEnv restatements (oracle/orc_traffic.c)."""
+    _name = "traffic"
 
     def __init__(self, n, mode=SAME_STEP, max_steps=None):
         self.n, self.mode = int(n), int(mode)
@@ -432,7 +444,7 @@ PARKING_INFO = {"timestep": 0, "total_customers": 1, "rejected": 2, "satisfied":
                 "price_changes_this_hour": 6, "zone_occupied": 7, "price_level": 8, "episodes": 9, "needs_reset": 10}
 
 
-class _SimpleOracle:
+class _SimpleOracle(_EpisodeStats):
     """Shared ctypes plumbing for the small discrete-action envs (int32 action per env, float32 obs)."""
     _name = None
     _obs = None

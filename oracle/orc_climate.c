@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include "orc_rng.h"
+#include "orc_epstats.h"
 
 #define COBS 9
 
@@ -22,7 +23,7 @@ typedef struct {
     int num_people, step, lights[4], comfort_time, needs_reset, episodes;
 } climate_env;
 
-typedef struct { int64_t n; int mode, max_occupancy, episode_minutes; climate_env *e; } orc_climate;
+typedef struct { int64_t n; int mode, max_occupancy, episode_minutes; climate_env *e; orc_eps eps; } orc_climate;
 
 static double outside_temp(double tod, orc_pcg *g) {                      /* utils.py:5-13 */
     double base = (0 <= tod && tod < 8) ? 25 : (8 <= tod && tod < 16) ? 45 : 35;
@@ -87,16 +88,17 @@ orc_climate *orc_climate_create(int64_t n, int mode) {
     orc_climate *h = (orc_climate *)calloc(1, sizeof(*h));
     h->n = n; h->mode = mode; h->max_occupancy = 8; h->episode_minutes = 1440;
     h->e = (climate_env *)calloc((size_t)n, sizeof(climate_env));
+    eps_init(&h->eps, n);
     for (int64_t i = 0; i < n; ++i) orc_pcg_seed(&h->e[i].g, (uint64_t)i);
     return h;
 }
-void orc_climate_destroy(orc_climate *h) { if (h) { free(h->e); free(h); } }
+void orc_climate_destroy(orc_climate *h) { if (h) { free(h->e); eps_free(&h->eps); free(h); } }
 /* reset(seed=s): self.rng = np.random.default_rng(s) */
 void orc_climate_seed(orc_climate *h, const uint64_t *seeds) { for (int64_t i = 0; i < h->n; ++i) orc_pcg_seed(&h->e[i].g, seeds[i]); }
 
 void orc_climate_reset(orc_climate *h, const uint8_t *mask, float *obs) {
     for (int64_t i = 0; i < h->n; ++i) {
-        if (!mask || mask[i]) env_reset(h, &h->e[i]);
+        if (!mask || mask[i]) { env_reset(h, &h->e[i]); eps_clear(&h->eps, i); }
         if (obs) write_obs(&h->e[i], obs + i * COBS);
     }
 }
@@ -107,18 +109,19 @@ void orc_climate_step(orc_climate *h, const float *ac_temp, const int8_t *lights
         climate_env *e = &h->e[i];
         float *o = obs + i * COBS;
         if (h->mode == 0 && e->needs_reset) {
-            env_reset(h, e); write_obs(e, o);
+            { env_reset(h, e); eps_clear(&h->eps, i); } write_obs(e, o);
             reward[i] = 0.0f; if (reward64) reward64[i] = 0.0; terminated[i] = 0; truncated[i] = 0;
             continue;
         }
         double r;
         int term = env_step(h, e, ac_temp[i], lights + 4 * i, &r);
+        eps_add(&h->eps, i, (double)r);
         reward[i] = (float)r; if (reward64) reward64[i] = r;
         terminated[i] = (uint8_t)term; truncated[i] = 0;
-        if (term) e->episodes += 1;
+        if (term) { e->episodes += 1; eps_done(&h->eps, i); }
         if (term && h->mode == 1) {
             if (final_obs) write_obs(e, final_obs + i * COBS);
-            env_reset(h, e); write_obs(e, o);
+            { env_reset(h, e); eps_clear(&h->eps, i); } write_obs(e, o);
         } else {
             write_obs(e, o);
             if (term && h->mode == 0) e->needs_reset = 1;
@@ -140,13 +143,14 @@ void orc_climate_rollout(orc_climate *h, int k_steps, uint64_t a_seed, int64_t t
         double rs = 0.0;
         int dc = 0;
         for (int t = 0; t < k_steps; ++t) {
-            if (h->mode == 0 && e->needs_reset) { env_reset(h, e); continue; }
+            if (h->mode == 0 && e->needs_reset) { { env_reset(h, e); eps_clear(&h->eps, i); } continue; }
             float ac; int8_t li[4];
             orc_climate_hash_action(a_seed, (uint64_t)(env0 + i), (uint64_t)(t0 + t), &ac, li);
             double r;
             int term = env_step(h, e, ac, li, &r);
+            eps_add(&h->eps, i, (double)r);
             rs += r;
-            if (term) { ++dc; e->episodes += 1; if (h->mode == 1) env_reset(h, e); else if (h->mode == 0) e->needs_reset = 1; }
+            if (term) { ++dc; e->episodes += 1; eps_done(&h->eps, i); if (h->mode == 1) { env_reset(h, e); eps_clear(&h->eps, i); } else if (h->mode == 0) e->needs_reset = 1; }
         }
         if (obs) write_obs(e, obs + i * COBS);
         if (reward_sum) reward_sum[i] = rs;
@@ -172,3 +176,6 @@ void orc_climate_info(const orc_climate *h, int field, double *out) {
 /* Time-limit override for the short-horizon parity tests (the reference's limit is a constructor constant /
  * config value; the device ABI takes it in its config struct).  Call before reset(). */
 void orc_climate_set_max_steps(orc_climate *h, int v) { h->episode_minutes = v; }
+
+/* return and length of each env's last finished episode (orc_epstats.h) */
+void orc_climate_episode_stats(const orc_climate *h, double *ret, int32_t *len) { eps_get(&h->eps, h->n, ret, len); }

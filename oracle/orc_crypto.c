@@ -25,6 +25,7 @@
 #include <string.h>
 
 #include "orc_rng.h"
+#include "orc_epstats.h"
 
 #define HLEN 50
 enum { BULL = 0, BEAR = 1, SIDEWAYS = 2, CRASH = 3, RECOVERY = 4 };
@@ -48,7 +49,7 @@ typedef struct {
     int64_t n;
     int mode;
     crypto_cfg c;
-    crypto_env *e;
+    crypto_env *e; orc_eps eps;
 } orc_crypto;
 
 static const double VOL_MULT[5] = {1.2, 1.5, 0.8, 3.0, 2.0};           /* :190-196 */
@@ -272,6 +273,7 @@ orc_crypto *orc_crypto_create(int64_t n, int continuous, int mode) {
     h->n = n; h->mode = mode;
     h->c = (crypto_cfg){10000.0, 0.001, 0.0005, 100.0, 100000.0, 0.02, 0.1, 1000, continuous};   /* :28-38, :278 */
     h->e = (crypto_env *)calloc((size_t)n, sizeof(crypto_env));
+    eps_init(&h->eps, n);
     for (int64_t i = 0; i < n; ++i) {
         crypto_env *e = &h->e[i];
         orc_py_seed(&e->P, (uint64_t)i); orc_np_seed(&e->L, (uint32_t)i);
@@ -280,7 +282,7 @@ orc_crypto *orc_crypto_create(int64_t n, int continuous, int mode) {
     }
     return h;
 }
-void orc_crypto_destroy(orc_crypto *h) { if (h) { free(h->e); free(h); } }
+void orc_crypto_destroy(orc_crypto *h) { if (h) { free(h->e); eps_free(&h->eps); free(h); } }
 
 /* reset(seed=s): random.seed(s); np.random.seed(s)  (:305-307).  The MarketSimulator is NOT re-created. */
 void orc_crypto_seed(orc_crypto *h, const uint64_t *seeds) {
@@ -289,7 +291,7 @@ void orc_crypto_seed(orc_crypto *h, const uint64_t *seeds) {
 
 void orc_crypto_reset(orc_crypto *h, const uint8_t *mask, float *obs) {
     for (int64_t i = 0; i < h->n; ++i) {
-        if (!mask || mask[i]) env_reset(h, &h->e[i]);
+        if (!mask || mask[i]) { env_reset(h, &h->e[i]); eps_clear(&h->eps, i); }
         if (obs) write_obs(h, &h->e[i], obs + i * CRYPTO_OBS);
     }
 }
@@ -302,7 +304,7 @@ int orc_crypto_step(orc_crypto *h, const void *actions, float *obs, float *rewar
         crypto_env *e = &h->e[i];
         float *o = obs + i * CRYPTO_OBS;
         if (h->mode == 0 && e->needs_reset) {
-            env_reset(h, e);
+            { env_reset(h, e); eps_clear(&h->eps, i); }
             write_obs(h, e, o);
             reward[i] = 0.0f; if (reward64) reward64[i] = 0.0; terminated[i] = 0; truncated[i] = 0;
             continue;
@@ -316,13 +318,14 @@ int orc_crypto_step(orc_crypto *h, const void *actions, float *obs, float *rewar
         }
         double r;
         int term = env_step(h, e, a, ac, &r);
+        eps_add(&h->eps, i, (double)r);
         reward[i] = (float)r; if (reward64) reward64[i] = r;
         terminated[i] = (uint8_t)term; truncated[i] = 0;
         e->last_reward = r;
-        if (term) e->episodes += 1;
+        if (term) { e->episodes += 1; eps_done(&h->eps, i); }
         if (term && h->mode == 1) {
             if (final_obs) write_obs(h, e, final_obs + i * CRYPTO_OBS);
-            env_reset(h, e);
+            { env_reset(h, e); eps_clear(&h->eps, i); }
             write_obs(h, e, o);
         } else {
             write_obs(h, e, o);
@@ -343,7 +346,7 @@ void orc_crypto_rollout(orc_crypto *h, int k_steps, uint64_t a_seed, int64_t t0,
         double rs = 0.0;
         int dc = 0;
         for (int t = 0; t < k_steps; ++t) {
-            if (h->mode == 0 && e->needs_reset) { env_reset(h, e); continue; }
+            if (h->mode == 0 && e->needs_reset) { { env_reset(h, e); eps_clear(&h->eps, i); } continue; }
             int a = (int)orc_hash_action(a_seed, (uint64_t)(env0 + i), (uint64_t)(t0 + t), 5, 0);
             float ac[2] = {0, 0};
             if (h->c.continuous) {
@@ -352,11 +355,12 @@ void orc_crypto_rollout(orc_crypto *h, int k_steps, uint64_t a_seed, int64_t t0,
             }
             double r;
             int term = env_step(h, e, a, ac, &r);
+            eps_add(&h->eps, i, (double)r);
             rs += r;
             if (obs) write_obs(h, e, scratch);
             if (term) {
-                ++dc; e->episodes += 1;
-                if (h->mode == 1) env_reset(h, e);
+                ++dc; e->episodes += 1; eps_done(&h->eps, i);
+                if (h->mode == 1) { env_reset(h, e); eps_clear(&h->eps, i); }
                 else if (h->mode == 0) e->needs_reset = 1;
             }
         }
@@ -429,3 +433,6 @@ void orc_crypto_set_state(orc_crypto *h, const void *buf) {
 /* Time-limit override for the short-horizon parity tests (the reference's limit is a constructor constant /
  * config value; the device ABI takes it in its config struct).  Call before reset(). */
 void orc_crypto_set_max_steps(orc_crypto *h, int v) { h->c.max_steps = v; }
+
+/* return and length of each env's last finished episode (orc_epstats.h) */
+void orc_crypto_episode_stats(const orc_crypto *h, double *ret, int32_t *len) { eps_get(&h->eps, h->n, ret, len); }

@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include "orc_rng.h"
+#include "orc_epstats.h"
 
 #define FOBS 76
 #define MAXD 12
@@ -34,7 +35,7 @@ typedef struct {
     double weather, total_reward;
 } fleet_env;
 
-typedef struct { int64_t n; int mode, max_steps; fleet_env *e; } orc_fleet;
+typedef struct { int64_t n; int mode, max_steps; fleet_env *e; orc_eps eps; } orc_fleet;
 
 static const double VRANGE[3] = {80, 120, 60}, VCONS[3] = {1.0, 0.5, 2.0};   /* van, motorcycle, truck :128-132 */
 static const int VCAP[3] = {3, 1, 5};
@@ -193,16 +194,17 @@ orc_fleet *orc_fleet_create(int64_t n, int mode) {
     orc_fleet *h = (orc_fleet *)calloc(1, sizeof(*h));
     h->n = n; h->mode = mode; h->max_steps = 800;
     h->e = (fleet_env *)calloc((size_t)n, sizeof(fleet_env));
+    eps_init(&h->eps, n);
     for (int64_t i = 0; i < n; ++i) { orc_py_seed(&h->e[i].P, (uint64_t)i); orc_np_seed(&h->e[i].L, (uint32_t)i); h->e[i].weather = 1.0; }
     return h;
 }
-void orc_fleet_destroy(orc_fleet *h) { if (h) { free(h->e); free(h); } }
+void orc_fleet_destroy(orc_fleet *h) { if (h) { free(h->e); eps_free(&h->eps); free(h); } }
 void orc_fleet_seed(orc_fleet *h, const uint64_t *seeds) {
     for (int64_t i = 0; i < h->n; ++i) { orc_py_seed(&h->e[i].P, seeds[i]); orc_np_seed(&h->e[i].L, (uint32_t)seeds[i]); }
 }
 void orc_fleet_reset(orc_fleet *h, const uint8_t *mask, float *obs) {
     for (int64_t i = 0; i < h->n; ++i) {
-        if (!mask || mask[i]) env_reset(h, &h->e[i]);
+        if (!mask || mask[i]) { env_reset(h, &h->e[i]); eps_clear(&h->eps, i); }
         if (obs) write_obs(&h->e[i], obs + i * FOBS);
     }
 }
@@ -213,18 +215,19 @@ void orc_fleet_step(orc_fleet *h, const int32_t *actions, float *obs, float *rew
         fleet_env *e = &h->e[i];
         float *o = obs + i * FOBS;
         if (h->mode == 0 && e->needs_reset) {
-            env_reset(h, e); write_obs(e, o);
+            { env_reset(h, e); eps_clear(&h->eps, i); } write_obs(e, o);
             reward[i] = 0.0f; if (reward64) reward64[i] = 0.0; terminated[i] = 0; truncated[i] = 0;
             continue;
         }
         double r;
         int f = env_step(h, e, actions + 3 * i, &r);
+        eps_add(&h->eps, i, (double)r);
         reward[i] = (float)r; if (reward64) reward64[i] = r;
         terminated[i] = (uint8_t)(f & 1); truncated[i] = (uint8_t)((f >> 1) & 1);
-        if (f) e->episodes += 1;
+        if (f) { e->episodes += 1; eps_done(&h->eps, i); }
         if (f && h->mode == 1) {
             if (final_obs) write_obs(e, final_obs + i * FOBS);
-            env_reset(h, e); write_obs(e, o);
+            { env_reset(h, e); eps_clear(&h->eps, i); } write_obs(e, o);
         } else {
             write_obs(e, o);
             if (f && h->mode == 0) e->needs_reset = 1;
@@ -239,13 +242,14 @@ void orc_fleet_rollout(orc_fleet *h, int k_steps, uint64_t a_seed, int64_t t0, i
         double rs = 0.0;
         int dc = 0;
         for (int t = 0; t < k_steps; ++t) {
-            if (h->mode == 0 && e->needs_reset) { env_reset(h, e); continue; }
+            if (h->mode == 0 && e->needs_reset) { { env_reset(h, e); eps_clear(&h->eps, i); } continue; }
             int32_t a[3];
             for (int j = 0; j < 3; ++j) a[j] = (int32_t)orc_hash_action(a_seed, (uint64_t)(env0 + i), (uint64_t)(t0 + t), 8, (uint32_t)j);
             double r;
             int f = env_step(h, e, a, &r);
+            eps_add(&h->eps, i, (double)r);
             rs += r;
-            if (f) { ++dc; e->episodes += 1; if (h->mode == 1) env_reset(h, e); else if (h->mode == 0) e->needs_reset = 1; }
+            if (f) { ++dc; e->episodes += 1; eps_done(&h->eps, i); if (h->mode == 1) { env_reset(h, e); eps_clear(&h->eps, i); } else if (h->mode == 0) e->needs_reset = 1; }
         }
         if (obs) write_obs(e, obs + i * FOBS);
         if (reward_sum) reward_sum[i] = rs;
@@ -271,3 +275,6 @@ void orc_fleet_info(const orc_fleet *h, int field, double *out) {
 /* Time-limit override for the short-horizon parity tests (the reference's limit is a constructor constant /
  * config value; the device ABI takes it in its config struct).  Call before reset(). */
 void orc_fleet_set_max_steps(orc_fleet *h, int v) { h->max_steps = v; }
+
+/* return and length of each env's last finished episode (orc_epstats.h) */
+void orc_fleet_episode_stats(const orc_fleet *h, double *ret, int32_t *len) { eps_get(&h->eps, h->n, ret, len); }

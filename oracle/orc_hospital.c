@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include "orc_rng.h"
+#include "orc_epstats.h"
 
 #define HOBS 243
 #define NDOC 15
@@ -43,7 +44,7 @@ typedef struct {
     pqueue q[6];
 } henv;
 
-typedef struct { int64_t n; int mode, max_steps; henv *e; } orc_hospital;
+typedef struct { int64_t n; int mode, max_steps; henv *e; orc_eps eps; } orc_hospital;
 
 static const int DEPT_POS[6][2] = {{0, 0}, {5, 0}, {9, 0}, {0, 5}, {7, 5}, {10, 5}};      /* department_configs :97-104 */
 static const int DEPT_SIZE[6][2] = {{4, 4}, {3, 3}, {4, 2}, {6, 4}, {2, 2}, {3, 3}};
@@ -287,15 +288,16 @@ orc_hospital *orc_hospital_create(int64_t n, int mode) {
     orc_hospital *h = (orc_hospital *)calloc(1, sizeof(*h));
     h->n = n; h->mode = mode; h->max_steps = 1440;
     h->e = (henv *)calloc((size_t)n, sizeof(henv));
+    eps_init(&h->eps, n);
     for (int64_t i = 0; i < n; ++i) orc_py_seed(&h->e[i].P, (uint64_t)i);
     return h;
 }
-void orc_hospital_destroy(orc_hospital *h) { if (h) { free(h->e); free(h); } }
+void orc_hospital_destroy(orc_hospital *h) { if (h) { free(h->e); eps_free(&h->eps); free(h); } }
 void orc_hospital_seed(orc_hospital *h, const uint64_t *seeds) { for (int64_t i = 0; i < h->n; ++i) orc_py_seed(&h->e[i].P, seeds[i]); }
 
 void orc_hospital_reset(orc_hospital *h, const uint8_t *mask, float *obs) {
     for (int64_t i = 0; i < h->n; ++i) {
-        if (!mask || mask[i]) env_reset(&h->e[i]);
+        if (!mask || mask[i]) { env_reset(&h->e[i]); eps_clear(&h->eps, i); }
         if (obs) write_obs(h, &h->e[i], obs + i * HOBS);
     }
 }
@@ -306,18 +308,19 @@ void orc_hospital_step(orc_hospital *h, const int32_t *actions, float *obs, floa
         henv *e = &h->e[i];
         float *o = obs + i * HOBS;
         if (h->mode == 0 && e->needs_reset) {
-            env_reset(e); write_obs(h, e, o);
+            { env_reset(e); eps_clear(&h->eps, i); } write_obs(h, e, o);
             reward[i] = 0.0f; if (reward64) reward64[i] = 0.0; terminated[i] = 0; truncated[i] = 0;
             continue;
         }
         double r;
         int f = env_step(h, e, actions[i], &r);
+        eps_add(&h->eps, i, (double)r);
         reward[i] = (float)r; if (reward64) reward64[i] = r;
         terminated[i] = (uint8_t)(f & 1); truncated[i] = (uint8_t)(f >> 1);
-        if (f) e->episodes += 1;
+        if (f) { e->episodes += 1; eps_done(&h->eps, i); }
         if (f && h->mode == 1) {
             if (final_obs) write_obs(h, e, final_obs + i * HOBS);
-            env_reset(e); write_obs(h, e, o);
+            { env_reset(e); eps_clear(&h->eps, i); } write_obs(h, e, o);
         } else {
             write_obs(h, e, o);
             if (f && h->mode == 0) e->needs_reset = 1;
@@ -332,11 +335,12 @@ void orc_hospital_rollout(orc_hospital *h, int k_steps, uint64_t a_seed, int64_t
         double rs = 0.0;
         int dc = 0;
         for (int t = 0; t < k_steps; ++t) {
-            if (h->mode == 0 && e->needs_reset) { env_reset(e); continue; }
+            if (h->mode == 0 && e->needs_reset) { { env_reset(e); eps_clear(&h->eps, i); } continue; }
             double r;
             int f = env_step(h, e, (int)orc_hash_action(a_seed, (uint64_t)(env0 + i), (uint64_t)(t0 + t), 35, 0), &r);
+            eps_add(&h->eps, i, (double)r);
             rs += r;
-            if (f) { ++dc; e->episodes += 1; if (h->mode == 1) env_reset(e); else if (h->mode == 0) e->needs_reset = 1; }
+            if (f) { ++dc; e->episodes += 1; eps_done(&h->eps, i); if (h->mode == 1) { env_reset(e); eps_clear(&h->eps, i); } else if (h->mode == 0) e->needs_reset = 1; }
         }
         if (obs) write_obs(h, e, obs + i * HOBS);
         if (reward_sum) reward_sum[i] = rs;
@@ -366,3 +370,6 @@ void orc_hospital_info(const orc_hospital *h, int field, double *out) {
 /* Time-limit override for the short-horizon parity tests (the reference's limit is a constructor constant /
  * config value; the device ABI takes it in its config struct).  Call before reset(). */
 void orc_hospital_set_max_steps(orc_hospital *h, int v) { h->max_steps = v; }
+
+/* return and length of each env's last finished episode (orc_epstats.h) */
+void orc_hospital_episode_stats(const orc_hospital *h, double *ret, int32_t *len) { eps_get(&h->eps, h->n, ret, len); }

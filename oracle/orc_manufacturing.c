@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include "orc_rng.h"
+#include "orc_epstats.h"
 
 #define MOBS 73
 #define MCAP 512      /* products started per episode: <= (250 + 29*99)/10 = 312 inside an episode */
@@ -47,7 +48,7 @@ typedef struct {
     int needs_reset, episodes, overflow;
 } menv;
 
-typedef struct { int64_t n; int mode, max_steps; menv *e; } orc_manufacturing;
+typedef struct { int64_t n; int mode, max_steps; menv *e; orc_eps eps; } orc_manufacturing;
 
 /* NumPy pairwise summation (loops_utils.h.src pairwise_sum), any n */
 static double np_sum(const double *a, int n) {
@@ -236,16 +237,17 @@ orc_manufacturing *orc_manufacturing_create(int64_t n, int mode) {
     orc_manufacturing *h = (orc_manufacturing *)calloc(1, sizeof(*h));
     h->n = n; h->mode = mode; h->max_steps = 1500;
     h->e = (menv *)calloc((size_t)n, sizeof(menv));
+    eps_init(&h->eps, n);
     for (int64_t i = 0; i < n; ++i) { orc_pcg_seed(&h->e[i].g, (uint64_t)i); h->e[i].thr[0] = 0.70; h->e[i].thr[1] = 0.80; h->e[i].thr[2] = 0.85; h->e[i].raw = 250; }
     return h;
 }
-void orc_manufacturing_destroy(orc_manufacturing *h) { if (h) { free(h->e); free(h); } }
+void orc_manufacturing_destroy(orc_manufacturing *h) { if (h) { free(h->e); eps_free(&h->eps); free(h); } }
 /* reset(seed=s): self.np_random = Generator(PCG64(SeedSequence(s))) */
 void orc_manufacturing_seed(orc_manufacturing *h, const uint64_t *seeds) { for (int64_t i = 0; i < h->n; ++i) orc_pcg_seed(&h->e[i].g, seeds[i]); }
 
 void orc_manufacturing_reset(orc_manufacturing *h, const uint8_t *mask, float *obs) {
     for (int64_t i = 0; i < h->n; ++i) {
-        if (!mask || mask[i]) env_reset(&h->e[i]);
+        if (!mask || mask[i]) { env_reset(&h->e[i]); eps_clear(&h->eps, i); }
         if (obs) write_obs(&h->e[i], obs + i * MOBS);
     }
 }
@@ -256,18 +258,19 @@ void orc_manufacturing_step(orc_manufacturing *h, const int32_t *actions, float 
         menv *e = &h->e[i];
         float *o = obs + i * MOBS;
         if (h->mode == 0 && e->needs_reset) {
-            env_reset(e); write_obs(e, o);
+            { env_reset(e); eps_clear(&h->eps, i); } write_obs(e, o);
             reward[i] = 0.0f; if (reward64) reward64[i] = 0.0; terminated[i] = 0; truncated[i] = 0;
             continue;
         }
         double r;
         int f = env_step(h, e, actions[i], &r);
+        eps_add(&h->eps, i, (double)r);
         reward[i] = (float)r; if (reward64) reward64[i] = r;
         terminated[i] = (uint8_t)(f & 1); truncated[i] = (uint8_t)(f >> 1);
-        if (f) e->episodes += 1;
+        if (f) { e->episodes += 1; eps_done(&h->eps, i); }
         if (f && h->mode == 1) {
             if (final_obs) write_obs(e, final_obs + i * MOBS);
-            env_reset(e); write_obs(e, o);
+            { env_reset(e); eps_clear(&h->eps, i); } write_obs(e, o);
         } else {
             write_obs(e, o);
             if (f && h->mode == 0) e->needs_reset = 1;
@@ -282,11 +285,12 @@ void orc_manufacturing_rollout(orc_manufacturing *h, int k_steps, uint64_t a_see
         double rs = 0.0;
         int dc = 0;
         for (int t = 0; t < k_steps; ++t) {
-            if (h->mode == 0 && e->needs_reset) { env_reset(e); continue; }
+            if (h->mode == 0 && e->needs_reset) { { env_reset(e); eps_clear(&h->eps, i); } continue; }
             double r;
             int f = env_step(h, e, (int)orc_hash_action(a_seed, (uint64_t)(env0 + i), (uint64_t)(t0 + t), 25, 0), &r);
+            eps_add(&h->eps, i, (double)r);
             rs += r;
-            if (f) { ++dc; e->episodes += 1; if (h->mode == 1) env_reset(e); else if (h->mode == 0) e->needs_reset = 1; }
+            if (f) { ++dc; e->episodes += 1; eps_done(&h->eps, i); if (h->mode == 1) { env_reset(e); eps_clear(&h->eps, i); } else if (h->mode == 0) e->needs_reset = 1; }
         }
         if (obs) write_obs(e, obs + i * MOBS);
         if (reward_sum) reward_sum[i] = rs;
@@ -317,3 +321,6 @@ void orc_manufacturing_info(const orc_manufacturing *h, int field, double *out) 
 /* Time-limit override for the short-horizon parity tests (the reference's limit is a constructor constant /
  * config value; the device ABI takes it in its config struct).  Call before reset(). */
 void orc_manufacturing_set_max_steps(orc_manufacturing *h, int v) { h->max_steps = v; }
+
+/* return and length of each env's last finished episode (orc_epstats.h) */
+void orc_manufacturing_episode_stats(const orc_manufacturing *h, double *ret, int32_t *len) { eps_get(&h->eps, h->n, ret, len); }

@@ -24,6 +24,7 @@
 #include <string.h>
 
 #include "orc_rng.h"
+#include "orc_epstats.h"
 
 #define NSPOT 50
 #define QMAX 10
@@ -45,7 +46,7 @@ typedef struct {
     double revenue, satisfaction_sum;
 } parking_env;
 
-typedef struct { int64_t n; int mode, max_steps; parking_env *e; } orc_parking;
+typedef struct { int64_t n; int mode, max_steps; parking_env *e; orc_eps eps; } orc_parking;
 
 static void env_reset(parking_env *e) {                                  /* parking_env.py:70-108, no draws */
     memset(e->s, 0, sizeof e->s);
@@ -175,15 +176,16 @@ orc_parking *orc_parking_create(int64_t n, int mode) {
     orc_parking *h = (orc_parking *)calloc(1, sizeof(*h));
     h->n = n; h->mode = mode; h->max_steps = 1440;
     h->e = (parking_env *)calloc((size_t)n, sizeof(parking_env));
-    for (int64_t i = 0; i < n; ++i) { orc_py_seed(&h->e[i].P, (uint64_t)i); env_reset(&h->e[i]); }
+    eps_init(&h->eps, n);
+    for (int64_t i = 0; i < n; ++i) { orc_py_seed(&h->e[i].P, (uint64_t)i); { env_reset(&h->e[i]); eps_clear(&h->eps, i); } }
     return h;
 }
-void orc_parking_destroy(orc_parking *h) { if (h) { free(h->e); free(h); } }
+void orc_parking_destroy(orc_parking *h) { if (h) { free(h->e); eps_free(&h->eps); free(h); } }
 void orc_parking_seed(orc_parking *h, const uint64_t *seeds) { for (int64_t i = 0; i < h->n; ++i) orc_py_seed(&h->e[i].P, seeds[i]); }
 
 void orc_parking_reset(orc_parking *h, const uint8_t *mask, float *obs) {
     for (int64_t i = 0; i < h->n; ++i) {
-        if (!mask || mask[i]) env_reset(&h->e[i]);
+        if (!mask || mask[i]) { env_reset(&h->e[i]); eps_clear(&h->eps, i); }
         if (obs) write_obs(&h->e[i], obs + i * POBS);
     }
 }
@@ -194,18 +196,19 @@ void orc_parking_step(orc_parking *h, const int32_t *actions, float *obs, float 
         parking_env *e = &h->e[i];
         float *o = obs + i * POBS;
         if (h->mode == 0 && e->needs_reset) {
-            env_reset(e); write_obs(e, o);
+            { env_reset(e); eps_clear(&h->eps, i); } write_obs(e, o);
             reward[i] = 0.0f; if (reward64) reward64[i] = 0.0; terminated[i] = 0; truncated[i] = 0;
             continue;
         }
         double r;
         int term = env_step(h, e, actions[i], &r);
+        eps_add(&h->eps, i, (double)r);
         reward[i] = (float)r; if (reward64) reward64[i] = r;
         terminated[i] = (uint8_t)term; truncated[i] = 0;
-        if (term) e->episodes += 1;
+        if (term) { e->episodes += 1; eps_done(&h->eps, i); }
         if (term && h->mode == 1) {
             if (final_obs) write_obs(e, final_obs + i * POBS);
-            env_reset(e); write_obs(e, o);
+            { env_reset(e); eps_clear(&h->eps, i); } write_obs(e, o);
         } else {
             write_obs(e, o);
             if (term && h->mode == 0) e->needs_reset = 1;
@@ -221,12 +224,13 @@ void orc_parking_rollout(orc_parking *h, int k_steps, uint64_t a_seed, int64_t t
         double rs = 0.0;
         int dc = 0;
         for (int t = 0; t < k_steps; ++t) {
-            if (h->mode == 0 && e->needs_reset) { env_reset(e); continue; }
+            if (h->mode == 0 && e->needs_reset) { { env_reset(e); eps_clear(&h->eps, i); } continue; }
             double r;
             int term = env_step(h, e, (int)orc_hash_action(a_seed, (uint64_t)(env0 + i), (uint64_t)(t0 + t), 8, 0), &r);
+            eps_add(&h->eps, i, (double)r);
             rs += r;
             if (obs) write_obs(e, scratch);
-            if (term) { ++dc; e->episodes += 1; if (h->mode == 1) env_reset(e); else if (h->mode == 0) e->needs_reset = 1; }
+            if (term) { ++dc; e->episodes += 1; eps_done(&h->eps, i); if (h->mode == 1) { env_reset(e); eps_clear(&h->eps, i); } else if (h->mode == 0) e->needs_reset = 1; }
         }
         if (obs) write_obs(e, obs + i * POBS);
         if (reward_sum) reward_sum[i] = rs;
@@ -264,3 +268,6 @@ void orc_parking_info64(const orc_parking *h, int field, double *out) {
 /* Time-limit override for the short-horizon parity tests (the reference's limit is a constructor constant /
  * config value; the device ABI takes it in its config struct).  Call before reset(). */
 void orc_parking_set_max_steps(orc_parking *h, int v) { h->max_steps = v; }
+
+/* return and length of each env's last finished episode (orc_epstats.h) */
+void orc_parking_episode_stats(const orc_parking *h, double *ret, int32_t *len) { eps_get(&h->eps, h->n, ret, len); }

@@ -21,6 +21,7 @@
 #include <string.h>
 
 #include "orc_rng.h"
+#include "orc_epstats.h"
 
 #define SNAKE_MAX_G 32
 
@@ -38,7 +39,7 @@ typedef struct {
 typedef struct {
     int64_t n;
     int G, mode, max_steps;
-    snake_env *e;
+    snake_env *e; orc_eps eps;
 } orc_snake;
 
 static void place_food(orc_snake *h, snake_env *e) {      /* snake_env.py:121-129 */
@@ -106,11 +107,12 @@ orc_snake *orc_snake_create(int64_t n, int grid, int mode) {
     orc_snake *h = (orc_snake *)calloc(1, sizeof(*h));
     h->n = n; h->G = grid; h->mode = mode; h->max_steps = 1000;              /* :47 */
     h->e = (snake_env *)calloc((size_t)n, sizeof(snake_env));
+    eps_init(&h->eps, n);
     for (int64_t i = 0; i < n; ++i) orc_py_seed(&h->e[i].rng, (uint64_t)i);
     return h;
 }
 
-void orc_snake_destroy(orc_snake *h) { if (h) { free(h->e); free(h); } }
+void orc_snake_destroy(orc_snake *h) { if (h) { free(h->e); eps_free(&h->eps); free(h); } }
 
 /* env i's private stream := CPython random.seed(seeds[i]) */
 void orc_snake_seed(orc_snake *h, const uint64_t *seeds) {
@@ -120,7 +122,7 @@ void orc_snake_seed(orc_snake *h, const uint64_t *seeds) {
 void orc_snake_reset(orc_snake *h, const uint8_t *mask, int8_t *obs) {
     int cells = h->G * h->G;
     for (int64_t i = 0; i < h->n; ++i) {
-        if (!mask || mask[i]) env_reset(h, &h->e[i]);
+        if (!mask || mask[i]) { env_reset(h, &h->e[i]); eps_clear(&h->eps, i); }
         if (obs) write_obs(h, &h->e[i], obs + i * cells);   /* every row is written, like the device ABI */
     }
 }
@@ -134,7 +136,7 @@ int orc_snake_step(orc_snake *h, const int32_t *actions, int8_t *obs, float *rew
         snake_env *e = &h->e[i];
         int8_t *o = obs + i * cells;
         if (h->mode == 0 && e->needs_reset) {
-            env_reset(h, e);
+            { env_reset(h, e); eps_clear(&h->eps, i); }
             write_obs(h, e, o);
             reward[i] = 0.0f; terminated[i] = 0; truncated[i] = 0;
             continue;
@@ -143,11 +145,12 @@ int orc_snake_step(orc_snake *h, const int32_t *actions, int8_t *obs, float *rew
         if (a < 0 || a > 3) { ++bad; write_obs(h, e, o); reward[i] = 0.0f; terminated[i] = 0; truncated[i] = 0; continue; }
         float r;
         int term = env_step(h, e, a, &r);
+        eps_add(&h->eps, i, (double)r);
         reward[i] = r; terminated[i] = (uint8_t)term; truncated[i] = 0;
-        if (term) e->episodes += 1;
+        if (term) { e->episodes += 1; eps_done(&h->eps, i); }
         if (term && h->mode == 1) {
             if (final_obs) write_obs(h, e, final_obs + i * cells);
-            env_reset(h, e);
+            { env_reset(h, e); eps_clear(&h->eps, i); }
             write_obs(h, e, o);
         } else {
             write_obs(h, e, o);
@@ -168,14 +171,15 @@ void orc_snake_rollout(orc_snake *h, int k_steps, uint64_t a_seed, int64_t t0, i
         float rs = 0.0f;
         int dc = 0;
         for (int t = 0; t < k_steps; ++t) {
-            if (h->mode == 0 && e->needs_reset) { env_reset(h, e); continue; }
+            if (h->mode == 0 && e->needs_reset) { { env_reset(h, e); eps_clear(&h->eps, i); } continue; }
             int a = (int)orc_hash_action(a_seed, (uint64_t)(env0 + i), (uint64_t)(t0 + t), 4, 0);
             float r;
             int term = env_step(h, e, a, &r);
+            eps_add(&h->eps, i, (double)r);
             rs += r;
             if (term) {
-                ++dc; e->episodes += 1;
-                if (h->mode == 1) env_reset(h, e);
+                ++dc; e->episodes += 1; eps_done(&h->eps, i);
+                if (h->mode == 1) { env_reset(h, e); eps_clear(&h->eps, i); }
                 else if (h->mode == 0) e->needs_reset = 1;
             }
         }
@@ -253,3 +257,6 @@ void orc_snake_set_state(orc_snake *h, const void *buf) {
 /* Time-limit override for the short-horizon parity tests (the reference's limit is a constructor constant /
  * config value; the device ABI takes it in its config struct).  Call before reset(). */
 void orc_snake_set_max_steps(orc_snake *h, int v) { h->max_steps = v; }
+
+/* return and length of each env's last finished episode (orc_epstats.h) */
+void orc_snake_episode_stats(const orc_snake *h, double *ret, int32_t *len) { eps_get(&h->eps, h->n, ret, len); }

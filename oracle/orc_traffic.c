@@ -22,6 +22,7 @@
 #include <string.h>
 
 #include "orc_rng.h"
+#include "orc_epstats.h"
 
 #define NI 9
 #define TOBS 130
@@ -41,7 +42,7 @@ typedef struct {
     int64_t n;
     int mode, max_steps, max_vehicles;
     double spawn_rate;
-    traffic_env *e;
+    traffic_env *e; orc_eps eps;
 } orc_traffic;
 
 static void env_reset(traffic_env *e) {                                  /* environment.py:141-166, no draws */
@@ -165,15 +166,16 @@ orc_traffic *orc_traffic_create(int64_t n, int mode) {
     orc_traffic *h = (orc_traffic *)calloc(1, sizeof(*h));
     h->n = n; h->mode = mode; h->max_steps = 1000; h->max_vehicles = 50; h->spawn_rate = 0.3;
     h->e = (traffic_env *)calloc((size_t)n, sizeof(traffic_env));
+    eps_init(&h->eps, n);
     for (int64_t i = 0; i < n; ++i) orc_py_seed(&h->e[i].P, (uint64_t)i);
     return h;
 }
-void orc_traffic_destroy(orc_traffic *h) { if (h) { free(h->e); free(h); } }
+void orc_traffic_destroy(orc_traffic *h) { if (h) { free(h->e); eps_free(&h->eps); free(h); } }
 void orc_traffic_seed(orc_traffic *h, const uint64_t *seeds) { for (int64_t i = 0; i < h->n; ++i) orc_py_seed(&h->e[i].P, seeds[i]); }
 
 void orc_traffic_reset(orc_traffic *h, const uint8_t *mask, float *obs) {
     for (int64_t i = 0; i < h->n; ++i) {
-        if (!mask || mask[i]) env_reset(&h->e[i]);
+        if (!mask || mask[i]) { env_reset(&h->e[i]); eps_clear(&h->eps, i); }
         if (obs) write_obs(&h->e[i], obs + i * TOBS);
     }
 }
@@ -184,19 +186,20 @@ void orc_traffic_step(orc_traffic *h, const int32_t *actions, float *obs, float 
         traffic_env *e = &h->e[i];
         float *o = obs + i * TOBS;
         if (h->mode == 0 && e->needs_reset) {
-            env_reset(e);
+            { env_reset(e); eps_clear(&h->eps, i); }
             write_obs(e, o);
             reward[i] = 0.0f; if (reward64) reward64[i] = 0.0; terminated[i] = 0; truncated[i] = 0;
             continue;
         }
         double r;
         int term = env_step(h, e, actions + i * NI, &r);
+        eps_add(&h->eps, i, (double)r);
         reward[i] = (float)r; if (reward64) reward64[i] = r;
         terminated[i] = (uint8_t)term; truncated[i] = 0;
-        if (term) e->episodes += 1;
+        if (term) { e->episodes += 1; eps_done(&h->eps, i); }
         if (term && h->mode == 1) {
             if (final_obs) write_obs(e, final_obs + i * TOBS);
-            env_reset(e);
+            { env_reset(e); eps_clear(&h->eps, i); }
             write_obs(e, o);
         } else {
             write_obs(e, o);
@@ -213,16 +216,17 @@ void orc_traffic_rollout(orc_traffic *h, int k_steps, uint64_t a_seed, int64_t t
         double rs = 0.0;
         int dc = 0;
         for (int t = 0; t < k_steps; ++t) {
-            if (h->mode == 0 && e->needs_reset) { env_reset(e); continue; }
+            if (h->mode == 0 && e->needs_reset) { { env_reset(e); eps_clear(&h->eps, i); } continue; }
             int32_t a[NI];
             for (int j = 0; j < NI; ++j) a[j] = (int32_t)orc_hash_action(a_seed, (uint64_t)(env0 + i), (uint64_t)(t0 + t), 3, (uint32_t)j);
             double r;
             int term = env_step(h, e, a, &r);
+            eps_add(&h->eps, i, (double)r);
             rs += r;
             if (obs) write_obs(e, scratch);
             if (term) {
-                ++dc; e->episodes += 1;
-                if (h->mode == 1) env_reset(e);
+                ++dc; e->episodes += 1; eps_done(&h->eps, i);
+                if (h->mode == 1) { env_reset(e); eps_clear(&h->eps, i); }
                 else if (h->mode == 0) e->needs_reset = 1;
             }
         }
@@ -292,3 +296,6 @@ void orc_traffic_set_state(orc_traffic *h, const void *buf) {
 /* Time-limit override for the short-horizon parity tests (the reference's limit is a constructor constant /
  * config value; the device ABI takes it in its config struct).  Call before reset(). */
 void orc_traffic_set_max_steps(orc_traffic *h, int v) { h->max_steps = v; }
+
+/* return and length of each env's last finished episode (orc_epstats.h) */
+void orc_traffic_episode_stats(const orc_traffic *h, double *ret, int32_t *len) { eps_get(&h->eps, h->n, ret, len); }
