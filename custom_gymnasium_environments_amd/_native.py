@@ -69,6 +69,7 @@ SIGNATURES = {
     "cge_snake_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cge_snake_rollout": (C.c_int, [_vp, _i32, _vp, _u64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "cge_snake_info": (C.c_int, [_vp, _i32, _vp, _vp]),
+    "cge_snake_render_rgb": (C.c_int, [_vp, _vp, _vp]),
     "cge_snake_state_bytes": (_sz, [_vp]),
     "cge_snake_get_state": (C.c_int, [_vp, _vp, _vp]),
     "cge_snake_set_state": (C.c_int, [_vp, _vp, _vp]),

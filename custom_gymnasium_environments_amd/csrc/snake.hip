@@ -579,6 +579,32 @@ __global__ __launch_bounds__(256) void info_kernel(const uint4 *__restrict__ sta
     out[i] = v;
 }
 
+// _render_rgb_array (snake_env.py:175-188): a 3-colour look-up over the observation — empty black, snake (0,255,0), food (255,0,0) —
+// as uint8 [n, G, G, 3].  One thread per output DWORD (4 of the 3*G*G bytes of an env: coalesced 4-byte stores); the env record
+// it decodes is shared by the 3*G*G/4 threads of that env and comes from cache.  Not a hot path.
+template <int G>
+__global__ __launch_bounds__(256) void render_kernel(const uint4 *__restrict__ state, int64_t n, uint32_t *__restrict__ out) {
+    using L = Lay<G>;
+    constexpr int DW = L::CELLS * 3 / 4;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n * DW) return;
+    const int64_t i = gid / DW;
+    const uint32_t q = (uint32_t)(gid - i * DW);
+    Env<G> e;
+    e.load(state, n, i);
+    const bool fv = e.flags & F_FOOD_VALID;
+    uint32_t w = 0;
+#pragma unroll
+    for (uint32_t b = 0; b < 4; ++b) {
+        const uint32_t byte = 4u * q + b, cell = byte / 3u, ch = byte - 3u * cell;
+        uint32_t v = 0;
+        if (fv && cell == e.food) v = ch == 0u ? 255u : 0u;          // obs == 2 (written last in _get_observation)
+        else if (e.occupied(cell)) v = ch == 1u ? 255u : 0u;         // obs == 1
+        w |= v << (8u * b);
+    }
+    out[gid] = w;
+}
+
 // ------------------------------------------------------------------ host side
 struct Ops {
     int cells, cols, block, nw, max_steps_limit;
@@ -587,6 +613,7 @@ struct Ops {
     void (*rollout)(const Params &, hipStream_t);
     void (*reset)(const Params &, hipStream_t);
     void (*info)(const uint4 *, int64_t, int, int32_t *, hipStream_t);
+    void (*render)(const uint4 *, int64_t, uint32_t *, hipStream_t);
     void (*decode)(const uint32_t *raw, int32_t *hdr, uint16_t *body, uint32_t *mt_pos, uint32_t *mt_pretw);
     void (*encode)(const int32_t *hdr, const uint16_t *body, uint32_t *raw);
 };
@@ -667,6 +694,10 @@ Ops make_ops() {
     };
     o.info = [](const uint4 *st, int64_t n, int field, int32_t *out, hipStream_t s) {
         hipLaunchKernelGGL(info_kernel<G>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st, n, field, out);
+    };
+    o.render = [](const uint4 *st, int64_t n, uint32_t *out, hipStream_t s) {
+        const int64_t total = n * (L::CELLS * 3 / 4);
+        hipLaunchKernelGGL(render_kernel<G>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, st, n, out);
     };
     o.decode = decode_env<G>;
     o.encode = encode_env<G>;
@@ -842,6 +873,15 @@ int cge_snake_info(cge_snake *h, int32_t field_id, int32_t *out, void *stream) {
         return h->fail(CGE_ERR_INVALID_ARG, "cge_snake_info: bad field id / null out");
     DeviceGuard g(h->device);
     h->ops.info(h->state, h->n, field_id, out, as_stream(stream));
+    CGE_TRY(h, hipGetLastError());
+    return CGE_OK;
+}
+
+int cge_snake_render_rgb(cge_snake *h, uint8_t *rgb_out, void *stream) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    if (!rgb_out || (reinterpret_cast<uintptr_t>(rgb_out) & 3u)) return h->fail(CGE_ERR_INVALID_ARG, "cge_snake_render_rgb: null or unaligned rgb_out");
+    DeviceGuard g(h->device);
+    h->ops.render(h->state, h->n, reinterpret_cast<uint32_t *>(rgb_out), as_stream(stream));
     CGE_TRY(h, hipGetLastError());
     return CGE_OK;
 }

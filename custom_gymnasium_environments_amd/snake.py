@@ -30,11 +30,14 @@ class SnakeVectorEnv(DeviceVectorEnv):
     """
 
     _abi = "cge_snake"
-    metadata = {"render_modes": []}
+    metadata = {"render_modes": ["rgb_array"]}
 
     def __init__(self, num_envs, grid_size=20, device="cuda:0", autoreset_mode="NextStep", env_index0=0,
-                 max_steps=1000, reuse_buffers=False, info_fields=(), record_episode_statistics=False):
+                 max_steps=1000, reuse_buffers=False, info_fields=(), record_episode_statistics=False, render_mode=None):
         self._init_common(num_envs, device, autoreset_mode, env_index0, reuse_buffers)
+        if render_mode not in (None, "rgb_array"):
+            raise ValueError("render_mode must be None or 'rgb_array' (the pygame window of 'human' is out of scope)")
+        self.render_mode = render_mode
         self.grid_size = int(grid_size)
         self.max_steps = int(max_steps)
         self.single_action_space = Discrete(4)
@@ -120,6 +123,19 @@ class SnakeVectorEnv(DeviceVectorEnv):
         if per_step:
             return obs, rt, tt, rs, dc
         return obs, rs, dc
+
+    def render_rgb(self):
+        """render_mode="rgb_array" for the whole batch (snake_env.py:175-188): uint8 [N, G, G, 3] of the current states —
+        empty black, snake (0, 255, 0), food (255, 0, 0)."""
+        out = self._out("rgb", self._obs_shape + (3,), torch.uint8)
+        self._check(self._lib.cge_snake_render_rgb(self._h, out.data_ptr(), self._stream()), "render_rgb")
+        return out
+
+    def render(self):
+        """gymnasium.vector.VectorEnv.render(): a tuple with one frame per env when render_mode == "rgb_array"."""
+        if self.render_mode != "rgb_array":
+            return None
+        return tuple(self.render_rgb())
 
     def info(self, field):
         out = torch.empty(self.num_envs, dtype=torch.int32, device=self.device)

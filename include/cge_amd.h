@@ -123,6 +123,9 @@ int cge_snake_rollout(cge_snake *h, int32_t k_steps, const int32_t *actions, uin
                       uint8_t *terminated_traj_out, float *reward_sum_out, int32_t *done_count_out,
                       void *stream);
 int cge_snake_info(cge_snake *h, int32_t field_id, int32_t *out, void *stream);
+/* render_mode="rgb_array" (snake_env.py:175-188): uint8 [n_envs, G, G, 3] (4-byte aligned) — empty (0,0,0), snake (0,255,0),
+ * food (255,0,0) — of the CURRENT state of every env.  The pygame window of render_mode="human" (:153-173) is out of scope. */
+int cge_snake_render_rgb(cge_snake *h, uint8_t *rgb_out, void *stream);
 /* canonical per-env state record (host memory), identical to the oracle's: 8 int32 {len, dir, food_r,
  * food_c, score, steps, needs_reset, mt_idx}, uint32 mt[624] (CPython layout: words >= mt_idx are
  * generated-but-unconsumed), uint16 body[G*G] head first (0xFFFF unused), padded to 4 bytes. */

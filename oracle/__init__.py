@@ -85,6 +85,7 @@ def _declare(L):
     L.orc_snake_state_bytes.argtypes = [vp]; L.orc_snake_state_bytes.restype = C.c_size_t
     L.orc_snake_get_state.argtypes = [vp, vp]
     L.orc_snake_set_state.argtypes = [vp, vp]
+    L.orc_snake_render_rgb.argtypes = [vp, vp]
 
     L.orc_crypto_create.argtypes = [i64, i32, i32]; L.orc_crypto_create.restype = vp
     L.orc_crypto_destroy.argtypes = [vp]
@@ -275,6 +276,11 @@ class SnakeOracle(_EpisodeStats):
     def info(self, field):
         out = np.zeros(self.n, np.int32)
         lib().orc_snake_info(self.h, field, _p(out))
+        return out
+
+    def render_rgb(self):
+        out = np.zeros((self.n, self.grid, self.grid, 3), np.uint8)
+        lib().orc_snake_render_rgb(self.h, _p(out))
         return out
 
     def get_state(self):

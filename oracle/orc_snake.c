@@ -258,5 +258,16 @@ void orc_snake_set_state(orc_snake *h, const void *buf) {
  * config value; the device ABI takes it in its config struct).  Call before reset(). */
 void orc_snake_set_max_steps(orc_snake *h, int v) { h->max_steps = v; }
 
+/* _render_rgb_array (snake_env.py:175-188): rgb[obs == 0] = (0,0,0), rgb[obs == 1] = (0,255,0), rgb[obs == 2] = (255,0,0) */
+void orc_snake_render_rgb(const orc_snake *h, uint8_t *rgb) {
+    int cells = h->G * h->G;
+    int8_t obs[SNAKE_MAX_G * SNAKE_MAX_G];
+    for (int64_t i = 0; i < h->n; ++i) {
+        write_obs(h, &h->e[i], obs);
+        uint8_t *o = rgb + i * cells * 3;
+        for (int c = 0; c < cells; ++c) { o[3 * c] = obs[c] == 2 ? 255 : 0; o[3 * c + 1] = obs[c] == 1 ? 255 : 0; o[3 * c + 2] = 0; }
+    }
+}
+
 /* return and length of each env's last finished episode (orc_epstats.h) */
 void orc_snake_episode_stats(const orc_snake *h, double *ret, int32_t *len) { eps_get(&h->eps, h->n, ret, len); }

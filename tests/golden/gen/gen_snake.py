@@ -6,7 +6,7 @@ Protocols:
     auto-reset = `env.reset()` (no seed) right after a terminal step, stream continues.
   * KAT-S1 (config 1): random.seed(0); reset(seed=0); 10,000 actions from
     np.random.default_rng(123).integers(0,4,10000); reset() after each done.
-Outputs: tests/golden/snake_g10_hash.npz, snake_g10_greedy.npz, snake_g20_greedy.npz, snake_g10_short.npz, snake_kat.json
+Outputs: tests/golden/snake_g10_hash.npz, snake_g10_greedy.npz, snake_g20_greedy.npz, snake_g10_short.npz, snake_rgb.npz, snake_kat.json
 """
 import json
 import os
@@ -130,8 +130,31 @@ def kat_s1():
     print("KAT-S1", kat)
 
 
+def rgb_fixture():
+    """render_mode="rgb_array": env.render() (snake_env.py:175-188) after the reset and after each of 120 greedy steps of 6 envs."""
+    obs_l, rgb_l = [], []
+    for i in range(6):
+        random.seed(9000 + i)
+        env = SnakeEnvClassic(render_mode="rgb_array", grid_size=10)
+        obs, _ = env.reset()
+        rng = np.random.default_rng([13, i])
+        obs_l.append(obs.copy()); rgb_l.append(env.render().copy())
+        for t in range(120):
+            hr, hc = env.snake[0]
+            fr, fc = env.food
+            cand = [a for a, ok in ((0, fr < hr), (1, fc > hc), (2, fr > hr), (3, fc < hc)) if ok] or [int(rng.integers(0, 4))]
+            obs, _, te, tr, _ = env.step(int(cand[rng.integers(0, len(cand))]))
+            if te or tr:
+                obs, _ = env.reset()
+            obs_l.append(obs.copy()); rgb_l.append(env.render().copy())
+    out = os.path.join(common.GOLDEN, "snake_rgb.npz")
+    np.savez_compressed(out, obs=np.array(obs_l, np.int8), rgb=np.array(rgb_l, np.uint8), versions=np.array(json.dumps(common.versions())))
+    print("snake_rgb", len(obs_l), "frames", os.path.getsize(out), "bytes")
+
+
 if __name__ == "__main__":
     kat_s1()
+    rgb_fixture()
     make("snake_g10_hash", 10, 64, 1000, "hash", seed0=0, a_seed=123)
     make("snake_g10_greedy", 10, 32, 1500, "greedy", seed0=1000, a_seed=7, eps=0.05)
     make("snake_g20_greedy", 20, 8, 1500, "greedy", seed0=5000, a_seed=9, eps=0.03)

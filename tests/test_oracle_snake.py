@@ -137,3 +137,20 @@ def test_state_roundtrip_and_rollout(oracle):
         if t >= 137:
             rs += rew
     assert np.array_equal(obs, oa) and np.array_equal(rs, ra)
+
+
+LUT = np.array([[0, 0, 0], [0, 255, 0], [255, 0, 0]], np.uint8)       # snake_env.py:181-186: empty, snake, food
+
+
+def test_render_rgb_is_the_reference_lut(oracle):
+    """snake_rgb.npz holds env.render() frames of the reference in render_mode="rgb_array" next to the observations they were
+    rendered from: the frame is the 3-colour look-up of the observation, and the oracle's render does exactly that."""
+    fx = golden("snake_rgb.npz")
+    assert np.array_equal(LUT[fx["obs"]], fx["rgb"]) and fx["rgb"].shape[1:] == (10, 10, 3)
+    assert set(np.unique(fx["obs"])) == {0, 1, 2}
+    o = oracle.SnakeOracle(50, 10, oracle.SAME_STEP)
+    o.seed(np.arange(50, dtype=np.uint64) + np.uint64(9))
+    obs = o.reset()
+    assert np.array_equal(o.render_rgb(), LUT[obs])
+    obs, _, _ = o.rollout(77, 4)
+    assert np.array_equal(o.render_rgb(), LUT[obs])

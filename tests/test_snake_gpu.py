@@ -260,3 +260,43 @@ def test_rollout_trajectory_equals_stepping_the_oracle(cge, oracle, mode, grid, 
     _, rs2, dc2 = env.rollout(K, actions=torch.from_numpy(acts).cuda(), want_obs=False)
     assert np.array_equal(_np(rs2), _np(rs)) and np.array_equal(_np(dc2), _np(dc))
     env.close()
+
+
+def test_render_rgb_matches_reference_lut_and_oracle(cge, oracle):
+    """rgb_array rendering (snake_env.py:175-188) for the whole batch: the device frames equal the reference's look-up table
+    (pinned by tests/golden/snake_rgb.npz, see test_oracle_snake.py) applied to the device observation, and the oracle's frames."""
+    lut = np.array([[0, 0, 0], [0, 255, 0], [255, 0, 0]], np.uint8)
+    fx = golden("snake_rgb.npz")
+    assert np.array_equal(lut[fx["obs"]], fx["rgb"])
+    for grid, n in [(10, 1000), (6, 70), (20, 129)]:
+        env = cge.SnakeVectorEnv(n, grid_size=grid, autoreset_mode="SameStep", render_mode="rgb_array", env_index0=3)
+        o = oracle.SnakeOracle(n, grid, oracle.SAME_STEP)
+        o.seed(np.arange(n, dtype=np.uint64) + np.uint64(3 + 5))
+        obs, _ = env.reset(seed=5); o.reset()
+        assert np.array_equal(_np(env.render_rgb()), lut[_np(obs)])
+        obs, _, _ = env.rollout(150, action_seed=8); o.rollout(150, 8, env0=3)
+        rgb = _np(env.render_rgb())
+        assert rgb.shape == (n, grid, grid, 3) and rgb.dtype == np.uint8
+        assert np.array_equal(rgb, lut[_np(obs)]) and np.array_equal(rgb, o.render_rgb())
+        frames = env.render()
+        assert len(frames) == n and tuple(frames[0].shape) == (grid, grid, 3)
+        env.close()
+    assert cge.SnakeVectorEnv(4, grid_size=10).render() is None
+    with pytest.raises(ValueError):
+        cge.SnakeVectorEnv(4, grid_size=10, render_mode="human")
+
+
+def test_set_state_rejects_malformed_records(cge, oracle):
+    """cge_snake_set_state validates every header field it packs into the bit-fields of the device record (a food cell or step
+    count out of range would spill into neighbouring fields or index outside the env's LDS row)."""
+    n = 8
+    env = cge.SnakeVectorEnv(n, grid_size=10)
+    env.reset(seed=1)
+    good = env.get_state()
+    env.set_state(good)                                               # round trip is accepted
+    for field, value in [(2, 10), (3, -2), (2, 99), (4, 101), (4, -1), (5, 70000), (5, -3), (6, 2), (0, 0), (1, 4), (7, 625)]:
+        bad = good.copy()
+        bad[3].view(np.int32)[field] = value
+        with pytest.raises(cge.NativeLibraryError):
+            env.set_state(bad)
+    env.close()
