@@ -403,7 +403,7 @@ __device__ __forceinline__ void coop_flush(LdsBulkDraws<W> &d, int row_stride) {
 // Runtime-indexed register arrays go to scratch on hipcc; these helpers keep every index static
 // (fully unrolled select chains) so the env state stays in VGPRs.
 template <int W>
-__device__ __forceinline__ uint32_t sel(const uint32_t (&a)[W], uint32_t idx) {
+__host__ __device__ __forceinline__ uint32_t sel(const uint32_t (&a)[W], uint32_t idx) {
     // mask form on purpose: a ternary chain gets folded by LLVM into "select the ADDRESS, then load",
     // which pins the array in scratch memory
     uint32_t r = 0;
@@ -412,12 +412,12 @@ __device__ __forceinline__ uint32_t sel(const uint32_t (&a)[W], uint32_t idx) {
     return r;
 }
 template <int W>
-__device__ __forceinline__ void or_word(uint32_t (&a)[W], uint32_t idx, uint32_t m) {
+__host__ __device__ __forceinline__ void or_word(uint32_t (&a)[W], uint32_t idx, uint32_t m) {
 #pragma unroll
     for (int k = 0; k < W; ++k) a[k] |= (idx == (uint32_t)k) ? m : 0u;
 }
 template <int W>
-__device__ __forceinline__ void andnot_word(uint32_t (&a)[W], uint32_t idx, uint32_t m) {
+__host__ __device__ __forceinline__ void andnot_word(uint32_t (&a)[W], uint32_t idx, uint32_t m) {
 #pragma unroll
     for (int k = 0; k < W; ++k) a[k] &= (idx == (uint32_t)k) ? ~m : 0xffffffffu;
 }

@@ -4,14 +4,14 @@
 // _place_food :121-129, _get_observation :131-143 for N independent instances, one lane per env.
 //
 // Device representation (per env, all integer, bit-exact with the reference's Python objects):
-//   occ   CELLS bits       occupancy of the body            (`new_head in self.snake`, obs value 1)
-//   dirs  2 bits per cell  direction the head LEFT that cell (replaces the Python list's order:
-//                          the tail advances by following its own cell's direction, O(1), no ring
-//                          buffer traffic; list.insert(0,..)/pop() become two bit updates)
-//   head, tail, food, dir, steps, score, flags, episodes, and the env's MT19937 cursor (pos, pretw)
-// stored struct-of-arrays as COLS columns of uint4 (column c of env i at state[c*N+i]) so a
-// wavefront's loads/stores are 16 B per lane, fully coalesced.  For the benchmark grid (G=10) the
-// scalars are packed into the spare bits of the occ/dirs words: 48 B per env (3 columns).
+//   sr    2 bits per move  the snake's move history, newest first (replaces the Python list's order: walking from the head
+//                          against it visits the body head to tail; list.insert(0,..)/pop() become a shift and a truncate)
+//   occ   CELLS bits       occupancy of the body (`new_head in self.snake`, obs value 1)
+//   head, tail, len, food, dir, steps, score, flags, episodes, and the env's MT19937 cursor (pos, pretw)
+// stored struct-of-arrays as columns of uint4 (column c of env i at state[c*N+i]) so a wavefront's loads/stores are 16 B per
+// lane, fully coalesced.  For the benchmark grid (G=10) the HOT column holds every scalar plus the 28 newest moves — 16 B per
+// env is all a step() reads and writes for snakes up to 29 cells — older moves live in two cold columns, and the occupancy
+// bits are not stored: they are rebuilt in registers by the head-to-tail walk when the record is loaded.
 // The whole record lives in VGPRs during a step (static-index mask/select chains, cge_device.hpp).
 // Food placement (the only RNG use) fetches a window of the env's MT19937 block in ONE round trip,
 // issued before the observation is staged so its latency hides behind that work.
@@ -41,95 +41,161 @@ template <int G>
 struct Lay {
     static constexpr int CELLS = G * G;
     static constexpr int OCCW = (CELLS + 31) / 32;
-    static constexpr int DIRW = (CELLS + 15) / 16;
-    // G=10: occ uses 100 of 128 bits, dirs 200 of 224 -> scalars live in the spare bits, 12 words total
+    static constexpr int SRW = (2 * (CELLS - 1) + 31) / 32;   // move history: 2 bits per body segment behind the head
+    // G=10 (the benchmark grid): a 16-byte HOT record holds every scalar and the 28 most recent moves; older moves spill into two
+    // cold columns that only snakes longer than 29 / 93 cells ever touch.  Occupancy is not stored at all there (see Env).
     static constexpr bool TIGHT = (G == 10);
-    static constexpr int NW = TIGHT ? 12 : OCCW + DIRW + 4;
+    static constexpr int HOT_DIRS = 28, COLD0_DIRS = 64;
+    static constexpr int NW = TIGHT ? 12 : OCCW + SRW + 4;
     static constexpr int COLS = (NW + 3) / 4;
     static constexpr int OBS_DW = CELLS / 4;
     static constexpr int KBITS = bitlen(G);  // CPython: k = n.bit_length() for _randbelow(G)
     static constexpr int BLOCK = (CELLS <= 144) ? 256 : 64;
     static constexpr int MAX_STEPS_LIMIT = TIGHT ? 4095 : 65535;
+    static constexpr uint32_t MAX_EPISODES = TIGHT ? 0xFFFFu : 0xFFFFFFFFu;   // the counter saturates
     static_assert(CELLS % 4 == 0, "obs rows are staged as dwords: G must be even");
     static_assert(CELLS <= 1023, "cell index is packed in 10 bits");
+    static_assert(!TIGHT || (SRW == 7 && OCCW == 4), "hot / cold split below is written for 10x10");
 };
 
+__host__ __device__ __forceinline__ int dir_delta(uint32_t d, int g) { return d == 0 ? -g : d == 1 ? 1 : d == 2 ? g : -1; }
+
+// Body representation: `sr` is the snake's move history, most recent move in bits 1:0 — move k (k = 0 newest) is the direction in
+// which the head entered the cell it occupied k moves ago, so walking from the head AGAINST sr[0], sr[1], ... visits the body
+// head to tail (the Python list's order).  list.insert(0, new_head) = shift left by 2 and OR the direction in; list.pop() =
+// drop entry len-1 and advance `tail` along it.  O(1) per step, no per-env byte-granular memory traffic.
+// `occ` (occupancy bits: `new_head in self.snake`, obs value 1) lives in registers only for G=10: it is rebuilt at load time by
+// that walk (len-1 iterations: 0-3 under random play), which is what lets the stored record shrink from 48 to 16 bytes.
 template <int G>
 struct Env {
     using L = Lay<G>;
     uint32_t occ[L::OCCW];
-    uint32_t dirs[L::DIRW];
-    uint32_t head, tail, food, dir, steps, score, flags, episodes, mt_pos, mt_pretw;
+    uint32_t sr[L::SRW];
+    uint32_t head, tail, len, food, dir, steps, score, flags, episodes, mt_pos, mt_pretw;
 
     __device__ __forceinline__ void load(const uint4 *__restrict__ state, int64_t n, int64_t i) {
         uint32_t raw[L::COLS * 4];
+        if constexpr (L::TIGHT) {
+            const uint4 h = state[i];
+            raw[0] = h.x; raw[1] = h.y; raw[2] = h.z; raw[3] = h.w;
+            const uint32_t moves = ((h.x >> 7) & 127u) - 1u;
+            uint4 c0 = make_uint4(0, 0, 0, 0), c1 = make_uint4(0, 0, 0, 0);
+            if (moves > (uint32_t)L::HOT_DIRS) c0 = state[n + i];                              // rare: long snakes only
+            if (moves > (uint32_t)(L::HOT_DIRS + L::COLD0_DIRS)) c1 = state[2 * n + i];
+            raw[4] = c0.x; raw[5] = c0.y; raw[6] = c0.z; raw[7] = c0.w;
+            raw[8] = c1.x; raw[9] = c1.y; raw[10] = c1.z; raw[11] = c1.w;
+        } else {
 #pragma unroll
-        for (int c = 0; c < L::COLS; ++c) {
-            uint4 v = state[(int64_t)c * n + i];
-            raw[4 * c] = v.x; raw[4 * c + 1] = v.y; raw[4 * c + 2] = v.z; raw[4 * c + 3] = v.w;
+            for (int c = 0; c < L::COLS; ++c) {
+                uint4 v = state[(int64_t)c * n + i];
+                raw[4 * c] = v.x; raw[4 * c + 1] = v.y; raw[4 * c + 2] = v.z; raw[4 * c + 3] = v.w;
+            }
         }
         unpack(raw);
     }
     __device__ __forceinline__ void store(uint4 *__restrict__ state, int64_t n, int64_t i) const {
         uint32_t raw[L::COLS * 4];
         pack(raw);
-#pragma unroll
-        for (int c = 0; c < L::COLS; ++c)
-            state[(int64_t)c * n + i] = make_uint4(raw[4 * c], raw[4 * c + 1], raw[4 * c + 2], raw[4 * c + 3]);
-    }
-    __host__ __device__ __forceinline__ void unpack(const uint32_t *raw) {
-#pragma unroll
-        for (int k = 0; k < L::OCCW; ++k) occ[k] = raw[k];
-#pragma unroll
-        for (int k = 0; k < L::DIRW; ++k) dirs[k] = raw[L::OCCW + k];
         if constexpr (L::TIGHT) {
-            // word 3: occ bits 96..99 | steps:12 @4 | score:7 @16 | flags:3 @23
-            // word 10: dirs of cells 96..99 (8 bits) | head:7 @8 | tail:7 @15 | food:7 @22 | dir:2 @29
-            // word 11: mt_pos:10 | mt_pretw!=0 @10 | episodes:21 @11
-            const uint32_t m1 = raw[3], m0 = raw[10], m2 = raw[11];
-            occ[3] = m1 & 0xFu;
-            steps = (m1 >> 4) & 0xFFFu; score = (m1 >> 16) & 0x7Fu; flags = (m1 >> 23) & 7u;
-            dirs[6] = m0 & 0xFFu;
-            head = (m0 >> 8) & 0x7Fu; tail = (m0 >> 15) & 0x7Fu; food = (m0 >> 22) & 0x7Fu; dir = (m0 >> 29) & 3u;
-            mt_pos = m2 & 1023u; mt_pretw = (m2 & 1024u) ? (uint32_t)MT_N : 0u; episodes = m2 >> 11;
+            state[i] = make_uint4(raw[0], raw[1], raw[2], raw[3]);
+            if (len - 1u > (uint32_t)L::HOT_DIRS) state[n + i] = make_uint4(raw[4], raw[5], raw[6], raw[7]);
+            if (len - 1u > (uint32_t)(L::HOT_DIRS + L::COLD0_DIRS)) state[2 * n + i] = make_uint4(raw[8], raw[9], raw[10], raw[11]);
         } else {
-            const uint32_t m0 = raw[L::OCCW + L::DIRW], m1 = raw[L::OCCW + L::DIRW + 1], m3 = raw[L::OCCW + L::DIRW + 3];
+#pragma unroll
+            for (int c = 0; c < L::COLS; ++c)
+                state[(int64_t)c * n + i] = make_uint4(raw[4 * c], raw[4 * c + 1], raw[4 * c + 2], raw[4 * c + 3]);
+        }
+    }
+    // G=10 hot record  w0: head:7 | len:7 @7 | food:7 @14 | dir:2 @21 | flags:3 @23 | score[5:0] @26
+    //                  w1: steps:12 | mt_pos:10 @12 | mt_pretw!=0 @22 | score[6] @23 | episodes[7:0] @24
+    //                  w2: episodes[15:8] | sr bits 0..23 @8      w3: sr bits 24..55
+    //       cold words 4..11: sr bits 56..  (read / written only when len-1 > 28, words 8.. only when len-1 > 92)
+    __host__ __device__ __forceinline__ void unpack(const uint32_t *raw) {
+        if constexpr (L::TIGHT) {
+            const uint32_t w0 = raw[0], w1 = raw[1], w2 = raw[2];
+            head = w0 & 127u; len = (w0 >> 7) & 127u; food = (w0 >> 14) & 127u; dir = (w0 >> 21) & 3u; flags = (w0 >> 23) & 7u;
+            score = (w0 >> 26) | (((w1 >> 23) & 1u) << 6);
+            steps = w1 & 0xFFFu; mt_pos = (w1 >> 12) & 1023u; mt_pretw = (w1 & (1u << 22)) ? (uint32_t)MT_N : 0u;
+            episodes = (w1 >> 24) | ((w2 & 0xFFu) << 8);
+            sr[0] = (w2 >> 8) | (raw[3] << 24);
+#pragma unroll
+            for (int k = 1; k < L::SRW; ++k) sr[k] = (raw[2 + k] >> 8) | (raw[3 + k] << 24);
+            mask_history();
+            rebuild_occupancy();
+        } else {
+#pragma unroll
+            for (int k = 0; k < L::OCCW; ++k) occ[k] = raw[k];
+#pragma unroll
+            for (int k = 0; k < L::SRW; ++k) sr[k] = raw[L::OCCW + k];
+            const uint32_t m0 = raw[L::OCCW + L::SRW], m1 = raw[L::OCCW + L::SRW + 1], m3 = raw[L::OCCW + L::SRW + 3];
             head = m0 & 1023u; tail = (m0 >> 10) & 1023u; food = (m0 >> 20) & 1023u; dir = m0 >> 30;
             steps = m1 & 0xffffu; score = (m1 >> 16) & 1023u; flags = m1 >> 26;
-            episodes = raw[L::OCCW + L::DIRW + 2];
-            mt_pos = m3 & 1023u; mt_pretw = (m3 & 1024u) ? (uint32_t)MT_N : 0u;
+            episodes = raw[L::OCCW + L::SRW + 2];
+            mt_pos = m3 & 1023u; mt_pretw = (m3 & 1024u) ? (uint32_t)MT_N : 0u; len = m3 >> 11;
         }
     }
     __host__ __device__ __forceinline__ void pack(uint32_t *raw) const {
-#pragma unroll
-        for (int k = 0; k < L::OCCW; ++k) raw[k] = occ[k];
-#pragma unroll
-        for (int k = 0; k < L::DIRW; ++k) raw[L::OCCW + k] = dirs[k];
         if constexpr (L::TIGHT) {
-            raw[3] = (occ[3] & 0xFu) | (steps << 4) | (score << 16) | (flags << 23);
-            raw[10] = (dirs[6] & 0xFFu) | (head << 8) | (tail << 15) | (food << 22) | (dir << 29);
-            raw[11] = mt_pos | (mt_pretw ? 1024u : 0u) | (episodes << 11);
+            const uint32_t ep = episodes < L::MAX_EPISODES ? episodes : L::MAX_EPISODES;
+            raw[0] = head | (len << 7) | (food << 14) | (dir << 21) | (flags << 23) | ((score & 63u) << 26);
+            raw[1] = steps | (mt_pos << 12) | (mt_pretw ? (1u << 22) : 0u) | (((score >> 6) & 1u) << 23) | ((ep & 0xFFu) << 24);
+            raw[2] = (ep >> 8) | (sr[0] << 8);
+#pragma unroll
+            for (int k = 1; k < L::SRW; ++k) raw[2 + k] = (sr[k - 1] >> 24) | (sr[k] << 8);
+            raw[2 + L::SRW] = sr[L::SRW - 1] >> 24;
+#pragma unroll
+            for (int k = 3 + L::SRW; k < 12; ++k) raw[k] = 0;
         } else {
-            raw[L::OCCW + L::DIRW] = head | (tail << 10) | (food << 20) | (dir << 30);
-            raw[L::OCCW + L::DIRW + 1] = steps | (score << 16) | (flags << 26);
-            raw[L::OCCW + L::DIRW + 2] = episodes;
-            raw[L::OCCW + L::DIRW + 3] = mt_pos | (mt_pretw ? 1024u : 0u);
+#pragma unroll
+            for (int k = 0; k < L::OCCW; ++k) raw[k] = occ[k];
+#pragma unroll
+            for (int k = 0; k < L::SRW; ++k) raw[L::OCCW + k] = sr[k];
+            raw[L::OCCW + L::SRW] = head | (tail << 10) | (food << 20) | (dir << 30);
+            raw[L::OCCW + L::SRW + 1] = steps | (score << 16) | (flags << 26);
+            raw[L::OCCW + L::SRW + 2] = episodes;
+            raw[L::OCCW + L::SRW + 3] = mt_pos | (mt_pretw ? 1024u : 0u) | (len << 11);
 #pragma unroll
             for (int k = L::NW; k < L::COLS * 4; ++k) raw[k] = 0;
         }
     }
-
-    __device__ __forceinline__ uint32_t occupied(uint32_t cell) const { return (sel(occ, cell >> 5) >> (cell & 31u)) & 1u; }
-    __host__ __device__ __forceinline__ uint32_t length() const {
-        uint32_t c = 0;
+    // entries at and beyond len-1 are not part of the body: keep them zero (canonical records; stale cold columns are ignored)
+    __host__ __device__ __forceinline__ void mask_history() {
+        const uint32_t bits = 2u * (len - 1u);
 #pragma unroll
-        for (int k = 0; k < L::OCCW; ++k) c += (uint32_t)__builtin_popcount(occ[k]);
-        return c;
+        for (int k = 0; k < L::SRW; ++k) {
+            const uint32_t lo = 32u * k;
+            sr[k] = bits >= lo + 32u ? sr[k] : (bits > lo ? (sr[k] & ((1u << (bits - lo)) - 1u)) : 0u);
+        }
     }
+    // head -> tail walk against the move history: occupancy bits and the tail cell.  The first 32 moves come out of a 64-bit
+    // shift register (all that random play ever needs); longer bodies continue with indexed extraction.
+    __host__ __device__ __forceinline__ void rebuild_occupancy() {
+#pragma unroll
+        for (int k = 0; k < L::OCCW; ++k) occ[k] = 0;
+        uint32_t cell = head;
+        or_word(occ, cell >> 5, 1u << (cell & 31u));
+        const uint32_t moves = len - 1u;
+        uint64_t q = (uint64_t)sr[0] | ((uint64_t)sr[1] << 32);
+        const uint32_t n1 = moves < 32u ? moves : 32u;
+        for (uint32_t k = 0; k < n1; ++k) {
+            cell = (uint32_t)((int)cell - dir_delta((uint32_t)q & 3u, G));
+            q >>= 2;
+            or_word(occ, cell >> 5, 1u << (cell & 31u));
+        }
+        for (uint32_t k = 32u; k < moves; ++k) {
+            const uint32_t d = (sel(sr, k >> 4) >> ((k & 15u) * 2u)) & 3u;
+            cell = (uint32_t)((int)cell - dir_delta(d, G));
+            or_word(occ, cell >> 5, 1u << (cell & 31u));
+        }
+        tail = cell;
+    }
+
+    __host__ __device__ __forceinline__ uint32_t occupied(uint32_t cell) const { return (sel(occ, cell >> 5) >> (cell & 31u)) & 1u; }
+    __host__ __device__ __forceinline__ uint32_t length() const { return len; }
 
     // snake_env.py:123 would spin forever on a full board: reported via info (sticky), never silent
     __device__ __forceinline__ bool can_place_food() {
-        if (length() >= (uint32_t)L::CELLS) {
+        if (len >= (uint32_t)L::CELLS) {
             flags = (flags | F_BOARD_FULL) & ~F_FOOD_VALID;
             return false;
         }
@@ -170,26 +236,15 @@ struct Env {
         flags |= F_FOOD_VALID;
     }
 
-    // _place_food() one draw at a time on the lane's own stream: for paths too rare to earn a window (an env that eats on the
-    // very step its time limit fires, in SameStep mode, needs the post-eat food AND the reset food in one step)
-    __device__ __forceinline__ void place_food_serial(uint32_t *__restrict__ blk) {
-        MtStream s(blk, mt_pos, mt_pretw);
-        for (;;) {
-            const uint32_t r = s.randbelow((uint32_t)G, L::KBITS), c = s.randbelow((uint32_t)G, L::KBITS);
-            if (!occupied(r * G + c)) { food = r * G + c; break; }
-        }
-        mt_pos = s.pos; mt_pretw = s.pretw;
-        flags |= F_FOOD_VALID;
-    }
-
     // snake_env.py:49-65 without the trailing _place_food()
     __device__ __forceinline__ void reset_body() {
 #pragma unroll
         for (int k = 0; k < L::OCCW; ++k) occ[k] = 0;
 #pragma unroll
-        for (int k = 0; k < L::DIRW; ++k) dirs[k] = 0;
+        for (int k = 0; k < L::SRW; ++k) sr[k] = 0;
         constexpr uint32_t center = (G / 2) * G + (G / 2);
         head = tail = center;
+        len = 1;
         occ[center >> 5] |= 1u << (center & 31u);
         dir = 1;
         score = 0;
@@ -211,23 +266,24 @@ struct Env {
             reward = -10.0f;
             return true;
         }
-        {   // :97 insert(0, new_head): remember which way the head left its old cell
-            const uint32_t w = head >> 4, sh = (head & 15u) * 2u;
-            andnot_word(dirs, w, 3u << sh);
-            or_word(dirs, w, dir << sh);
-        }
+        // :97 insert(0, new_head): the move joins the history at position 0
+#pragma unroll
+        for (int k = L::SRW - 1; k > 0; --k) sr[k] = (sr[k] << 2) | (sr[k - 1] >> 30);
+        sr[0] = (sr[0] << 2) | dir;
         or_word(occ, ncell >> 5, 1u << (ncell & 31u));
         head = ncell;
         reward = 0.0f;
         if ((flags & F_FOOD_VALID) && ncell == food) {                            // :101-104
             score += 1;
+            len += 1;
             reward = 10.0f;
             ate = true;
-        } else {                                                                  // :107 pop()
-            const uint32_t td = (sel(dirs, tail >> 4) >> ((tail & 15u) * 2u)) & 3u;
+        } else {                                                                  // :107 pop(): the oldest move (entry len-1) leaves
+            const uint32_t p = 2u * (len - 1u);
+            const uint32_t td = (sel(sr, p >> 5) >> (p & 31u)) & 3u;
+            andnot_word(sr, p >> 5, 3u << (p & 31u));
             andnot_word(occ, tail >> 5, 1u << (tail & 31u));
-            const int delta = td == 0 ? -G : td == 1 ? 1 : td == 2 ? G : -1;
-            tail = (uint32_t)((int)tail + delta);
+            tail = (uint32_t)((int)tail + dir_delta(td, G));
         }
         steps += 1;                                                               // :109
         return steps >= max_steps;                                                // :113-114
@@ -343,13 +399,24 @@ __device__ __forceinline__ void wave_place_food(Env<G> &e, uint32_t *blk, bool n
     if (need) e.flags |= F_FOOD_VALID;
 }
 
+enum : uint32_t { T_NEED_FOOD = 1u, T_WAS_RESET = 2u, T_DEFERRED = 4u };
+
+// SameStep: the terminal observation of a lane whose episode just ended (rare lanes only: direct row store)
+template <int G>
+__device__ __forceinline__ void write_final_obs(const Env<G> &e, const Params &p, int64_t i) {
+    if (!p.final_obs) return;
+    uint32_t *frow = reinterpret_cast<uint32_t *>(p.final_obs + i * Lay<G>::CELLS);
+    e.write_obs_body(frow);
+    e.write_obs_food(frow);
+}
+
 // One env transition with fused auto-reset.  Everything except the food draw happens first; the RNG
 // window load is issued, the obs body is staged while it is in flight, then the food is placed.
 template <int G, int FW = FOOD_WINDOW>
 __device__ __forceinline__ uint32_t transition(Env<G> &e, const Params &p, int64_t i, uint32_t action, bool valid_action,
                                                uint32_t *__restrict__ obs_row, float &reward, bool &term) {
     using L = Lay<G>;
-    bool need_food = false, was_reset = false;
+    bool need_food = false, was_reset = false, deferred = false;
     reward = 0.0f;
     term = false;
     if (p.mode == CGE_AUTORESET_NEXT_STEP && (e.flags & F_NEEDS_RESET)) {
@@ -367,16 +434,17 @@ __device__ __forceinline__ uint32_t transition(Env<G> &e, const Params &p, int64
             if (p.ep_ret) p.ep_ret[i] = 10.0 * (double)e.score - (crashed ? 10.0 : 0.0);
             if (p.ep_len) p.ep_len[i] = (int32_t)e.steps + (crashed ? 1 : 0);
             if (p.mode == CGE_AUTORESET_SAME_STEP) {
-                // time limit on a step that also ate: the reference places the new food (snake_env.py:104) BEFORE it tests
-                // steps >= max_steps (:113), so the terminal obs shows it and the reset below draws a second one
-                if (need_food && e.can_place_food()) e.place_food_serial(p.mt + i * MT_STRIDE);
-                if (p.final_obs) {   // terminal observation, rare lanes only: direct row store
-                    uint32_t *frow = reinterpret_cast<uint32_t *>(p.final_obs + i * L::CELLS);
-                    e.write_obs_body(frow);
-                    e.write_obs_food(frow);
+                if (need_food) {
+                    // time limit on a step that also ate: the reference places the new food (snake_env.py:104) BEFORE it tests
+                    // steps >= max_steps (:113), so the terminal obs shows it and the reset draws a second one.  Both draws go
+                    // through the caller's wave-cooperative placement: this round places the post-eat food, finish_deferred()
+                    // then writes the terminal obs, resets, and the caller runs a second round.
+                    deferred = true;
+                } else {
+                    write_final_obs(e, p, i);
+                    e.reset_body();
+                    need_food = true; was_reset = true;
                 }
-                e.reset_body();
-                need_food = true; was_reset = true;
             } else if (p.mode == CGE_AUTORESET_NEXT_STEP) {
                 e.flags |= F_NEEDS_RESET;
             }
@@ -384,7 +452,18 @@ __device__ __forceinline__ uint32_t transition(Env<G> &e, const Params &p, int64
     }
     if (need_food) need_food = e.can_place_food();
     if (obs_row) e.write_obs_body(obs_row);
-    return (need_food ? 1u : 0u) | (was_reset ? 2u : 0u);      // the caller runs wave_place_food with the whole wave, then write_obs_food
+    // the caller runs wave_place_food with the whole wave, then (T_DEFERRED, rare) finish_deferred + a second round, then write_obs_food
+    return (need_food ? T_NEED_FOOD : 0u) | (was_reset ? T_WAS_RESET : 0u) | (deferred ? T_DEFERRED : 0u);
+}
+
+// second half of a SameStep episode end whose last step also ate (see transition): terminal obs with the post-eat food, reset.
+// Returns whether the fresh episode needs its food placed (always, unless the board were full).
+template <int G>
+__device__ __forceinline__ bool finish_deferred(Env<G> &e, const Params &p, int64_t i, uint32_t *__restrict__ obs_row) {
+    write_final_obs(e, p, i);
+    e.reset_body();
+    if (obs_row) e.write_obs_body(obs_row);
+    return e.can_place_food();
 }
 
 template <int G, int BLOCK, int MINW, int FW>
@@ -399,13 +478,18 @@ __global__ __launch_bounds__(BLOCK, MINW) void step_kernel(Params p) {
     Env<G> e;
     e.load(p.state, p.n, li);
     float r = 0.0f;
-    bool term = false, need_food = false;
+    bool term = false;
+    uint32_t tf = 0;
     uint32_t *row = tile + threadIdx.x * L::OBS_DW;
     if (live_lane) {
         const int32_t a = p.actions[i];
-        need_food = transition<G, FW>(e, p, i, (uint32_t)a, (uint32_t)a <= 3u, row, r, term) & 1u;
+        tf = transition<G, FW>(e, p, i, (uint32_t)a, (uint32_t)a <= 3u, row, r, term);
     }
-    wave_place_food<G>(e, p.mt + li * MT_STRIDE, need_food);
+    wave_place_food<G>(e, p.mt + li * MT_STRIDE, tf & T_NEED_FOOD);
+    if (__ballot(tf & T_DEFERRED)) {                           // rare, wave-uniform
+        const bool again = (tf & T_DEFERRED) && finish_deferred<G>(e, p, i, row);
+        wave_place_food<G>(e, p.mt + li * MT_STRIDE, again);
+    }
     if (live_lane) {
         e.write_obs_food(row);
         e.store(p.state, p.n, i);
@@ -467,6 +551,7 @@ __global__ __launch_bounds__(BLOCK + WRITERS, MINW) void rollout_kernel(Params p
     for (int t = 0; t < p.k_steps; ++t) {
         float r = 0.0f;
         bool term = false, need_food = false, was_reset = false;
+        uint32_t tf = 0;
         const uint32_t old_head = e.head, old_tail = e.tail;
         if (live_lane) {
             uint32_t a;
@@ -476,10 +561,15 @@ __global__ __launch_bounds__(BLOCK + WRITERS, MINW) void rollout_kernel(Params p
             } else {
                 a = hash_action_from_key(key, (uint64_t)(p.t0 + t), 4u, 0u);
             }
-            const uint32_t f = transition<G, FW>(e, p, i, a, a <= 3u, nullptr, r, term);
-            need_food = f & 1u; was_reset = f & 2u;
+            tf = transition<G, FW>(e, p, i, a, a <= 3u, nullptr, r, term);
+            need_food = tf & T_NEED_FOOD; was_reset = tf & T_WAS_RESET;
         }
         wave_place_food<G>(e, blk, need_food);
+        if (__ballot(tf & T_DEFERRED)) {                       // rare, wave-uniform: ate on the step the time limit fired (SameStep)
+            const bool again = (tf & T_DEFERRED) && finish_deferred<G>(e, p, i, nullptr);
+            wave_place_food<G>(e, blk, again);
+            if (tf & T_DEFERRED) { was_reset = true; need_food = again; }
+        }
         if (row) {
             if (t > 0) lds_barrier();                          // B2(t-1): the writer has read obs(t-1)
             unsigned long long rm = __ballot(was_reset);
@@ -615,7 +705,7 @@ struct Ops {
     void (*info)(const uint4 *, int64_t, int, int32_t *, hipStream_t);
     void (*render)(const uint4 *, int64_t, uint32_t *, hipStream_t);
     void (*decode)(const uint32_t *raw, int32_t *hdr, uint16_t *body, uint32_t *mt_pos, uint32_t *mt_pretw);
-    void (*encode)(const int32_t *hdr, const uint16_t *body, uint32_t *raw);
+    bool (*encode)(const int32_t *hdr, const uint16_t *body, uint32_t *raw);
 };
 
 template <int G>
@@ -630,43 +720,49 @@ void decode_env(const uint32_t *raw, int32_t *hdr, uint16_t *body, uint32_t *mt_
     hdr[0] = len; hdr[1] = (int32_t)e.dir;
     hdr[2] = fv ? (int32_t)(e.food / G) : -1; hdr[3] = fv ? (int32_t)(e.food % G) : -1;
     hdr[4] = (int32_t)e.score; hdr[5] = (int32_t)e.steps; hdr[6] = (e.flags & F_NEEDS_RESET) ? 1 : 0;
-    // walk tail -> head along the stored directions, emit head first
-    std::vector<uint16_t> order;
-    uint32_t c = e.tail;
-    for (int k = 0; k < len; ++k) {
-        order.push_back((uint16_t)c);
-        if (c == e.head) break;
-        const uint32_t td = (e.dirs[c >> 4] >> ((c & 15u) * 2u)) & 3u;
-        c = (uint32_t)((int)c + (td == 0 ? -G : td == 1 ? 1 : td == 2 ? G : -1));
+    // walk head -> tail against the move history (the Python list's order)
+    uint32_t c = e.head;
+    for (int k = 0; k < L::CELLS; ++k) {
+        body[k] = k < len ? (uint16_t)c : 0xFFFF;
+        if (k + 1 < len) c = (uint32_t)((int)c - dir_delta((e.sr[k >> 4] >> ((k & 15) * 2)) & 3u, G));
     }
-    for (int k = 0; k < L::CELLS; ++k) body[k] = k < (int)order.size() ? order[order.size() - 1 - k] : 0xFFFF;
 }
 
+// false: the body is not a path of unit moves inside the board (no such list can arise from the reference's step())
 template <int G>
-void encode_env(const int32_t *hdr, const uint16_t *body, uint32_t *raw) {
-    using L = Lay<G>;
+bool encode_env(const int32_t *hdr, const uint16_t *body, uint32_t *raw) {
     Env<G> e;
     memset(&e, 0, sizeof e);
     const int len = hdr[0];
-    for (int k = 0; k < len; ++k) e.occ[body[k] >> 5] |= 1u << (body[k] & 31u);
-    for (int k = len - 1; k >= 1; --k) {   // body[k] is older than body[k-1]
-        const int from = body[k], to = body[k - 1];
-        const uint32_t d = to == from - G ? 0u : to == from + 1 ? 1u : to == from + G ? 2u : 3u;
-        e.dirs[from >> 4] |= d << ((from & 15) * 2);
+    for (int k = 0; k < len; ++k) {
+        if (e.occ[body[k] >> 5] & (1u << (body[k] & 31u))) return false;               // a cell twice
+        e.occ[body[k] >> 5] |= 1u << (body[k] & 31u);
+    }
+    for (int k = 0; k + 1 < len; ++k) {   // move k took the snake from body[k+1] to body[k]
+        const int from = body[k + 1], to = body[k];
+        uint32_t d;
+        if (to == from - G) d = 0u;
+        else if (to == from + 1 && from % G != G - 1) d = 1u;
+        else if (to == from + G) d = 2u;
+        else if (to == from - 1 && from % G != 0) d = 3u;
+        else return false;
+        e.sr[k >> 4] |= d << ((k & 15) * 2);
     }
     e.head = body[0];
     e.tail = body[len - 1];
+    e.len = (uint32_t)len;
     e.dir = (uint32_t)hdr[1];
     const bool fv = hdr[2] >= 0;
     e.food = fv ? (uint32_t)(hdr[2] * G + hdr[3]) : 0u;
     e.score = (uint32_t)hdr[4];
     e.steps = (uint32_t)hdr[5];
     e.flags = (hdr[6] ? F_NEEDS_RESET : 0u) | (fv ? F_FOOD_VALID : 0u);
-    e.episodes = 0;
+    e.episodes = 0;                        // not part of the canonical record: a restored env starts counting again
     // canonical CPython cursor -> incremental cursor
     if (hdr[7] >= MT_N) { e.mt_pos = 0; e.mt_pretw = 0; }
     else { e.mt_pos = (uint32_t)hdr[7]; e.mt_pretw = MT_N; }
     e.pack(raw);
+    return true;
 }
 
 template <int G, int BLOCK, int MINW, int FW>
@@ -957,7 +1053,7 @@ int cge_snake_set_state(cge_snake *h, const void *host_buf, void *stream) {
             return h->fail(CGE_ERR_INVALID_ARG, "cge_snake_set_state: food / score / steps / needs_reset out of range");
         for (int k = 0; k < hdr[0]; ++k)
             if (body[k] >= cells) return h->fail(CGE_ERR_INVALID_ARG, "cge_snake_set_state: body cell out of range");
-        h->ops.encode(hdr, body, raw.data());
+        if (!h->ops.encode(hdr, body, raw.data())) return h->fail(CGE_ERR_INVALID_ARG, "cge_snake_set_state: the body is not a path of unit moves");
         for (int c = 0; c < cols; ++c) st[(size_t)c * n + i] = make_uint4(raw[4 * c], raw[4 * c + 1], raw[4 * c + 2], raw[4 * c + 3]);
         uint32_t *w = &mt[(size_t)i * MT_STRIDE];
         memcpy(w, p + 32, MT_N * 4);

@@ -118,10 +118,12 @@ def test_rollout_matches_oracle_and_step_path(cge, oracle):
     env.close(); twin.close()
 
 
-def test_state_injection_long_snakes_and_full_board(cge, oracle):
+@pytest.mark.parametrize("grid,shrink", [(6, 1), (10, 12), (10, 1), (12, 9)])
+def test_state_injection_long_snakes_and_full_board(cge, oracle, grid, shrink):
     """Rare branches: food placement among long bodies (heavy rejection), tail-cell collision rule,
-    and the board-full guard (reference would spin forever, snake_env.py:123)."""
-    grid, n = 6, 64
+    and the board-full guard (reference would spin forever, snake_env.py:123).  On the 10x10 grid the lengths 100, 88, ..., 16
+    also cover every storage class of the device record: hot column only (<= 29 cells), one cold column, both (>= 94)."""
+    n = 64
     o = oracle.SnakeOracle(n, grid, oracle.DISABLED)
     o.seed(np.arange(n, dtype=np.uint64))
     o.reset()
@@ -129,13 +131,13 @@ def test_state_injection_long_snakes_and_full_board(cge, oracle):
     rec = st.shape[1]
     hdr = st[:, :32].view(np.int32)
     body = st[:, 32 + 624 * 4: 32 + 624 * 4 + grid * grid * 2].view(np.uint16)
-    # boustrophedon path covering the whole 6x6 board; env i gets a snake of length 36 - (i % 8)
+    # boustrophedon path covering the whole board; env i gets a snake of length G*G - (i % 8) * shrink
     path = []
     for r in range(grid):
         cols = range(grid) if r % 2 == 0 else range(grid - 1, -1, -1)
         path += [r * grid + c for c in cols]
     for i in range(n):
-        L = grid * grid - (i % 8)
+        L = grid * grid - (i % 8) * shrink
         cells = path[:L][::-1]                      # head = last cell of the prefix
         body[i, :] = 0xFFFF
         body[i, :L] = cells
@@ -162,6 +164,28 @@ def test_state_injection_long_snakes_and_full_board(cge, oracle):
         assert np.array_equal(_np(rd), ro) and np.array_equal(_np(ted), teo.astype(bool))
     assert np.array_equal(_np(env.info("board_full")), o.info(6))
     assert np.array_equal(_np(env.info("snake_length")), o.info(1))
+    back, ref = env.get_state(), o.get_state()                        # bodies after 60 steps, head first
+    assert np.array_equal(back[:, 32 + 624 * 4:], ref[:, 32 + 624 * 4:]) and np.array_equal(back[:, :28], ref[:, :28])
+    # the fused kernel loads / stores the same records
+    obs, rs, dc = env.rollout(40, action_seed=3)
+    oo, ro, do = o.rollout(40, 3)
+    assert np.array_equal(_np(obs), oo) and np.array_equal(_np(rs), ro) and np.array_equal(_np(dc), do)
+    assert np.array_equal(env.get_state()[:, 32 + 624 * 4:], o.get_state()[:, 32 + 624 * 4:])
+    env.close()
+
+
+def test_set_state_rejects_bodies_that_are_not_paths(cge):
+    env = cge.SnakeVectorEnv(4, grid_size=10)
+    env.reset(seed=1)
+    good = env.get_state()
+    for cells in ([55, 57], [55, 55], [59, 60], [50, 49, 48, 38, 39, 49]):          # gap, repeat, row wrap, self-crossing
+        bad = good.copy()
+        bad[1, :32].view(np.int32)[0] = len(cells)
+        body = bad[1, 32 + 624 * 4:32 + 624 * 4 + 200].view(np.uint16)
+        body[:] = 0xFFFF
+        body[:len(cells)] = cells
+        with pytest.raises(cge.NativeLibraryError):
+            env.set_state(bad)
     env.close()
 
 
