@@ -160,7 +160,7 @@ struct Env {
     }
     // entries at and beyond len-1 are not part of the body: keep them zero (canonical records; stale cold columns are ignored)
     __host__ __device__ __forceinline__ void mask_history() {
-        const uint32_t bits = 2u * (len - 1u);
+        const uint32_t bits = len == 0u ? 0u : 2u * (len - 1u);
 #pragma unroll
         for (int k = 0; k < L::SRW; ++k) {
             const uint32_t lo = 32u * k;
@@ -174,7 +174,8 @@ struct Env {
         for (int k = 0; k < L::OCCW; ++k) occ[k] = 0;
         uint32_t cell = head;
         or_word(occ, cell >> 5, 1u << (cell & 31u));
-        const uint32_t moves = len - 1u;
+        // len is 0 in never-initialised (zeroed) records and arbitrary in a corrupted one: bound the walk, whatever the bits say
+        const uint32_t moves = len == 0u ? 0u : (len <= (uint32_t)L::CELLS ? len - 1u : (uint32_t)L::CELLS - 1u);
         uint64_t q = (uint64_t)sr[0] | ((uint64_t)sr[1] << 32);
         const uint32_t n1 = moves < 32u ? moves : 32u;
         for (uint32_t k = 0; k < n1; ++k) {
