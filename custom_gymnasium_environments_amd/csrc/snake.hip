@@ -191,7 +191,14 @@ struct Env {
         tail = cell;
     }
 
-    __host__ __device__ __forceinline__ uint32_t occupied(uint32_t cell) const { return (sel(occ, cell >> 5) >> (cell & 31u)) & 1u; }
+    __host__ __device__ __forceinline__ uint32_t occupied(uint32_t cell) const {
+        if constexpr (L::OCCW == 4) {                          // two 64-bit halves: 2 selects + one 64-bit shift instead of a 4-way select chain
+            const uint64_t lo = (uint64_t)occ[0] | ((uint64_t)occ[1] << 32), hi = (uint64_t)occ[2] | ((uint64_t)occ[3] << 32);
+            return (uint32_t)(((cell < 64u ? lo : hi) >> (cell & 63u)) & 1ull);
+        } else {
+            return (sel(occ, cell >> 5) >> (cell & 31u)) & 1u;
+        }
+    }
     __host__ __device__ __forceinline__ uint32_t length() const { return len; }
 
     // snake_env.py:123 would spin forever on a full board: reported via info (sticky), never silent
@@ -321,6 +328,7 @@ struct Params {
     double *ep_ret;       // episode statistics (cge_snake_episode_stats), nullable
     int32_t *ep_len;
     unsigned long long *err_count;
+    int32_t debug;        // measurement switches (CGE_SNAKE_DEBUG, never set by the product): 1 = rollout skips food placement, 2 = its writer skips the stores
 };
 
 __device__ __forceinline__ uint32_t shfl_u32(uint32_t v, uint32_t src) { return (uint32_t)__shfl((int)v, (int)src, 64); }
@@ -398,6 +406,141 @@ __device__ __forceinline__ void wave_place_food(Env<G> &e, uint32_t *blk, bool n
         pending = __ballot(pending_me);
     }
     if (need) e.flags |= F_FOOD_VALID;
+}
+
+// ------------------------------------------------------------------ per-launch digit queue (fused rollout)
+// _place_food only ever looks at the top KBITS bits of a generator word (`getrandbits(k)`), and a 200-step launch consumes ~50
+// words per env.  The fused rollout therefore draws them up front: when a launch starts, every wave twists the next QN words
+// of each of its 64 envs cooperatively (64 lanes load 64 CONSECUTIVE state words of one env: coalesced, unlike a lane walking
+// its own 2560-byte block), tempers them and parks just the digits in LDS — 48 bytes per env for 10x10.  Inside the step loop a
+// placement is then pure VALU + LDS.  Why it matters: in the K-step loop the only global LOADS were these generator words, and on
+// gfx950 they queued behind the CU's backlog of observation STORES (loads and stores share the vector memory pipe): 22 us per
+// 1M-env step without any placement, 38 us with the per-step window loads (profiles/README.md, round 2).  The words a launch
+// consumed are committed (twisted in place, cursor advanced) once, after the last step; a wave whose queue runs low mid-launch
+// commits and refills — wave-convergent, rare (mean consumption 0.25 words per env-step).
+template <int G>
+struct QLay {
+    static constexpr int DB = Lay<G>::KBITS <= 4 ? 4 : 8;     // stored bits per digit
+    static constexpr int PER = 32 / DB;                        // digits per dword = digits examined per placement round
+    static constexpr int QN = 96;                              // digits per fill (< 227: no window word depends on another)
+    static constexpr int QDW = QN / PER;
+    static constexpr int QROW = (QDW + 1) | 1;                 // odd dword stride, one pad word behind the last digit
+    static constexpr int MIN_STEPS = 24;                       // shorter launches keep the per-step window loads
+};
+
+template <int G>
+__device__ __forceinline__ void queue_fill(const Env<G> &e, const uint32_t *blk, uint32_t *wave_q, uint32_t &qcur, uint32_t &qlen) {
+    using L = Lay<G>;
+    using Q = QLay<G>;
+    constexpr int NQ = (Q::QN + 63) / 64, RG = 2;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t plo = (uint32_t)reinterpret_cast<uintptr_t>(blk), phi = (uint32_t)(reinterpret_cast<uintptr_t>(blk) >> 32);
+#pragma unroll 1
+    for (int r0 = 0; r0 < 64; r0 += RG) {
+        uint32_t a[RG][NQ], b[RG][NQ], c[RG][NQ];
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {                         // all loads of RG envs first: one round trip, not RG * NQ
+            const uint32_t *ob = lane_ptr(plo, phi, r0 + g);
+            const uint32_t pos = lane_u32(e.mt_pos, r0 + g) & 1023u;           // 10-bit field; a valid cursor is < 624, so k stays inside the 640-word block
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                uint32_t k = pos + 64u * q + lane;              // < 624 + 128: one wrap
+                k -= k >= (uint32_t)MT_N ? MT_N : 0;
+                const uint32_t k1 = k + 1 == (uint32_t)MT_N ? 0 : k + 1;
+                const uint32_t km = k + MT_M >= (uint32_t)MT_N ? k + MT_M - MT_N : k + MT_M;
+                a[g][q] = ob[k]; b[g][q] = ob[k1]; c[g][q] = ob[km];
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+            const uint32_t pos = lane_u32(e.mt_pos, r0 + g), pretw = lane_u32(e.mt_pretw, r0 + g);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const uint32_t j = 64u * q + lane;
+                const uint32_t y = pos + j < pretw ? a[g][q] : mt_twist(a[g][q], b[g][q], c[g][q]);
+                uint32_t x = (mt_temper(y) >> (32 - L::KBITS)) << (Q::DB * (j % Q::PER));
+                x |= shfl_u32(x, lane ^ 1u);                    // OR over each aligned group of PER lanes -> one dword of digits
+                x |= shfl_u32(x, lane ^ 2u);
+                if (Q::PER == 8) x |= shfl_u32(x, lane ^ 4u);
+                if (j % Q::PER == 0 && j < (uint32_t)Q::QN) wave_q[(r0 + g) * Q::QROW + j / Q::PER] = x;
+            }
+        }
+    }
+    qcur = 0;
+    qlen = Q::QN;
+}
+
+// twist-in-place the words each env consumed since its fill and advance the cursors
+template <int G>
+__device__ __forceinline__ void queue_commit(Env<G> &e, uint32_t *blk, uint32_t &qcur, uint32_t &qlen) {
+    using Q = QLay<G>;
+    constexpr int NQ = (Q::QN + 63) / 64;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t plo = (uint32_t)reinterpret_cast<uintptr_t>(blk), phi = (uint32_t)(reinterpret_cast<uintptr_t>(blk) >> 32);
+#pragma unroll 1
+    for (int r = 0; r < 64; ++r) {
+        const uint32_t used = lane_u32(qcur, r);
+        if (used == 0) continue;                               // wave-uniform
+        uint32_t *ob = lane_ptr(plo, phi, r);
+        const uint32_t pos = lane_u32(e.mt_pos, r) & 1023u, pretw = lane_u32(e.mt_pretw, r);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (64u * q >= used) break;                        // wave-uniform
+            const uint32_t j = 64u * q + lane;
+            uint32_t k = pos + j;
+            k -= k >= (uint32_t)MT_N ? MT_N : 0;
+            const uint32_t k1 = k + 1 == (uint32_t)MT_N ? 0 : k + 1;
+            const uint32_t km = k + MT_M >= (uint32_t)MT_N ? k + MT_M - MT_N : k + MT_M;
+            const uint32_t y = mt_twist(ob[k], ob[k1], ob[km]);   // every load of the round precedes its stores (program order)
+            if (j < used && pos + j >= pretw) ob[k] = y;
+        }
+    }
+    uint32_t np = e.mt_pos + qcur;
+    if (np >= (uint32_t)MT_N) { np -= MT_N; e.mt_pretw = 0; }
+    e.mt_pos = np;
+    qcur = 0;
+    qlen = 0;
+}
+
+// _place_food (snake_env.py:121-129) out of the lane's digit queue; must be called by all 64 lanes of the wave
+template <int G>
+__device__ __forceinline__ void queue_place_food(Env<G> &e, uint32_t *blk, uint32_t *wave_q, uint32_t &qcur, uint32_t &qlen, bool need) {
+    using Q = QLay<G>;
+    const uint32_t *myq = wave_q + (threadIdx.x & 63u) * Q::QROW;
+    bool pending = need;
+    uint32_t phase = 0, row = 0;
+#pragma unroll 1
+    while (__ballot(pending)) {
+        if (__ballot(pending && qcur + (uint32_t)Q::PER > qlen)) {   // some lane could run dry in this round: commit and refill (rare)
+            queue_commit<G>(e, blk, qcur, qlen);
+            queue_fill<G>(e, blk, wave_q, qcur, qlen);
+        }
+        const uint32_t idx = qcur / Q::PER < (uint32_t)Q::QDW ? qcur / Q::PER : (uint32_t)Q::QDW - 1u, off = (qcur % Q::PER) * Q::DB;   // (idle lanes may sit at the end)
+        const uint32_t bits = (uint32_t)((((uint64_t)myq[idx + 1] << 32) | (uint64_t)myq[idx]) >> off);
+        uint32_t used = 0;
+        bool done = !pending;
+#pragma unroll
+        for (int j = 0; j < Q::PER; ++j) {
+            if (!done) {
+                const uint32_t r = (bits >> (Q::DB * j)) & ((1u << Q::DB) - 1u);
+                used = j + 1;
+                if (r < (uint32_t)G) {
+                    if (phase == 0) {
+                        row = r;
+                        phase = 1;
+                    } else {
+                        phase = 0;
+                        const uint32_t cell = row * G + r;
+                        if (!e.occupied(cell)) { e.food = cell; done = true; }
+                    }
+                }
+            }
+        }
+        if (pending) {
+            qcur += used;
+            if (done) { pending = false; e.flags |= F_FOOD_VALID; }
+        }
+    }
 }
 
 enum : uint32_t { T_NEED_FOOD = 1u, T_WAS_RESET = 2u, T_DEFERRED = 4u };
@@ -513,7 +656,9 @@ __global__ __launch_bounds__(BLOCK, MINW) void step_kernel(Params p) {
 template <int G, int BLOCK, int MINW, int FW>
 __global__ __launch_bounds__(BLOCK + WRITERS, MINW) void rollout_kernel(Params p) {
     using L = Lay<G>;
+    using Q = QLay<G>;
     __shared__ uint4 tile4[BLOCK * L::OBS_DW / 4];
+    __shared__ uint32_t qmem[BLOCK * Q::QROW];
     uint32_t *tile = reinterpret_cast<uint32_t *>(tile4);
     const int64_t first = (int64_t)blockIdx.x * BLOCK;
     const int64_t live = p.n - first < BLOCK ? p.n - first : BLOCK;
@@ -522,7 +667,7 @@ __global__ __launch_bounds__(BLOCK + WRITERS, MINW) void rollout_kernel(Params p
         const uint32_t w = threadIdx.x - BLOCK;
         for (int t = 0; t < p.k_steps; ++t) {
             lds_barrier();                                     // B1(t)
-            store_tile<WRITERS, BLOCK * L::CELLS>(tile, p.obs + (int64_t)t * p.obs_step_stride + first * L::CELLS, (uint32_t)(live * L::CELLS), w);
+            if (!(p.debug & 2)) store_tile<WRITERS, BLOCK * L::CELLS>(tile, p.obs + (int64_t)t * p.obs_step_stride + first * L::CELLS, (uint32_t)(live * L::CELLS), w);
             lds_barrier();                                     // B2(t): LDS reads done (lgkmcnt), the stores drain on their own
         }
         return;
@@ -533,10 +678,8 @@ __global__ __launch_bounds__(BLOCK + WRITERS, MINW) void rollout_kernel(Params p
     uint64_t key = 0;
     float rsum = 0.0f;
     int32_t dcount = 0;
-    if (live_lane) {
-        e.load(p.state, p.n, i);
-        key = hash_env_key(p.a_seed, (uint64_t)(p.env0 + i));
-    }
+    e.load(p.state, p.n, live_lane ? i : first);               // dead lanes of the last workgroup mirror a valid env: the
+    if (live_lane) key = hash_env_key(p.a_seed, (uint64_t)(p.env0 + i));   // cooperative queue code reads every lane's cursor
     // The lane's obs row lives in LDS for the whole rollout and is kept up to date INCREMENTALLY: a move sets the new head
     // byte and clears the vacated tail byte, a new food sets one byte; only an episode reset rewrites the row, and that is
     // done by the wave together (25 lanes clear the row of each resetting env) — rebuilding 25 dwords per lane per step
@@ -549,6 +692,16 @@ __global__ __launch_bounds__(BLOCK + WRITERS, MINW) void rollout_kernel(Params p
     // explicit actions are fetched one step ahead so the load's latency hides behind the previous step
     uint32_t a_next = (live_lane && p.actions && p.k_steps > 0) ? (uint32_t)p.actions[i] : 0u;
     uint32_t *blk = p.mt + (live_lane ? i : first) * MT_STRIDE;
+    // generator words for the whole launch, drawn before the first observation store is in flight (see QLay)
+    const bool use_q = p.k_steps >= Q::MIN_STEPS;
+    uint32_t *wave_q = qmem + (threadIdx.x & ~63u) * Q::QROW;
+    uint32_t qcur = 0, qlen = 0;
+    if (use_q) queue_fill<G>(e, blk, wave_q, qcur, qlen);
+    auto place = [&](bool need) {
+        if (p.debug & 1) return;
+        if (use_q) queue_place_food<G>(e, blk, wave_q, qcur, qlen, need);
+        else wave_place_food<G>(e, blk, need);
+    };
     for (int t = 0; t < p.k_steps; ++t) {
         float r = 0.0f;
         bool term = false, need_food = false, was_reset = false;
@@ -565,10 +718,10 @@ __global__ __launch_bounds__(BLOCK + WRITERS, MINW) void rollout_kernel(Params p
             tf = transition<G, FW>(e, p, i, a, a <= 3u, nullptr, r, term);
             need_food = tf & T_NEED_FOOD; was_reset = tf & T_WAS_RESET;
         }
-        wave_place_food<G>(e, blk, need_food);
+        place(need_food);
         if (__ballot(tf & T_DEFERRED)) {                       // rare, wave-uniform: ate on the step the time limit fired (SameStep)
             const bool again = (tf & T_DEFERRED) && finish_deferred<G>(e, p, i, nullptr);
-            wave_place_food<G>(e, blk, again);
+            place(again);
             if (tf & T_DEFERRED) { was_reset = true; need_food = again; }
         }
         if (row) {
@@ -595,6 +748,7 @@ __global__ __launch_bounds__(BLOCK + WRITERS, MINW) void rollout_kernel(Params p
         }
     }
     if (row && p.k_steps > 0) lds_barrier();                   // B2(k-1), pairs with the writer's last barrier
+    if (use_q) queue_commit<G>(e, blk, qcur, qlen);
     if (live_lane) {
         e.store(p.state, p.n, i);
         if (p.reward_sum) p.reward_sum[i] = rsum;
@@ -810,12 +964,10 @@ static bool ops_for(int grid, Ops &o) {
             // tuning variants of the benchmark grid, selectable for A/B runs (default = best measured)
             const char *v = getenv("CGE_SNAKE_VARIANT");
             const int k = v ? atoi(v) : 0;
-            if (k == 1) set_variant<10, 256, 6, 8>(o);
+            if (k == 1) set_variant<10, 256, 5, 8>(o);
             else if (k == 2) set_variant<10, 128, 1, 8>(o);
-            else if (k == 3) set_variant<10, 64, 1, 8>(o);
-            else if (k == 4) set_variant<10, 256, 6, 6>(o);
-            else if (k == 5) set_variant<10, 128, 6, 6>(o);
-            else if (k == 6) set_variant<10, 64, 6, 6>(o);
+            else if (k == 3) set_variant<10, 128, 5, 8>(o);
+            else if (k == 4) set_variant<10, 64, 5, 8>(o);
             return true;
         }
         case 12: o = make_ops<12>(); return true;
@@ -841,6 +993,7 @@ struct cge_snake : HandleBase {
         snake::Params p{};
         p.state = state; p.mt = mt; p.n = n; p.env0 = env0;
         p.mode = cfg.autoreset_mode; p.max_steps = cfg.max_steps; p.err_count = err;
+        { const char *d = getenv("CGE_SNAKE_DEBUG"); p.debug = d ? atoi(d) : 0; }
         p.ep_ret = ep_ret; p.ep_len = ep_len;
         return p;
     }
