@@ -34,7 +34,6 @@ constexpr int bitlen(int n) {
 }
 
 enum : uint32_t { F_NEEDS_RESET = 1u, F_BOARD_FULL = 2u, F_FOOD_VALID = 4u };
-constexpr int WRITERS = 64;       // lanes of the rollout kernel's obs writer (see rollout_kernel)
 constexpr int FOOD_WINDOW = 8;   // default MT words fetched per round trip by _place_food (mean use: 3.2 for G=10)
 
 template <int G>
@@ -328,7 +327,7 @@ struct Params {
     double *ep_ret;       // episode statistics (cge_snake_episode_stats), nullable
     int32_t *ep_len;
     unsigned long long *err_count;
-    int32_t debug;        // measurement switches (CGE_SNAKE_DEBUG, never set by the product): 1 = rollout skips food placement, 2 = its writer skips the stores
+    int32_t debug;        // measurement switches (CGE_SNAKE_DEBUG, never set by the product): 1 = rollout skips food placement, 2 = skips the obs stores, 4 = trivial actions instead of the hash, 8 = skips the row updates
 };
 
 __device__ __forceinline__ uint32_t shfl_u32(uint32_t v, uint32_t src) { return (uint32_t)__shfl((int)v, (int)src, 64); }
@@ -646,40 +645,52 @@ __global__ __launch_bounds__(BLOCK, MINW) void step_kernel(Params p) {
     store_tile<BLOCK, BLOCK * L::CELLS>(tile, p.obs + first * L::CELLS, (uint32_t)(live * L::CELLS));
 }
 
-// k fused steps per launch: state stays in VGPRs, only obs (+ optional explicit actions) touch HBM per step.
-// The workgroup is BLOCK compute lanes plus one 64-lane WRITER wave that does nothing but stream the obs tile to HBM.
-// On gfx950 loads and stores share one in-order counter (vmcnt): when the compute waves issued the obs stores
-// themselves, their next food-placement loads had to wait for those stores to retire, so output and compute never
-// overlapped (12 us of compute + 13 us of stores per 1M-env step).  With the stores on their own wave the compute waves
-// only wait for their own loads; two LDS-only barriers per step hand the tile back and forth:
-//   B1(t) rows hold obs(t) -> writer reads them | compute does transition(t+1) in registers | B2(t) rows may change.
+// One wave streams its own 64 obs rows (FULL contiguous bytes) from LDS to HBM: (ds_read_b128, global_store_dwordx4) pairs at
+// constant offsets, two pairs in flight at a time — the fully unrolled copy kept 28 VGPRs of tile data live across the step and
+// cost a wave per SIMD of occupancy.  Partial last wave / unaligned destination: the generic store_tile paths.
+template <int FULL>
+__device__ __forceinline__ void store_wave_rows(const uint32_t *rows, int8_t *dst, uint32_t bytes_valid, uint32_t lane) {
+    if (bytes_valid == (uint32_t)FULL && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+        constexpr int NVEC = FULL / 16, ITERS = NVEC / 64, TAIL = NVEC % 64;
+        static_assert(FULL % 16 == 0, "whole tiles are a multiple of 16 bytes");
+        const uint4 *t4 = reinterpret_cast<const uint4 *>(rows) + lane;
+        uint4 *d4 = reinterpret_cast<uint4 *>(dst) + lane;
+#pragma unroll 2
+        for (int it = 0; it < ITERS; ++it) d4[it * 64] = t4[it * 64];
+        if (TAIL && lane < (uint32_t)TAIL) d4[ITERS * 64] = t4[ITERS * 64];
+        return;
+    }
+    store_tile<64, 0>(rows, dst, bytes_valid, lane);
+}
+
+// k fused steps per launch: state stays in VGPRs, only the obs rows (+ optional per-step reward / flag / explicit actions) touch
+// HBM per step.  Every WAVE is on its own here — no workgroup barrier anywhere in the kernel: a wave keeps the 64 observation
+// rows of its envs in LDS (updated incrementally), streams them out itself after each step (6400 contiguous bytes for 10x10:
+// six full 1-KiB store instructions and a 256-byte tail) and goes straight on to the next transition while the stores drain.
+// History: round 1 gave the stores to a dedicated writer wave behind two LDS-only barriers per step, because on gfx950 loads
+// and stores retire through one in-order counter and a compute wave's next food-placement LOADS had to wait for its own obs
+// STORES.  The per-launch digit queue (QLay) removed every global load from the step loop, and with it the reason for the
+// writer: measured on 1M envs with every step's obs written to a [K, N, 100] trajectory, writer-wave kernel 28.5-38 us per
+// step (74 % of wave time parked at the barriers), this kernel see DESIGN.md section 6.
 template <int G, int BLOCK, int MINW, int FW>
-__global__ __launch_bounds__(BLOCK + WRITERS, MINW) void rollout_kernel(Params p) {
+__global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
     using L = Lay<G>;
     using Q = QLay<G>;
     __shared__ uint4 tile4[BLOCK * L::OBS_DW / 4];
     __shared__ uint32_t qmem[BLOCK * Q::QROW];
     uint32_t *tile = reinterpret_cast<uint32_t *>(tile4);
     const int64_t first = (int64_t)blockIdx.x * BLOCK;
-    const int64_t live = p.n - first < BLOCK ? p.n - first : BLOCK;
-    if (threadIdx.x >= (unsigned)BLOCK) {                      // ---- writer wave
-        if (!p.obs) return;
-        const uint32_t w = threadIdx.x - BLOCK;
-        for (int t = 0; t < p.k_steps; ++t) {
-            lds_barrier();                                     // B1(t)
-            if (!(p.debug & 2)) store_tile<WRITERS, BLOCK * L::CELLS>(tile, p.obs + (int64_t)t * p.obs_step_stride + first * L::CELLS, (uint32_t)(live * L::CELLS), w);
-            lds_barrier();                                     // B2(t): LDS reads done (lgkmcnt), the stores drain on their own
-        }
-        return;
-    }
+    const int64_t wfirst = first + (threadIdx.x & ~63u);       // first env of this wave
+    if (wfirst >= p.n) return;                                 // a wholly dead wave of the last workgroup (no barriers to miss)
+    const int64_t wlive = p.n - wfirst < 64 ? p.n - wfirst : 64;
     const int64_t i = first + threadIdx.x;
     const bool live_lane = i < p.n;
     Env<G> e;
     uint64_t key = 0;
     float rsum = 0.0f;
     int32_t dcount = 0;
-    e.load(p.state, p.n, live_lane ? i : first);               // dead lanes of the last workgroup mirror a valid env: the
-    if (live_lane) key = hash_env_key(p.a_seed, (uint64_t)(p.env0 + i));   // cooperative queue code reads every lane's cursor
+    e.load(p.state, p.n, live_lane ? i : wfirst);              // dead lanes of the last wave mirror a valid env: the cooperative
+    if (live_lane) key = hash_env_key(p.a_seed, (uint64_t)(p.env0 + i));   // queue code reads every lane's cursor
     // The lane's obs row lives in LDS for the whole rollout and is kept up to date INCREMENTALLY: a move sets the new head
     // byte and clears the vacated tail byte, a new food sets one byte; only an episode reset rewrites the row, and that is
     // done by the wave together (25 lanes clear the row of each resetting env) — rebuilding 25 dwords per lane per step
@@ -691,7 +702,7 @@ __global__ __launch_bounds__(BLOCK + WRITERS, MINW) void rollout_kernel(Params p
     if (row && live_lane) { e.write_obs_body(row); e.write_obs_food(row); }
     // explicit actions are fetched one step ahead so the load's latency hides behind the previous step
     uint32_t a_next = (live_lane && p.actions && p.k_steps > 0) ? (uint32_t)p.actions[i] : 0u;
-    uint32_t *blk = p.mt + (live_lane ? i : first) * MT_STRIDE;
+    uint32_t *blk = p.mt + (live_lane ? i : wfirst) * MT_STRIDE;
     // generator words for the whole launch, drawn before the first observation store is in flight (see QLay)
     const bool use_q = p.k_steps >= Q::MIN_STEPS;
     uint32_t *wave_q = qmem + (threadIdx.x & ~63u) * Q::QROW;
@@ -713,7 +724,7 @@ __global__ __launch_bounds__(BLOCK + WRITERS, MINW) void rollout_kernel(Params p
                 a = a_next;
                 if (t + 1 < p.k_steps) a_next = (uint32_t)p.actions[(int64_t)(t + 1) * p.n + i];
             } else {
-                a = hash_action_from_key(key, (uint64_t)(p.t0 + t), 4u, 0u);
+                a = (p.debug & 4) ? ((uint32_t)t + lane) & 3u : hash_action_from_key(key, (uint64_t)(p.t0 + t), 4u, 0u);
             }
             tf = transition<G, FW>(e, p, i, a, a <= 3u, nullptr, r, term);
             need_food = tf & T_NEED_FOOD; was_reset = tf & T_WAS_RESET;
@@ -724,8 +735,7 @@ __global__ __launch_bounds__(BLOCK + WRITERS, MINW) void rollout_kernel(Params p
             place(again);
             if (tf & T_DEFERRED) { was_reset = true; need_food = again; }
         }
-        if (row) {
-            if (t > 0) lds_barrier();                          // B2(t-1): the writer has read obs(t-1)
+        if (row && !(p.debug & 8)) {
             unsigned long long rm = __ballot(was_reset);
             while (rm) {                                       // wave-uniform: clear the rows of the envs that were reset
                 const uint32_t rl = (uint32_t)__ffsll((long long)rm) - 1u;
@@ -738,7 +748,10 @@ __global__ __launch_bounds__(BLOCK + WRITERS, MINW) void rollout_kernel(Params p
                 else if (e.head != old_head) { rowb[e.head] = 1; if (e.tail != old_tail) rowb[old_tail] = 0; }
                 if (need_food) e.write_obs_food(row);
             }
-            lds_barrier();                                     // B1(t): rows hold obs(t)
+            // the wave's own LDS traffic is ordered (one in-order queue per wave): the tile reads below see the row writes above,
+            // and the next step's row writes cannot overtake these reads
+            if (!(p.debug & 2))
+                store_wave_rows<64 * L::CELLS>(wave_rows, p.obs + (int64_t)t * p.obs_step_stride + wfirst * L::CELLS, (uint32_t)(wlive * L::CELLS), lane);
         }
         if (live_lane) {
             rsum += r;
@@ -747,7 +760,6 @@ __global__ __launch_bounds__(BLOCK + WRITERS, MINW) void rollout_kernel(Params p
             if (p.terminated) p.terminated[(int64_t)t * p.n + i] = term ? 1 : 0;
         }
     }
-    if (row && p.k_steps > 0) lds_barrier();                   // B2(k-1), pairs with the writer's last barrier
     if (use_q) queue_commit<G>(e, blk, qcur, qlen);
     if (live_lane) {
         e.store(p.state, p.n, i);
@@ -927,7 +939,7 @@ void set_variant(Ops &o) {
         hipLaunchKernelGGL((step_kernel<G, BLOCK, MINW, FW>), dim3((unsigned)((p.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, p);
     };
     o.rollout = [](const Params &p, hipStream_t s) {
-        hipLaunchKernelGGL((rollout_kernel<G, BLOCK, MINW, FW>), dim3((unsigned)((p.n + BLOCK - 1) / BLOCK)), dim3(BLOCK + WRITERS), 0, s, p);
+        hipLaunchKernelGGL((rollout_kernel<G, BLOCK, MINW, FW>), dim3((unsigned)((p.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, p);
     };
 }
 
@@ -965,9 +977,10 @@ static bool ops_for(int grid, Ops &o) {
             const char *v = getenv("CGE_SNAKE_VARIANT");
             const int k = v ? atoi(v) : 0;
             if (k == 1) set_variant<10, 256, 5, 8>(o);
-            else if (k == 2) set_variant<10, 128, 1, 8>(o);
-            else if (k == 3) set_variant<10, 128, 5, 8>(o);
-            else if (k == 4) set_variant<10, 64, 5, 8>(o);
+            else if (k == 2) set_variant<10, 64, 1, 8>(o);
+            else if (k == 3) set_variant<10, 64, 5, 8>(o);
+            else if (k == 4) set_variant<10, 256, 4, 8>(o);
+            else if (k == 5) set_variant<10, 64, 4, 8>(o);
             return true;
         }
         case 12: o = make_ops<12>(); return true;
