@@ -13,6 +13,7 @@ from .manufacturing import ManufacturingVectorEnv  # noqa: F401
 from .hospital import HospitalVectorEnv  # noqa: F401
 from . import sharding  # noqa: F401
 from .sharding import gather_obs, make_sharded, shard_range  # noqa: F401
+from .registry import NumpyVectorEnv, make_vec, registered_ids  # noqa: F401
 
-__all__ = ["SnakeVectorEnv", "CryptoVectorEnv", "TrafficVectorEnv", "ParkingVectorEnv", "ClimateVectorEnv", "FleetVectorEnv", "ManufacturingVectorEnv", "HospitalVectorEnv", "sharding", "make_sharded", "gather_obs", "shard_range", "AutoresetMode", "DeviceVectorEnv", "NativeLibraryError", "native_lib"]
+__all__ = ["SnakeVectorEnv", "CryptoVectorEnv", "TrafficVectorEnv", "ParkingVectorEnv", "ClimateVectorEnv", "FleetVectorEnv", "ManufacturingVectorEnv", "HospitalVectorEnv", "sharding", "make_sharded", "gather_obs", "shard_range", "make_vec", "registered_ids", "NumpyVectorEnv", "AutoresetMode", "DeviceVectorEnv", "NativeLibraryError", "native_lib"]
 __version__ = "0.1.0"
