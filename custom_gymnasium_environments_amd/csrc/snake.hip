@@ -23,6 +23,7 @@
 
 #include "cge_device.hpp"
 #include "cge_host.hpp"
+#include "snake_place.hpp"
 
 namespace cge {
 namespace snake {
@@ -260,7 +261,7 @@ struct Env {
     }
 
     // snake_env.py:67-119 without _place_food(); returns terminated, sets `ate`
-    __device__ __forceinline__ bool move(uint32_t action, uint32_t max_steps, float &reward, bool &ate) {
+    __device__ __forceinline__ bool move(uint32_t action, uint32_t max_steps, float &reward, bool &ate, bool short_wave) {
         ate = false;
         const int d = (int)action - (int)dir;
         if (d != 2 && d != -2) dir = action;                                      // :73-74
@@ -273,9 +274,12 @@ struct Env {
             reward = -10.0f;
             return true;
         }
-        // :97 insert(0, new_head): the move joins the history at position 0
+        // :97 insert(0, new_head): the move joins the history at position 0.  short_wave (wave-uniform: no lane of the wave has more
+        // than 15 cells, i.e. all of random play): the whole history sits in sr[0] and stays there after this move
+        if (!short_wave) {
 #pragma unroll
-        for (int k = L::SRW - 1; k > 0; --k) sr[k] = (sr[k] << 2) | (sr[k - 1] >> 30);
+            for (int k = L::SRW - 1; k > 0; --k) sr[k] = (sr[k] << 2) | (sr[k - 1] >> 30);
+        }
         sr[0] = (sr[0] << 2) | dir;
         or_word(occ, ncell >> 5, 1u << (ncell & 31u));
         head = ncell;
@@ -287,8 +291,14 @@ struct Env {
             ate = true;
         } else {                                                                  // :107 pop(): the oldest move (entry len-1) leaves
             const uint32_t p = 2u * (len - 1u);
-            const uint32_t td = (sel(sr, p >> 5) >> (p & 31u)) & 3u;
-            andnot_word(sr, p >> 5, 3u << (p & 31u));
+            uint32_t td;
+            if (short_wave) {
+                td = (sr[0] >> p) & 3u;
+                sr[0] &= ~(3u << p);
+            } else {
+                td = (sel(sr, p >> 5) >> (p & 31u)) & 3u;
+                andnot_word(sr, p >> 5, 3u << (p & 31u));
+            }
             andnot_word(occ, tail >> 5, 1u << (tail & 31u));
             tail = (uint32_t)((int)tail + dir_delta(td, G));
         }
@@ -504,6 +514,7 @@ __device__ __forceinline__ void queue_commit(Env<G> &e, uint32_t *blk, uint32_t 
 // _place_food (snake_env.py:121-129) out of the lane's digit queue; must be called by all 64 lanes of the wave
 template <int G>
 __device__ __forceinline__ void queue_place_food(Env<G> &e, uint32_t *blk, uint32_t *wave_q, uint32_t &qcur, uint32_t &qlen, bool need) {
+    using L = Lay<G>;
     using Q = QLay<G>;
     const uint32_t *myq = wave_q + (threadIdx.x & 63u) * Q::QROW;
     bool pending = need;
@@ -518,19 +529,25 @@ __device__ __forceinline__ void queue_place_food(Env<G> &e, uint32_t *blk, uint3
         const uint32_t bits = (uint32_t)((((uint64_t)myq[idx + 1] << 32) | (uint64_t)myq[idx]) >> off);
         uint32_t used = 0;
         bool done = !pending;
+        if constexpr (L::TIGHT) {                              // 10x10: bit-parallel scan of the 8 digits (snake_place.hpp)
+            const uint64_t lo = (uint64_t)e.occ[0] | ((uint64_t)e.occ[1] << 32), hi = (uint64_t)e.occ[2] | ((uint64_t)e.occ[3] << 32);
+            const PlaceScan r = place_scan8<G>(bits, phase, row, lo, hi);
+            if (pending) { used = r.used; phase = r.phase; row = r.row; done = r.done; if (r.done) e.food = r.food; }
+        } else {
 #pragma unroll
-        for (int j = 0; j < Q::PER; ++j) {
-            if (!done) {
-                const uint32_t r = (bits >> (Q::DB * j)) & ((1u << Q::DB) - 1u);
-                used = j + 1;
-                if (r < (uint32_t)G) {
-                    if (phase == 0) {
-                        row = r;
-                        phase = 1;
-                    } else {
-                        phase = 0;
-                        const uint32_t cell = row * G + r;
-                        if (!e.occupied(cell)) { e.food = cell; done = true; }
+            for (int j = 0; j < Q::PER; ++j) {
+                if (!done) {
+                    const uint32_t r = (bits >> (Q::DB * j)) & ((1u << Q::DB) - 1u);
+                    used = j + 1;
+                    if (r < (uint32_t)G) {
+                        if (phase == 0) {
+                            row = r;
+                            phase = 1;
+                        } else {
+                            phase = 0;
+                            const uint32_t cell = row * G + r;
+                            if (!e.occupied(cell)) { e.food = cell; done = true; }
+                        }
                     }
                 }
             }
@@ -557,7 +574,7 @@ __device__ __forceinline__ void write_final_obs(const Env<G> &e, const Params &p
 // window load is issued, the obs body is staged while it is in flight, then the food is placed.
 template <int G, int FW = FOOD_WINDOW>
 __device__ __forceinline__ uint32_t transition(Env<G> &e, const Params &p, int64_t i, uint32_t action, bool valid_action,
-                                               uint32_t *__restrict__ obs_row, float &reward, bool &term) {
+                                               uint32_t *__restrict__ obs_row, float &reward, bool &term, bool short_wave) {
     using L = Lay<G>;
     bool need_food = false, was_reset = false, deferred = false;
     reward = 0.0f;
@@ -568,7 +585,7 @@ __device__ __forceinline__ uint32_t transition(Env<G> &e, const Params &p, int64
     } else if (!valid_action) {
         atomicAdd(p.err_count, 1ull);   // reference: ValueError (snake_env.py:69-70)
     } else {
-        term = e.move(action, (uint32_t)p.max_steps, reward, need_food);
+        term = e.move(action, (uint32_t)p.max_steps, reward, need_food, short_wave);
         if (term) {
             e.episodes += 1;
             // episode statistics need no accumulator here: every reward is +10 per point of `score`, -10 for the collision that
@@ -624,9 +641,10 @@ __global__ __launch_bounds__(BLOCK, MINW) void step_kernel(Params p) {
     bool term = false;
     uint32_t tf = 0;
     uint32_t *row = tile + threadIdx.x * L::OBS_DW;
+    const bool short_wave = __ballot(e.len > 15u) == 0ull;     // every history of this wave fits one word (see Env::move)
     if (live_lane) {
         const int32_t a = p.actions[i];
-        tf = transition<G, FW>(e, p, i, (uint32_t)a, (uint32_t)a <= 3u, row, r, term);
+        tf = transition<G, FW>(e, p, i, (uint32_t)a, (uint32_t)a <= 3u, row, r, term, short_wave);
     }
     wave_place_food<G>(e, p.mt + li * MT_STRIDE, tf & T_NEED_FOOD);
     if (__ballot(tf & T_DEFERRED)) {                           // rare, wave-uniform
@@ -718,6 +736,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
         bool term = false, need_food = false, was_reset = false;
         uint32_t tf = 0;
         const uint32_t old_head = e.head, old_tail = e.tail;
+        const bool short_wave = __ballot(e.len > 15u) == 0ull;  // every history of this wave fits one word (see Env::move)
         if (live_lane) {
             uint32_t a;
             if (p.actions) {
@@ -726,7 +745,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
             } else {
                 a = (p.debug & 4) ? ((uint32_t)t + lane) & 3u : hash_action_from_key(key, (uint64_t)(p.t0 + t), 4u, 0u);
             }
-            tf = transition<G, FW>(e, p, i, a, a <= 3u, nullptr, r, term);
+            tf = transition<G, FW>(e, p, i, a, a <= 3u, nullptr, r, term, short_wave);
             need_food = tf & T_NEED_FOOD; was_reset = tf & T_WAS_RESET;
         }
         place(need_food);

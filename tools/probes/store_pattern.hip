@@ -67,15 +67,25 @@ int main() {
     const int ntiles = 4096, K = 200;
     const long long slab_v = (long long)ntiles * TILE_V;
     uint4 *buf;
-    CK(hipMalloc(&buf, (size_t)K * slab_v * 16));
+    CK(hipMalloc(&buf, (size_t)K * slab_v * 16 + (64u << 20) + (size_t)K * (2 << 20) + (1 << 20)));
     CK(hipMemset(buf, 0, (size_t)K * slab_v * 16));
     const double mb_step = ntiles * (double)TILE_B / 1e6;
     auto report = [&](const char *name, float ms, int steps) {
-        printf("%-64s %8.2f us/step  %6.2f TB/s\n", name, ms * 1e3 / steps, mb_step * steps / ms / 1e6);
+        printf("%-72s %8.2f us/step  %6.2f TB/s\n", name, ms * 1e3 / steps, mb_step * steps / ms / 1e3);
     };
 #define RUN(NAME, THREADS, NT, LDS, RING, DELAY) \
     report(NAME, time_ms([&] { hipLaunchKernelGGL((tile_per_step<THREADS, NT, LDS>), dim3(ntiles), dim3(THREADS), 0, 0, buf, slab_v, K, RING, ntiles, DELAY); }), K)
     RUN("64 writers/WG, 6 WG/CU, trajectory", 64, false, 25600, K, 0);
+    // does the slab stride matter?  (N*100 bytes = 100 MiB exactly: steps that are in flight together differ by multiples of 2^20)
+    {
+        const long long pads[] = {16, 256 / 16 * 17, 4096 / 16 + 16, 65536 / 16 + 48, (2 << 20) / 16 + 272};
+        for (long long pad : pads) {
+            const long long sv = slab_v + pad;
+            char name[96];
+            snprintf(name, sizeof name, "64 writers/WG, 6 WG/CU, trajectory, slab stride + %lld B", pad * 16);
+            report(name, time_ms([&] { hipLaunchKernelGGL((tile_per_step<64, false, 25600>), dim3(ntiles), dim3(64), 0, 0, buf, sv, K, K, ntiles, 0); }), K);
+        }
+    }
     RUN("64 writers/WG, 6 WG/CU, trajectory, nt", 64, true, 25600, K, 0);
     RUN("64 writers/WG, 6 WG/CU, in place (ring 1)", 64, false, 25600, 1, 0);
     RUN("64 writers/WG, 6 WG/CU, ring 4", 64, false, 25600, 4, 0);
