@@ -30,7 +30,27 @@ __host__ __device__ inline uint32_t hash_action_from_key(uint64_t key, uint64_t 
 // ------------------------------------------------------------------ MT19937 (family P / L)
 constexpr int MT_N = 624;
 constexpr int MT_M = 397;
-constexpr int MT_STRIDE = 640;  // words per stream block: mt[624] + pad (=2560 B, 20 x 128-B lines)
+constexpr int MT_STRIDE = 640;  // words per stream block: mt[624] + 16 mirror words (=2560 B, 20 x 128-B lines)
+constexpr int MT_PAD = MT_STRIDE - MT_N;
+// Words 624..639 of a block MIRROR words 0..15.  A draw window is then always a run of CONSECUTIVE words — w[pos .. pos+W] and
+// w[pos+397 .. ] never wrap for W <= 16 — which lets a lane fetch it with a few 16-byte loads instead of 2W+1 single-dword loads
+// (every one of them a 64-address instruction for the CU's address unit: round 2 profile of the crypto dynamics, 63 % of the wave
+// time was issue stall).  Every writer of a block keeps the mirror current through mt_store().
+__device__ __forceinline__ void mt_store(uint32_t *blk, uint32_t k, uint32_t y) {
+    blk[k] = y;
+    if (k < (uint32_t)MT_PAD) blk[MT_N + k] = y;
+}
+struct __attribute__((packed, aligned(4))) MtQuad { uint32_t a, b, c, d; };   // 4-byte aligned 16-byte access (unaligned access mode)
+template <int N>
+__device__ __forceinline__ void mt_load_run(const uint32_t *__restrict__ src, uint32_t (&dst)[N]) {
+#pragma unroll
+    for (int q = 0; q + 4 <= N; q += 4) {
+        const MtQuad v = *reinterpret_cast<const MtQuad *>(src + q);
+        dst[q] = v.a; dst[q + 1] = v.b; dst[q + 2] = v.c; dst[q + 3] = v.d;
+    }
+#pragma unroll
+    for (int q = N - N % 4; q < N; ++q) dst[q] = src[q];
+}
 // The stream cursor lives in the ENV's state record, not in the block, so a draw never starts with a
 // dependent "load the cursor" round trip:
 //   pos    next word index, 0..623
@@ -65,7 +85,7 @@ struct MtStream {
             const uint32_t p1 = p + 1 == MT_N ? 0 : p + 1;
             const uint32_t pm = p + MT_M >= MT_N ? p + MT_M - MT_N : p + MT_M;
             y = mt_twist(w[p], w[p1], w[pm]);
-            w[p] = y;
+            mt_store(w, p, y);
         }
         ++p;
         if (p == MT_N) { p = 0; pretw = 0; }
@@ -95,18 +115,26 @@ struct MtWindow {
     uint32_t a[W + 1];
     uint32_t c[W];
 
+    static constexpr bool RUN = W <= MT_PAD;                      // short windows are runs of consecutive words (mirror), see MT_PAD
     __device__ __forceinline__ void load(const uint32_t *__restrict__ blk, uint32_t pos) {
+        if constexpr (RUN) {
+            mt_load_run<W + 1>(blk + pos, a);                     // w[pos .. pos+W], mirror words past 623
+            uint32_t cpos = pos + MT_M;
+            cpos -= cpos >= (uint32_t)MT_N ? MT_N : 0;
+            mt_load_run<W>(blk + cpos, c);                        // w[pos+397 ..]
+        } else {
 #pragma unroll
-        for (int j = 0; j <= W; ++j) {
-            uint32_t k = pos + j;
-            k -= k >= (uint32_t)MT_N ? MT_N : 0;
-            a[j] = blk[k];
-        }
+            for (int j = 0; j <= W; ++j) {
+                uint32_t k = pos + j;
+                k -= k >= (uint32_t)MT_N ? MT_N : 0;
+                a[j] = blk[k];
+            }
 #pragma unroll
-        for (int j = 0; j < W; ++j) {
-            uint32_t k = pos + MT_M + j;
-            k -= k >= (uint32_t)MT_N ? MT_N : 0;
-            c[j] = blk[k];
+            for (int j = 0; j < W; ++j) {
+                uint32_t k = pos + MT_M + j;
+                k -= k >= (uint32_t)MT_N ? MT_N : 0;
+                c[j] = blk[k];
+            }
         }
     }
     // untempered word number j (static index) of the stream starting at (pos, pretw)
@@ -117,13 +145,32 @@ struct MtWindow {
     __device__ __forceinline__ uint32_t draw(int j, uint32_t pos, uint32_t pretw) const { return mt_temper(twisted(j, pos, pretw)); }
     // persist the first `used` words and advance the cursor
     __device__ __forceinline__ void commit(uint32_t *__restrict__ blk, uint32_t &pos, uint32_t &pretw, uint32_t used) const {
+        if constexpr (RUN) {
+            // the window goes back as one run: consumed words twisted, the others as they were (this lane owns the block)
+            uint32_t v[W];
 #pragma unroll
-        for (int j = 0; j < W; ++j) {
-            uint32_t k = pos + j;
-            if ((uint32_t)j < used && k >= pretw) {
-                const uint32_t y = mt_twist(a[j], a[j + 1], c[j]);
-                k -= k >= (uint32_t)MT_N ? MT_N : 0;
-                blk[k] = y;
+            for (int j = 0; j < W; ++j) v[j] = ((uint32_t)j < used && pos + j >= pretw) ? mt_twist(a[j], a[j + 1], c[j]) : a[j];
+#pragma unroll
+            for (int q = 0; q + 4 <= W; q += 4) *reinterpret_cast<MtQuad *>(blk + pos + q) = MtQuad{v[q], v[q + 1], v[q + 2], v[q + 3]};
+#pragma unroll
+            for (int q = W - W % 4; q < W; ++q) blk[pos + q] = v[q];
+            if (pos + W > (uint32_t)MT_N || pos < (uint32_t)MT_PAD) {     // the run touched the mirror or the mirrored words: fix the twin
+#pragma unroll
+                for (int j = 0; j < W; ++j) {
+                    const uint32_t k = pos + j;
+                    if (k >= (uint32_t)MT_N) blk[k - MT_N] = v[j];
+                    else if (k < (uint32_t)MT_PAD) blk[MT_N + k] = v[j];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                uint32_t k = pos + j;
+                if ((uint32_t)j < used && k >= pretw) {
+                    const uint32_t y = mt_twist(a[j], a[j + 1], c[j]);
+                    k -= k >= (uint32_t)MT_N ? MT_N : 0;
+                    mt_store(blk, k, y);
+                }
             }
         }
         uint32_t p = pos + used;
@@ -159,7 +206,7 @@ struct LdsDraws {
             uint32_t k = pos + j;
             if (k >= pretw) {
                 k -= k >= (uint32_t)MT_N ? MT_N : 0;
-                blk[k] = row[j];
+                mt_store(blk, k, row[j]);
             }
         }
         uint32_t p = pos + cur;
@@ -282,7 +329,7 @@ struct LdsBulkDraws {
             uint32_t k = pos + j;
             if (k >= pretw) {
                 k -= k >= (uint32_t)MT_N ? MT_N : 0;
-                blk[k] = row[j];
+                mt_store(blk, k, row[j]);
             }
         }
         uint32_t p = pos + cur;
@@ -388,7 +435,7 @@ __device__ __forceinline__ void coop_flush(LdsBulkDraws<W> &d, int row_stride) {
             uint32_t k = pos + j;
             if (j < cur && k >= pretw) {
                 k -= k >= (uint32_t)MT_N ? MT_N : 0;
-                blk[k] = row[j];
+                mt_store(blk, k, row[j]);
             }
         }
     }
@@ -458,6 +505,36 @@ __device__ __forceinline__ void store_tile(const uint32_t *tile, int8_t *dst, ui
         const uint32_t ndw = bytes_valid >> 2;
         uint32_t *d1 = reinterpret_cast<uint32_t *>(dst);
         for (uint32_t q = tid; q < ndw; q += BLOCK) d1[q] = tile[q];
+    }
+}
+
+
+// ------------------------------------------------------------------ row chunks -> HBM in 16-byte pieces
+// float32 observations wider than a few dozen values are assembled by COLUMN chunks: each lane stages W consecutive values of
+// its own env's row in LDS (row stride LSTRIDE dwords, odd: conflict-free), then the wave streams the [rows][W] chunk into the
+// row-major (N, OBS) output.  A piece is 4 consecutive values of one row; consecutive lanes take consecutive pieces of a row and
+// then of the next row, so one store instruction covers 64/(W/4) row segments of W*4 contiguous bytes each.  Rows are only
+// 4-byte aligned (OBS is odd for crypto): gfx950 runs with unaligned access enabled, the compiler emits global_store_dwordx4
+// for these 4-byte-aligned 16-byte stores (checked on the ISA and on the device).  Round 1 stored the chunks dword by dword:
+// 261 store instructions and ~3,000 VALU of index arithmetic per wave and step for crypto, against 66 / ~600 this way.
+struct __attribute__((packed, aligned(4))) Piece16 { uint32_t a, b, c, d; };
+
+template <int W, int LSTRIDE, int OBS>
+__device__ __forceinline__ void store_row_chunk(const uint32_t *tile, float *dst, int col0, int64_t nrows, unsigned long long rowmask) {
+    static_assert(W % 4 == 0, "a chunk is a whole number of 16-byte pieces");
+    constexpr uint32_t P = W / 4;                              // pieces per row
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t row = lane / P, piece = lane - row * P;
+#pragma unroll
+    for (uint32_t m = 0; m < P; ++m) {                         // 64 rows x P pieces = P passes of 64 lanes
+        if ((int64_t)row < nrows && ((rowmask >> row) & 1ull)) {
+            const uint32_t *src = tile + row * LSTRIDE + piece * 4u;
+            Piece16 v{src[0], src[1], src[2], src[3]};
+            *reinterpret_cast<Piece16 *>(dst + (int64_t)row * OBS + col0 + piece * 4u) = v;
+        }
+        piece += 64u % P;
+        row += 64u / P;
+        if (piece >= P) { piece -= P; row += 1u; }
     }
 }
 

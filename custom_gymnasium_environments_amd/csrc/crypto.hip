@@ -856,6 +856,8 @@ int cge_crypto_set_state(cge_crypto *h, const void *host_buf, void *stream) {
                                    ppos | ppre | (lpos << 11) | lpre | ((ep >> 9) << 22), lo(scv[5]), hi(scv[5]));
         memcpy(&mp[(size_t)i * MT_STRIDE], p + 96, MT_N * 4);
         memcpy(&ml[(size_t)i * MT_STRIDE], p + 96 + MT_N * 4, MT_N * 4);
+        memcpy(&mp[(size_t)i * MT_STRIDE + MT_N], &mp[(size_t)i * MT_STRIDE], MT_PAD * 4);       // mirror words (cge_device.hpp)
+        memcpy(&ml[(size_t)i * MT_STRIDE + MT_N], &ml[(size_t)i * MT_STRIDE], MT_PAD * 4);
         for (int k = 0; k < crypto::HLEN; ++k) {
             const int slot = (h->phase + k) % crypto::HLEN;
             cl[(size_t)slot * n + i] = hh[5 * k + 3];

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(SEED_LANES) void mt_seed_kernel(uint32_t *__restric
     const int live = (int)((n - first) < SEED_LANES ? (n - first) : SEED_LANES);
     for (int e = 0; e < live; ++e) {
         uint32_t *dst = mt + (first + e) * stride_words;
-        for (int w = lane; w < MT_STRIDE; w += SEED_LANES) dst[w] = w < MT_N ? s[w * SEED_ROW + e] : 0u;  // pos = pretw = 0
+        for (int w = lane; w < MT_STRIDE; w += SEED_LANES) dst[w] = s[(w < MT_N ? w : w - MT_N) * SEED_ROW + e];   // 624.. mirror 0..15
     }
 }
 

@@ -394,7 +394,7 @@ __device__ __forceinline__ void wave_place_food(Env<G> &e, uint32_t *blk, bool n
         const uint32_t cm = (uint32_t)(__ballot(cand) >> (8u * g)) & 0xFFu;
         const uint32_t jdone = cm ? (uint32_t)__ffs((int)cm) - 1u : 7u;
         const uint32_t used = cm ? jdone + 1u : 8u;
-        if (active && j < used && pos + j >= pretw) const_cast<uint32_t *>(oblk)[k] = y;   // persist the consumed words
+        if (active && j < used && pos + j >= pretw) mt_store(const_cast<uint32_t *>(oblk), k, y);   // persist the consumed words
         const uint32_t wcell = shfl_u32(cell, g * 8u + jdone);
         // not placed with these 8 words: an unpaired row (odd number of valid draws) carries into the next window
         const uint32_t nv = (uint32_t)__popc(vm) + (ocarry & 1u);
@@ -501,7 +501,7 @@ __device__ __forceinline__ void queue_commit(Env<G> &e, uint32_t *blk, uint32_t 
             const uint32_t k1 = k + 1 == (uint32_t)MT_N ? 0 : k + 1;
             const uint32_t km = k + MT_M >= (uint32_t)MT_N ? k + MT_M - MT_N : k + MT_M;
             const uint32_t y = mt_twist(ob[k], ob[k1], ob[km]);   // every load of the round precedes its stores (program order)
-            if (j < used && pos + j >= pretw) ob[k] = y;
+            if (j < used && pos + j >= pretw) mt_store(ob, k, y);
         }
     }
     uint32_t np = e.mt_pos + qcur;
@@ -1243,6 +1243,7 @@ int cge_snake_set_state(cge_snake *h, const void *host_buf, void *stream) {
         for (int c = 0; c < cols; ++c) st[(size_t)c * n + i] = make_uint4(raw[4 * c], raw[4 * c + 1], raw[4 * c + 2], raw[4 * c + 3]);
         uint32_t *w = &mt[(size_t)i * MT_STRIDE];
         memcpy(w, p + 32, MT_N * 4);
+        memcpy(w + MT_N, w, MT_PAD * 4);                           // words 624.. mirror words 0..15 (cge_device.hpp)
     }
     CGE_TRY(h, hipStreamSynchronize(as_stream(stream)));
     CGE_TRY(h, hipMemcpy(h->state, st.data(), st.size() * sizeof(uint4), hipMemcpyHostToDevice));

@@ -619,6 +619,7 @@ int cge_traffic_set_state(cge_traffic *h, const void *host_buf, void *stream) {
         e.pack(raw);
         for (int c = 0; c < traffic::COLS; ++c) st[(size_t)c * n + i] = make_uint4(raw[4 * c], raw[4 * c + 1], raw[4 * c + 2], raw[4 * c + 3]);
         memcpy(&mt[(size_t)i * MT_STRIDE], w + 144, MT_N * 4);
+        memcpy(&mt[(size_t)i * MT_STRIDE + MT_N], &mt[(size_t)i * MT_STRIDE], MT_PAD * 4);     // mirror words (cge_device.hpp)
     }
     CGE_TRY(h, hipStreamSynchronize(as_stream(stream)));
     CGE_TRY(h, hipMemcpy(h->state, st.data(), st.size() * sizeof(uint4), hipMemcpyHostToDevice));
