@@ -748,11 +748,15 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
             tf = transition<G, FW>(e, p, i, a, a <= 3u, nullptr, r, term, short_wave);
             need_food = tf & T_NEED_FOOD; was_reset = tf & T_WAS_RESET;
         }
-        place(need_food);
-        if (__ballot(tf & T_DEFERRED)) {                       // rare, wave-uniform: ate on the step the time limit fired (SameStep)
-            const bool again = (tf & T_DEFERRED) && finish_deferred<G>(e, p, i, nullptr);
-            place(again);
-            if (tf & T_DEFERRED) { was_reset = true; need_food = again; }
+        // one inlined copy of the placement code, run a second time only when some lane ate on the very step its time limit fired
+        // (SameStep: post-eat food, then reset, then the fresh episode's food — rare, wave-uniform)
+        bool want = need_food;
+#pragma unroll 1
+        for (int round = 0; round < 2; ++round) {
+            place(want);
+            if (round == 1 || __ballot(tf & T_DEFERRED) == 0ull) break;
+            want = (tf & T_DEFERRED) && finish_deferred<G>(e, p, i, nullptr);
+            if (tf & T_DEFERRED) { was_reset = true; need_food = want; }
         }
         if (row && !(p.debug & 8)) {
             unsigned long long rm = __ballot(was_reset);
