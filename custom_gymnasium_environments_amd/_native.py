@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcge_amd.so")
+# CGE_AMD_LIBRARY: A/B measurements against another build of the SAME library (tools/ab/); not a backend switch
+LIB_PATH = os.environ.get("CGE_AMD_LIBRARY") or os.path.join(_HERE, "libcge_amd.so")
 
 CGE_OK = 0
 STATUS_NAMES = {0: "CGE_OK", -1: "CGE_ERR_INVALID_ARG", -2: "CGE_ERR_HIP", -3: "CGE_ERR_UNSUPPORTED",

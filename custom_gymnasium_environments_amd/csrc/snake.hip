@@ -337,7 +337,6 @@ struct Params {
     double *ep_ret;       // episode statistics (cge_snake_episode_stats), nullable
     int32_t *ep_len;
     unsigned long long *err_count;
-    int32_t debug;        // measurement switches (CGE_SNAKE_DEBUG, never set by the product): 1 = rollout skips food placement, 2 = skips the obs stores, 4 = trivial actions instead of the hash, 8 = skips the row updates
 };
 
 __device__ __forceinline__ uint32_t shfl_u32(uint32_t v, uint32_t src) { return (uint32_t)__shfl((int)v, (int)src, 64); }
@@ -572,14 +571,14 @@ __device__ __forceinline__ void write_final_obs(const Env<G> &e, const Params &p
 
 // One env transition with fused auto-reset.  Everything except the food draw happens first; the RNG
 // window load is issued, the obs body is staged while it is in flight, then the food is placed.
-template <int G, int FW = FOOD_WINDOW>
+template <int G, int MODE>
 __device__ __forceinline__ uint32_t transition(Env<G> &e, const Params &p, int64_t i, uint32_t action, bool valid_action,
                                                uint32_t *__restrict__ obs_row, float &reward, bool &term, bool short_wave) {
     using L = Lay<G>;
     bool need_food = false, was_reset = false, deferred = false;
     reward = 0.0f;
     term = false;
-    if (p.mode == CGE_AUTORESET_NEXT_STEP && (e.flags & F_NEEDS_RESET)) {
+    if (MODE == CGE_AUTORESET_NEXT_STEP && (e.flags & F_NEEDS_RESET)) {
         e.reset_body();
         need_food = true; was_reset = true;
     } else if (!valid_action) {
@@ -593,7 +592,7 @@ __device__ __forceinline__ uint32_t transition(Env<G> &e, const Params &p, int64
             const bool crashed = reward < 0.0f;
             if (p.ep_ret) p.ep_ret[i] = 10.0 * (double)e.score - (crashed ? 10.0 : 0.0);
             if (p.ep_len) p.ep_len[i] = (int32_t)e.steps + (crashed ? 1 : 0);
-            if (p.mode == CGE_AUTORESET_SAME_STEP) {
+            if (MODE == CGE_AUTORESET_SAME_STEP) {
                 if (need_food) {
                     // time limit on a step that also ate: the reference places the new food (snake_env.py:104) BEFORE it tests
                     // steps >= max_steps (:113), so the terminal obs shows it and the reset draws a second one.  Both draws go
@@ -605,7 +604,7 @@ __device__ __forceinline__ uint32_t transition(Env<G> &e, const Params &p, int64
                     e.reset_body();
                     need_food = true; was_reset = true;
                 }
-            } else if (p.mode == CGE_AUTORESET_NEXT_STEP) {
+            } else if (MODE == CGE_AUTORESET_NEXT_STEP) {
                 e.flags |= F_NEEDS_RESET;
             }
         }
@@ -626,7 +625,7 @@ __device__ __forceinline__ bool finish_deferred(Env<G> &e, const Params &p, int6
     return e.can_place_food();
 }
 
-template <int G, int BLOCK, int MINW, int FW>
+template <int G, int BLOCK, int MINW, int MODE>
 __global__ __launch_bounds__(BLOCK, MINW) void step_kernel(Params p) {
     using L = Lay<G>;
     __shared__ uint4 tile4[BLOCK * L::OBS_DW / 4];
@@ -644,7 +643,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void step_kernel(Params p) {
     const bool short_wave = __ballot(e.len > 15u) == 0ull;     // every history of this wave fits one word (see Env::move)
     if (live_lane) {
         const int32_t a = p.actions[i];
-        tf = transition<G, FW>(e, p, i, (uint32_t)a, (uint32_t)a <= 3u, row, r, term, short_wave);
+        tf = transition<G, MODE>(e, p, i, (uint32_t)a, (uint32_t)a <= 3u, row, r, term, short_wave);
     }
     wave_place_food<G>(e, p.mt + li * MT_STRIDE, tf & T_NEED_FOOD);
     if (__ballot(tf & T_DEFERRED)) {                           // rare, wave-uniform
@@ -690,7 +689,7 @@ __device__ __forceinline__ void store_wave_rows(const uint32_t *rows, int8_t *ds
 // STORES.  The per-launch digit queue (QLay) removed every global load from the step loop, and with it the reason for the
 // writer: measured on 1M envs with every step's obs written to a [K, N, 100] trajectory, writer-wave kernel 28.5-38 us per
 // step (74 % of wave time parked at the barriers), this kernel see DESIGN.md section 6.
-template <int G, int BLOCK, int MINW, int FW>
+template <int G, int BLOCK, int MINW, int MODE, bool USE_Q>
 __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
     using L = Lay<G>;
     using Q = QLay<G>;
@@ -722,13 +721,11 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
     uint32_t a_next = (live_lane && p.actions && p.k_steps > 0) ? (uint32_t)p.actions[i] : 0u;
     uint32_t *blk = p.mt + (live_lane ? i : wfirst) * MT_STRIDE;
     // generator words for the whole launch, drawn before the first observation store is in flight (see QLay)
-    const bool use_q = p.k_steps >= Q::MIN_STEPS;
     uint32_t *wave_q = qmem + (threadIdx.x & ~63u) * Q::QROW;
     uint32_t qcur = 0, qlen = 0;
-    if (use_q) queue_fill<G>(e, blk, wave_q, qcur, qlen);
+    if (USE_Q) queue_fill<G>(e, blk, wave_q, qcur, qlen);
     auto place = [&](bool need) {
-        if (p.debug & 1) return;
-        if (use_q) queue_place_food<G>(e, blk, wave_q, qcur, qlen, need);
+        if (USE_Q) queue_place_food<G>(e, blk, wave_q, qcur, qlen, need);
         else wave_place_food<G>(e, blk, need);
     };
     for (int t = 0; t < p.k_steps; ++t) {
@@ -743,9 +740,9 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
                 a = a_next;
                 if (t + 1 < p.k_steps) a_next = (uint32_t)p.actions[(int64_t)(t + 1) * p.n + i];
             } else {
-                a = (p.debug & 4) ? ((uint32_t)t + lane) & 3u : hash_action_from_key(key, (uint64_t)(p.t0 + t), 4u, 0u);
+                a = hash_action_from_key(key, (uint64_t)(p.t0 + t), 4u, 0u);
             }
-            tf = transition<G, FW>(e, p, i, a, a <= 3u, nullptr, r, term, short_wave);
+            tf = transition<G, MODE>(e, p, i, a, a <= 3u, nullptr, r, term, short_wave);
             need_food = tf & T_NEED_FOOD; was_reset = tf & T_WAS_RESET;
         }
         // one inlined copy of the placement code, run a second time only when some lane ate on the very step its time limit fired
@@ -758,7 +755,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
             want = (tf & T_DEFERRED) && finish_deferred<G>(e, p, i, nullptr);
             if (tf & T_DEFERRED) { was_reset = true; need_food = want; }
         }
-        if (row && !(p.debug & 8)) {
+        if (row) {
             unsigned long long rm = __ballot(was_reset);
             while (rm) {                                       // wave-uniform: clear the rows of the envs that were reset
                 const uint32_t rl = (uint32_t)__ffsll((long long)rm) - 1u;
@@ -773,8 +770,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
             }
             // the wave's own LDS traffic is ordered (one in-order queue per wave): the tile reads below see the row writes above,
             // and the next step's row writes cannot overtake these reads
-            if (!(p.debug & 2))
-                store_wave_rows<64 * L::CELLS>(wave_rows, p.obs + (int64_t)t * p.obs_step_stride + wfirst * L::CELLS, (uint32_t)(wlive * L::CELLS), lane);
+            store_wave_rows<64 * L::CELLS>(wave_rows, p.obs + (int64_t)t * p.obs_step_stride + wfirst * L::CELLS, (uint32_t)(wlive * L::CELLS), lane);
         }
         if (live_lane) {
             rsum += r;
@@ -783,7 +779,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
             if (p.terminated) p.terminated[(int64_t)t * p.n + i] = term ? 1 : 0;
         }
     }
-    if (use_q) queue_commit<G>(e, blk, qcur, qlen);
+    if (USE_Q) queue_commit<G>(e, blk, qcur, qlen);
     if (live_lane) {
         e.store(p.state, p.n, i);
         if (p.reward_sum) p.reward_sum[i] = rsum;
@@ -955,15 +951,25 @@ bool encode_env(const int32_t *hdr, const uint16_t *body, uint32_t *raw) {
     return true;
 }
 
-template <int G, int BLOCK, int MINW, int FW>
+// the autoreset mode and the placement scheme are compile-time properties of the kernels (no mode tests in the step loop)
+template <int G, int BLOCK, int MINW, int MODE>
+void launch_mode(const Params &p, bool rollout, hipStream_t s) {
+    const dim3 grid((unsigned)((p.n + BLOCK - 1) / BLOCK)), block(BLOCK);
+    if (!rollout) hipLaunchKernelGGL((step_kernel<G, BLOCK, MINW, MODE>), grid, block, 0, s, p);
+    else if (p.k_steps >= QLay<G>::MIN_STEPS) hipLaunchKernelGGL((rollout_kernel<G, BLOCK, MINW, MODE, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((rollout_kernel<G, BLOCK, MINW, MODE, false>), grid, block, 0, s, p);
+}
+template <int G, int BLOCK, int MINW>
+void launch_any(const Params &p, bool rollout, hipStream_t s) {
+    if (p.mode == CGE_AUTORESET_SAME_STEP) launch_mode<G, BLOCK, MINW, CGE_AUTORESET_SAME_STEP>(p, rollout, s);
+    else if (p.mode == CGE_AUTORESET_NEXT_STEP) launch_mode<G, BLOCK, MINW, CGE_AUTORESET_NEXT_STEP>(p, rollout, s);
+    else launch_mode<G, BLOCK, MINW, CGE_AUTORESET_DISABLED>(p, rollout, s);
+}
+template <int G, int BLOCK, int MINW>
 void set_variant(Ops &o) {
     o.block = BLOCK;
-    o.step = [](const Params &p, hipStream_t s) {
-        hipLaunchKernelGGL((step_kernel<G, BLOCK, MINW, FW>), dim3((unsigned)((p.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, p);
-    };
-    o.rollout = [](const Params &p, hipStream_t s) {
-        hipLaunchKernelGGL((rollout_kernel<G, BLOCK, MINW, FW>), dim3((unsigned)((p.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, p);
-    };
+    o.step = [](const Params &p, hipStream_t s) { launch_any<G, BLOCK, MINW>(p, false, s); };
+    o.rollout = [](const Params &p, hipStream_t s) { launch_any<G, BLOCK, MINW>(p, true, s); };
 }
 
 template <int G>
@@ -974,7 +980,7 @@ Ops make_ops() {
     o.rewind = [](uint4 *st, int64_t n, hipStream_t s) {
         hipLaunchKernelGGL(rewind_kernel<G>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st, n);
     };
-    set_variant<G, L::BLOCK, 1, FOOD_WINDOW>(o);
+    set_variant<G, L::BLOCK, 1>(o);
     o.reset = [](const Params &p, hipStream_t s) {
         hipLaunchKernelGGL(reset_kernel<G>, dim3((unsigned)((p.n + L::BLOCK - 1) / L::BLOCK)), dim3(L::BLOCK), 0, s, p);
     };
@@ -999,11 +1005,7 @@ static bool ops_for(int grid, Ops &o) {
             // tuning variants of the benchmark grid, selectable for A/B runs (default = best measured)
             const char *v = getenv("CGE_SNAKE_VARIANT");
             const int k = v ? atoi(v) : 0;
-            if (k == 1) set_variant<10, 256, 5, 8>(o);
-            else if (k == 2) set_variant<10, 64, 1, 8>(o);
-            else if (k == 3) set_variant<10, 64, 5, 8>(o);
-            else if (k == 4) set_variant<10, 256, 4, 8>(o);
-            else if (k == 5) set_variant<10, 64, 4, 8>(o);
+            if (k == 1) set_variant<10, 64, 1>(o);
             return true;
         }
         case 12: o = make_ops<12>(); return true;
@@ -1029,7 +1031,6 @@ struct cge_snake : HandleBase {
         snake::Params p{};
         p.state = state; p.mt = mt; p.n = n; p.env0 = env0;
         p.mode = cfg.autoreset_mode; p.max_steps = cfg.max_steps; p.err_count = err;
-        { const char *d = getenv("CGE_SNAKE_DEBUG"); p.debug = d ? atoi(d) : 0; }
         p.ep_ret = ep_ret; p.ep_len = ep_len;
         return p;
     }
