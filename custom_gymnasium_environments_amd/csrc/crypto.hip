@@ -36,7 +36,7 @@ namespace crypto {
 
 constexpr int HLEN = 50;
 constexpr int OBS = 261;
-constexpr int CH = 10;            // candles per staged chunk
+constexpr int CH = 12;            // candles per chunk: 60 floats = 15 sixteen-byte stores per row
 constexpr int ROW = CH * 5 + 1;   // LDS row stride (dwords), odd
 constexpr int WP = 10;            // P window: trade slippage + volume + regime test + high + low = 5 doubles
 constexpr int WL = 8;             // L window: two polar-method attempts
@@ -356,137 +356,148 @@ struct Pairwise {
     }
 };
 
+// indicator state of one env while its 50 closes stream by (K = logical candle index, 0 oldest)
+struct Indicators {
+    double ef, es, sig, macd, mx, mn, prev;
+    double bb[20];
+    Pairwise pg, pl, pm;
+
+    template <int K>
+    __device__ __forceinline__ void close(double x) {
+        constexpr double mf = 2.0 / (12 + 1), ms = 2.0 / (26 + 1), mg = 2.0 / (9 + 1);
+        if constexpr (K == 0) { ef = es = x; mx = mn = x; }
+        else {
+            ef = (x * mf) + (ef * (1.0 - mf));                     // _ema :113-117
+            es = (x * ms) + (es * (1.0 - ms));
+            mx = x > mx ? x : mx;
+            mn = x < mn ? x : mn;
+        }
+        if constexpr (K >= 25) {                                    // macd_values for prefixes 26..50, :94-100
+            macd = ef - es;
+            sig = K == 25 ? macd : (macd * mg) + (sig * (1.0 - mg));
+        }
+        if constexpr (K >= 36) {                                    // last 14 deltas, :50-55
+            const double d = x - prev;
+            pg.add<K - 36, 14>(d > 0.0 ? d : 0.0);
+            pl.add<K - 36, 14>(d < 0.0 ? -d : 0.0);
+        }
+        if constexpr (K >= 30) {                                    // Bollinger window, :64-76
+            bb[K - 30] = x;
+            pm.add<K - 30, 20>(x);
+        }
+        prev = x;
+    }
+};
+
+constexpr int NFULL = HLEN / CH;            // 4 chunks of CH candles ...
+constexpr int CT = HLEN - NFULL * CH;       // ... and 2 candles that travel with the 11 scalar features
+static_assert(CH % 4 == 0 && CT * 5 + 11 == 21 && NFULL * CH * 5 + CT * 5 + 11 == OBS, "column bookkeeping of the observation row");
+
+template <int C, int NC>
+__device__ __forceinline__ void load_candles(const Params &p, int64_t li, int oldest, double (&cl)[CH], float4 (&oh)[CH]) {
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        int slot = oldest + C * CH + j;
+        slot -= slot >= HLEN ? HLEN : 0;
+        cl[j] = p.closes[(int64_t)slot * p.n + li];
+        oh[j] = p.ohlv[(int64_t)slot * p.n + li];
+    }
+}
+
+// candles K0+J.. of the chunk -> observation columns 5*(K0+J).. : the five ratios of a candle (:513-515, [O,H,L,C,V] / current close)
+template <int K0, int J, int NC, int NF>
+__device__ __forceinline__ void ratios(Indicators &ind, double inv, const double (&cl)[CH], const float4 (&oh)[CH], float (&out)[NF]) {
+    if constexpr (J < NC) {
+        const double x = cl[J];
+        out[5 * J + 0] = (float)((double)oh[J].x * inv);
+        out[5 * J + 1] = (float)((double)oh[J].y * inv);
+        out[5 * J + 2] = (float)((double)oh[J].z * inv);
+        out[5 * J + 3] = (float)(x * inv);
+        out[5 * J + 4] = (float)((double)oh[J].w * inv);
+        ind.template close<K0 + J>(x);
+        ratios<K0, J + 1, NC, NF>(ind, inv, cl, oh, out);
+    }
+}
+
+// NF consecutive float32 values of THIS lane's row -> dst[col0 ..): 16-byte stores straight from registers (+ single dwords for
+// the remainder).  Rows are 1044 B apart, so one store instruction touches 64 different lines — but consecutive instructions walk
+// each row front to back, every 128-byte line is completed by 8 back-to-back stores of the same lane, and the L2 hands whole lines
+// to HBM.  No LDS staging, no transposition, no index arithmetic.
+template <int NF>
+__device__ __forceinline__ void store_own_row(float *row, int col0, const float (&v)[NF], bool mine) {
+    if (!mine) return;
+#pragma unroll
+    for (int q = 0; q + 4 <= NF; q += 4)
+        *reinterpret_cast<Piece16 *>(row + col0 + q) = Piece16{__float_as_uint(v[q]), __float_as_uint(v[q + 1]), __float_as_uint(v[q + 2]), __float_as_uint(v[q + 3])};
+#pragma unroll
+    for (int q = NF - NF % 4; q < NF; ++q) row[col0 + q] = v[q];
+}
+
 // _get_observation :505-561 for the wave's 64 envs.  `oldest` = slot of logical candle 0.  Rows of
 // lanes whose bit is set in `rowmask` are written to dst (+ row*261 floats).
 __device__ __forceinline__ void observe(const Env &e, const Params &p, int64_t i0, int64_t i, bool live, int oldest,
                                         float *__restrict__ dst, unsigned long long rowmask, uint32_t *__restrict__ tile) {
+    (void)tile;
     const uint32_t lane = threadIdx.x & 63u;
-    const int64_t nrows = p.n - i0 < 64 ? p.n - i0 : 64;
     const int64_t li = live ? i : i0;            // dead lanes of a partial last wave read a valid column, write nothing
+    const bool mine = live && ((rowmask >> lane) & 1ull);
+    float *row = dst + (int64_t)lane * OBS;
     const double cur = e.close;
     const double inv = 1.0 / cur;
-    const double mf = 2.0 / (12 + 1), ms = 2.0 / (26 + 1), mg = 2.0 / (9 + 1);
-    double ef = 0, es = 0, sig = 0, macd = 0, mx = 0, mn = 0, prev = 0;
-    double bb[20];
-    Pairwise pg, pl, pm;
-    pg.res = pl.res = pm.res = 0.0;
-#pragma unroll
-    for (int c = 0; c < HLEN / CH; ++c) {
-        double cl[CH];
-        float4 oh[CH];
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            int slot = oldest + c * CH + j;
-            slot -= slot >= HLEN ? HLEN : 0;
-            cl[j] = p.closes[(int64_t)slot * p.n + li];
-            oh[j] = p.ohlv[(int64_t)slot * p.n + li];
-        }
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            const int k = c * CH + j;
-            const double x = cl[j];
-            float *row = reinterpret_cast<float *>(tile) + lane * ROW + j * 5;   // :513-515, [O,H,L,C,V] / current close
-            row[0] = (float)((double)oh[j].x * inv);
-            row[1] = (float)((double)oh[j].y * inv);
-            row[2] = (float)((double)oh[j].z * inv);
-            row[3] = (float)(x * inv);
-            row[4] = (float)((double)oh[j].w * inv);
-            if (k == 0) { ef = es = x; mx = mn = x; }
-            else {
-                ef = (x * mf) + (ef * (1.0 - mf));                 // _ema :113-117
-                es = (x * ms) + (es * (1.0 - ms));
-                mx = x > mx ? x : mx;
-                mn = x < mn ? x : mn;
-            }
-            if (k >= 25) {                                          // macd_values for prefixes 26..50, :94-100
-                macd = ef - es;
-                sig = k == 25 ? macd : (macd * mg) + (sig * (1.0 - mg));
-            }
-            if (k >= 36) {                                          // last 14 deltas, :50-55
-                const double d = x - prev;
-                const double gain = d > 0.0 ? d : 0.0, loss = d < 0.0 ? -d : 0.0;
-                switch (k) {
-#define CGE_CASE(K) case K: pg.add<K - 36, 14>(gain); pl.add<K - 36, 14>(loss); break;
-                    CGE_CASE(36) CGE_CASE(37) CGE_CASE(38) CGE_CASE(39) CGE_CASE(40) CGE_CASE(41) CGE_CASE(42)
-                    CGE_CASE(43) CGE_CASE(44) CGE_CASE(45) CGE_CASE(46) CGE_CASE(47) CGE_CASE(48) CGE_CASE(49)
-#undef CGE_CASE
-                }
-            }
-            if (k >= 30) {
-                bb[k >= 30 ? k - 30 : 0] = x;
-                switch (k) {
-#define CGE_CASE(K) case K: pm.add<K - 30, 20>(x); break;
-                    CGE_CASE(30) CGE_CASE(31) CGE_CASE(32) CGE_CASE(33) CGE_CASE(34) CGE_CASE(35) CGE_CASE(36) CGE_CASE(37)
-                    CGE_CASE(38) CGE_CASE(39) CGE_CASE(40) CGE_CASE(41) CGE_CASE(42) CGE_CASE(43) CGE_CASE(44) CGE_CASE(45)
-                    CGE_CASE(46) CGE_CASE(47) CGE_CASE(48) CGE_CASE(49)
-#undef CGE_CASE
-                }
-            }
-            prev = x;
-        }
-        // stream the chunk: element idx = m*64 + lane of the [64 rows][50 cols] tile -> row idx/50, col idx%50
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        {
-            uint32_t row = lane >= 50u ? 1u : 0u, col = lane >= 50u ? lane - 50u : lane;
-#pragma unroll 5
-            for (int m = 0; m < CH * 5; ++m) {
-                if ((int64_t)row < nrows && ((rowmask >> row) & 1ull))
-                    reinterpret_cast<uint32_t *>(dst)[(int64_t)row * OBS + c * (CH * 5) + col] = tile[row * ROW + col];
-                col += 14u; row += 1u;
-                if (col >= 50u) { col -= 50u; row += 1u; }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    Indicators ind;
+    ind.ef = ind.es = ind.sig = ind.macd = ind.mx = ind.mn = ind.prev = 0.0;
+    ind.pg.res = ind.pl.res = ind.pm.res = 0.0;
+    double cl[CH];
+    float4 oh[CH];
+    load_candles<0, CH>(p, li, oldest, cl, oh);
+    static_assert(NFULL == 4, "the chunk sequence below is written out for 4 full chunks + tail");
+#define CGE_CHUNK(C, NEXT_NC)                                                                           \
+    {                                                                                                   \
+        float out[CH * 5];                                                                              \
+        ratios<C * CH, 0, CH, CH * 5>(ind, inv, cl, oh, out);                                           \
+        load_candles<C + 1, NEXT_NC>(p, li, oldest, cl, oh);          /* next chunk's loads, then */    \
+        store_own_row<CH * 5>(row, C * CH * 5, out, mine);            /* this chunk's 15 stores   */    \
     }
-    // ---- the 11 scalar features, staged [64][11]
-    float tail[11];
+    CGE_CHUNK(0, CH) CGE_CHUNK(1, CH) CGE_CHUNK(2, CH) CGE_CHUNK(3, CT)
+#undef CGE_CHUNK
+    // ---- the last CT candles and the 11 scalar features: columns 240..260
+    float tail[CT * 5 + 11];
+    ratios<NFULL * CH, 0, CT, CT * 5 + 11>(ind, inv, cl, oh, tail);
+    float *ft = tail + CT * 5;
     const double pv = e.cash + e.holdings * cur;
-    tail[0] = e.cash_kind == 1 ? (float)e.cash / (float)p.cfg.initial_balance : (float)(e.cash / p.cfg.initial_balance);   // :524
-    tail[1] = (float)(e.holdings * cur / p.cfg.initial_balance);
-    tail[2] = (float)(pv / p.cfg.initial_balance);
+    ft[0] = e.cash_kind == 1 ? (float)e.cash / (float)p.cfg.initial_balance : (float)(e.cash / p.cfg.initial_balance);   // :524
+    ft[1] = (float)(e.holdings * cur / p.cfg.initial_balance);
+    ft[2] = (float)(pv / p.cfg.initial_balance);
     {
-        const double ag = pg.res / 14, al = pl.res / 14;
+        const double ag = ind.pg.res / 14, al = ind.pl.res / 14;
         double rsi;
         if (al == 0.0) rsi = 100.0;
         else { const double rs = ag / al; rsi = 100.0 - (100.0 / (1.0 + rs)); }
-        tail[3] = (float)(rsi / 100.0);
+        ft[3] = (float)(rsi / 100.0);
     }
     {
-        const double hist = macd - sig, range = mx - mn;
+        const double hist = ind.macd - ind.sig, range = ind.mx - ind.mn;
         const bool ok = range > 0.0;
-        tail[4] = ok ? (float)(macd / range) : 0.0f;
-        tail[5] = ok ? (float)(sig / range) : 0.0f;
-        tail[6] = ok ? (float)(hist / range) : 0.0f;
+        ft[4] = ok ? (float)(ind.macd / range) : 0.0f;
+        ft[5] = ok ? (float)(ind.sig / range) : 0.0f;
+        ft[6] = ok ? (float)(hist / range) : 0.0f;
     }
     {
-        const double sma = pm.res / 20;
+        const double sma = ind.pm.res / 20;
         Pairwise pd;
         pd.res = 0.0;
-#define CGE_DEV(P) { const double x = bb[P] - sma; pd.add<P, 20>(x * x); }
+#define CGE_DEV(P) { const double x = ind.bb[P] - sma; pd.add<P, 20>(x * x); }
         CGE_DEV(0) CGE_DEV(1) CGE_DEV(2) CGE_DEV(3) CGE_DEV(4) CGE_DEV(5) CGE_DEV(6) CGE_DEV(7) CGE_DEV(8) CGE_DEV(9)
         CGE_DEV(10) CGE_DEV(11) CGE_DEV(12) CGE_DEV(13) CGE_DEV(14) CGE_DEV(15) CGE_DEV(16) CGE_DEV(17) CGE_DEV(18) CGE_DEV(19)
 #undef CGE_DEV
         const double sd = sqrt(pd.res / 20);
         const double upper = sma + (2.0 * sd), lower = sma - (2.0 * sd);
-        tail[7] = (float)(upper > lower ? (cur - lower) / (upper - lower) : 0.5);
-        tail[8] = (float)(sma > 0.0 ? (upper - lower) / sma : 0.0);
-        tail[9] = (float)(sma > 0.0 ? (cur - sma) / sma : 0.0);
+        ft[7] = (float)(upper > lower ? (cur - lower) / (upper - lower) : 0.5);
+        ft[8] = (float)(sma > 0.0 ? (upper - lower) / sma : 0.0);
+        ft[9] = (float)(sma > 0.0 ? (cur - sma) / sma : 0.0);
     }
-    tail[10] = (float)e.psych;
-#pragma unroll
-    for (int j = 0; j < 11; ++j) reinterpret_cast<float *>(tile)[lane * 11 + j] = tail[j];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    {
-        uint32_t row = lane / 11u, col = lane - row * 11u;       // 64 = 5*11 + 9
-#pragma unroll
-        for (int m = 0; m < 11; ++m) {
-            if ((int64_t)row < nrows && ((rowmask >> row) & 1ull))
-                reinterpret_cast<uint32_t *>(dst)[(int64_t)row * OBS + 250 + col] = tile[row * 11 + col];
-            col += 9u; row += 5u;
-            if (col >= 11u) { col -= 11u; row += 1u; }
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    ft[10] = (float)e.psych;
+    store_own_row<CT * 5 + 11>(row, NFULL * CH * 5, tail, mine);
 }
 
 __device__ __forceinline__ void hash_cont(uint64_t key, uint64_t t, float &b, float &s) {
