@@ -49,7 +49,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 
 # record once per launch (2 x resident / kc); it reads no actions (device-side hash).
 ENVS = {
     "snake":   dict(algo=145,  obs=100, state=48, resident=48, stream=0, n_act=4, act_shape=(),   dtype="i8",
-                    step_kernel="cge::snake::step_kernel<10, 256, 1, 1>", roll_kernel="cge::snake::rollout_kernel<10, 256, 1, 1, true>",
+                    step_kernel="cge::snake::step_kernel<10, 256, 1, 1>", roll_kernel="cge::snake::rollout_kernel<10, 256, 1, 1, true, false>",
                     ref_py="3.4e5-4.2e5 steps/s/process"),
     "crypto":  dict(algo=2346, obs=1044, state=64, resident=64, stream=1164, n_act=5, act_shape=(),   dtype="f64",
                     step_kernel="cge::crypto::step_kernel<false>", roll_kernel="cge::crypto::step_kernel<true>", ref_py="1.64e3-1.68e3 steps/s/process"),

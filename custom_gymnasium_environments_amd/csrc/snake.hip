@@ -689,7 +689,7 @@ __device__ __forceinline__ void store_wave_rows(const uint32_t *rows, int8_t *ds
 // STORES.  The per-launch digit queue (QLay) removed every global load from the step loop, and with it the reason for the
 // writer: measured on 1M envs with every step's obs written to a [K, N, 100] trajectory, writer-wave kernel 28.5-38 us per
 // step (74 % of wave time parked at the barriers), this kernel see DESIGN.md section 6.
-template <int G, int BLOCK, int MINW, int MODE, bool USE_Q>
+template <int G, int BLOCK, int MINW, int MODE, bool USE_Q, bool ACTIONS>
 __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
     using L = Lay<G>;
     using Q = QLay<G>;
@@ -717,8 +717,12 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t *wave_rows = tile + (threadIdx.x & ~63u) * L::OBS_DW;
     if (row && live_lane) { e.write_obs_body(row); e.write_obs_food(row); }
-    // explicit actions are fetched one step ahead so the load's latency hides behind the previous step
-    uint32_t a_next = (live_lane && p.actions && p.k_steps > 0) ? (uint32_t)p.actions[i] : 0u;
+    // ACTIONS (compile time): explicit [k, n] actions, fetched one step ahead so the load's latency hides behind the previous step.
+    // The hash-action instance has NO global load anywhere in its step loop — on purpose: gfx950 counts loads and stores in one
+    // in-order counter, and a load that is merely POSSIBLE on some path makes the compiler put `s_waitcnt vmcnt(0)` at the join,
+    // which also drains the wave's observation stores.  With `p.actions` tested at run time that wait sat in every step of the
+    // hash path (round 2, found in the ISA): the wave waited for its previous tile to reach HBM before every transition.
+    uint32_t a_next = (ACTIONS && live_lane && p.k_steps > 0) ? (uint32_t)p.actions[i] : 0u;
     uint32_t *blk = p.mt + (live_lane ? i : wfirst) * MT_STRIDE;
     // generator words for the whole launch, drawn before the first observation store is in flight (see QLay)
     uint32_t *wave_q = qmem + (threadIdx.x & ~63u) * Q::QROW;
@@ -736,7 +740,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
         const bool short_wave = __ballot(e.len > 15u) == 0ull;  // every history of this wave fits one word (see Env::move)
         if (live_lane) {
             uint32_t a;
-            if (p.actions) {
+            if constexpr (ACTIONS) {
                 a = a_next;
                 if (t + 1 < p.k_steps) a_next = (uint32_t)p.actions[(int64_t)(t + 1) * p.n + i];
             } else {
@@ -956,8 +960,13 @@ template <int G, int BLOCK, int MINW, int MODE>
 void launch_mode(const Params &p, bool rollout, hipStream_t s) {
     const dim3 grid((unsigned)((p.n + BLOCK - 1) / BLOCK)), block(BLOCK);
     if (!rollout) hipLaunchKernelGGL((step_kernel<G, BLOCK, MINW, MODE>), grid, block, 0, s, p);
-    else if (p.k_steps >= QLay<G>::MIN_STEPS) hipLaunchKernelGGL((rollout_kernel<G, BLOCK, MINW, MODE, true>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((rollout_kernel<G, BLOCK, MINW, MODE, false>), grid, block, 0, s, p);
+    else if (p.k_steps >= QLay<G>::MIN_STEPS) {
+        if (p.actions) hipLaunchKernelGGL((rollout_kernel<G, BLOCK, MINW, MODE, true, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((rollout_kernel<G, BLOCK, MINW, MODE, true, false>), grid, block, 0, s, p);
+    } else {
+        if (p.actions) hipLaunchKernelGGL((rollout_kernel<G, BLOCK, MINW, MODE, false, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((rollout_kernel<G, BLOCK, MINW, MODE, false, false>), grid, block, 0, s, p);
+    }
 }
 template <int G, int BLOCK, int MINW>
 void launch_any(const Params &p, bool rollout, hipStream_t s) {
