@@ -519,33 +519,24 @@ __device__ __forceinline__ void store_tile(const uint32_t *tile, int8_t *dst, ui
 }
 
 
-// ------------------------------------------------------------------ row chunks -> HBM in 16-byte pieces
-// float32 observations wider than a few dozen values are assembled by COLUMN chunks: each lane stages W consecutive values of
-// its own env's row in LDS (row stride LSTRIDE dwords, odd: conflict-free), then the wave streams the [rows][W] chunk into the
-// row-major (N, OBS) output.  A piece is 4 consecutive values of one row; consecutive lanes take consecutive pieces of a row and
-// then of the next row, so one store instruction covers 64/(W/4) row segments of W*4 contiguous bytes each.  Rows are only
-// 4-byte aligned (OBS is odd for crypto): gfx950 runs with unaligned access enabled, the compiler emits global_store_dwordx4
-// for these 4-byte-aligned 16-byte stores (checked on the ISA and on the device).  Round 1 stored the chunks dword by dword:
-// 261 store instructions and ~3,000 VALU of index arithmetic per wave and step for crypto, against 66 / ~600 this way.
+// ------------------------------------------------------------------ a lane's own obs row -> HBM in 16-byte stores
+// NF consecutive float32 values of THIS lane's row -> row[col0 ..): 16-byte stores straight from registers (+ single dwords for a
+// remainder).  Rows of the float envs are hundreds of bytes apart and only 4-byte aligned (gfx950 runs with unaligned access
+// enabled: the compiler emits global_store_dwordx4 for these 4-byte-aligned 16-byte stores — checked on the ISA and on the
+// device), so one store instruction touches 64 different lines; but consecutive instructions walk each row front to back, every
+// 128-byte line is completed by 8 back-to-back stores of one lane, and the L2 hands whole lines to HBM.  No LDS staging, no
+// transposition, no index arithmetic.  (Round 1 staged column chunks in LDS and wrote them dword by dword: for crypto 261 store
+// instructions and ~3,000 VALU of index arithmetic per wave and step.)
 struct __attribute__((packed, aligned(4))) Piece16 { uint32_t a, b, c, d; };
 
-template <int W, int LSTRIDE, int OBS>
-__device__ __forceinline__ void store_row_chunk(const uint32_t *tile, float *dst, int col0, int64_t nrows, unsigned long long rowmask) {
-    static_assert(W % 4 == 0, "a chunk is a whole number of 16-byte pieces");
-    constexpr uint32_t P = W / 4;                              // pieces per row
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t row = lane / P, piece = lane - row * P;
+template <int NF>
+__device__ __forceinline__ void store_own_row(float *row, int col0, const float (&v)[NF], bool mine) {
+    if (!mine) return;
 #pragma unroll
-    for (uint32_t m = 0; m < P; ++m) {                         // 64 rows x P pieces = P passes of 64 lanes
-        if ((int64_t)row < nrows && ((rowmask >> row) & 1ull)) {
-            const uint32_t *src = tile + row * LSTRIDE + piece * 4u;
-            Piece16 v{src[0], src[1], src[2], src[3]};
-            *reinterpret_cast<Piece16 *>(dst + (int64_t)row * OBS + col0 + piece * 4u) = v;
-        }
-        piece += 64u % P;
-        row += 64u / P;
-        if (piece >= P) { piece -= P; row += 1u; }
-    }
+    for (int q = 0; q + 4 <= NF; q += 4)
+        *reinterpret_cast<Piece16 *>(row + col0 + q) = Piece16{__float_as_uint(v[q]), __float_as_uint(v[q + 1]), __float_as_uint(v[q + 2]), __float_as_uint(v[q + 3])};
+#pragma unroll
+    for (int q = NF - NF % 4; q < NF; ++q) row[col0 + q] = v[q];
 }
 
 }  // namespace cge

@@ -419,20 +419,6 @@ __device__ __forceinline__ void ratios(Indicators &ind, double inv, const double
     }
 }
 
-// NF consecutive float32 values of THIS lane's row -> dst[col0 ..): 16-byte stores straight from registers (+ single dwords for
-// the remainder).  Rows are 1044 B apart, so one store instruction touches 64 different lines — but consecutive instructions walk
-// each row front to back, every 128-byte line is completed by 8 back-to-back stores of the same lane, and the L2 hands whole lines
-// to HBM.  No LDS staging, no transposition, no index arithmetic.
-template <int NF>
-__device__ __forceinline__ void store_own_row(float *row, int col0, const float (&v)[NF], bool mine) {
-    if (!mine) return;
-#pragma unroll
-    for (int q = 0; q + 4 <= NF; q += 4)
-        *reinterpret_cast<Piece16 *>(row + col0 + q) = Piece16{__float_as_uint(v[q]), __float_as_uint(v[q + 1]), __float_as_uint(v[q + 2]), __float_as_uint(v[q + 3])};
-#pragma unroll
-    for (int q = NF - NF % 4; q < NF; ++q) row[col0 + q] = v[q];
-}
-
 // _get_observation :505-561 for the wave's 64 envs.  `oldest` = slot of logical candle 0.  Rows of
 // lanes whose bit is set in `rowmask` are written to dst (+ row*261 floats).
 __device__ __forceinline__ void observe(const Env &e, const Params &p, int64_t i0, int64_t i, bool live, int oldest,

@@ -332,21 +332,39 @@ __device__ __forceinline__ void update_queue(Misc &m, const Ring &rg, Draws &D, 
 // ------------------------------------------------------------------ obs tile -> HBM
 // Rows of `ncols` dwords (LDS stride TILE) go to columns [col0, col0 + ncols) of the (N, 243) output; rows selected by mask.
 // Columns 45..50 (nurse counts) are skipped: they are written directly once the nurse group has been processed.
-__device__ __forceinline__ void flush_rows(const uint32_t *tile, int ncols, int col0, int64_t nrows, float *__restrict__ dst, unsigned long long rowmask) {
+// columns [C0, C1) of this lane's row: LDS -> registers -> 16-byte stores, 16 values at a time (a bounded register footprint)
+template <int C0, int C1, int COL0>
+__device__ __forceinline__ void copy_segment(const float *trow, float *drow, bool mine) {
+    if constexpr (C1 - C0 >= 16) {
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = trow[C0 - COL0 + j];
+        store_own_row<16>(drow, C0, v, mine);
+        copy_segment<C0 + 16, C1, COL0>(trow, drow, mine);
+    } else if constexpr (C1 > C0) {
+        float v[C1 - C0];
+#pragma unroll
+        for (int j = 0; j < C1 - C0; ++j) v[j] = trow[C0 - COL0 + j];
+        store_own_row<C1 - C0>(drow, C0, v, mine);
+    }
+}
+
+// The staged chunk [64 rows][NC columns] (LDS, row stride TILE) -> columns [COL0, COL0+NC) of the (N, 243) output: every lane
+// streams its OWN row in 16-byte stores (cge_device.hpp: store_own_row); columns 45..50 (nurse counts) are written directly by
+// wave_step and skipped here.  Round 1 walked the 64 rows one after the other with 2-3 masked dword stores each (~320 store
+// instructions per wave-step for the two chunks); this is 58 sixteen-byte stores and 7 dwords.
+template <int NC, int COL0>
+__device__ __forceinline__ void flush_rows(const uint32_t *tile, int64_t nrows, float *__restrict__ dst, unsigned long long rowmask) {
     const uint32_t lane = threadIdx.x & 63u;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // one row at a time (wave-uniform: rows outside the mask cost a scalar branch), each lane 1-3 columns of it
-#pragma unroll 1
-    for (int r = 0; r < (int)nrows; ++r) {
-        if (!((rowmask >> r) & 1ull)) continue;
-        uint32_t *drow = reinterpret_cast<uint32_t *>(dst) + (int64_t)r * OBS + col0;
-        const uint32_t *trow = tile + r * TILE;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const uint32_t c = lane + 64u * q, gc = (uint32_t)col0 + c;
-            if (c < (uint32_t)ncols && !(gc >= 45u && gc <= 50u)) drow[c] = trow[c];
-        }
-    }
+    const bool mine = (int64_t)lane < nrows && ((rowmask >> lane) & 1ull);
+    const float *trow = reinterpret_cast<const float *>(tile) + lane * TILE;
+    float *drow = dst + (int64_t)lane * OBS;
+    // segments of consecutive columns that this chunk owns: [COL0, COL0+NC) minus [45, 51)
+    constexpr int A0 = COL0, A1 = (COL0 < 45 && COL0 + NC > 45) ? 45 : COL0 + NC;          // first segment [A0, A1)
+    constexpr int B0 = (COL0 < 45 && COL0 + NC > 51) ? 51 : COL0 + NC, B1 = COL0 + NC;    // second segment [B0, B1), empty for chunk B
+    copy_segment<A0, A1, COL0>(trow, drow, mine);
+    if constexpr (B1 > B0) copy_segment<B0, B1, COL0>(trow, drow, mine);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
@@ -392,7 +410,7 @@ __device__ __forceinline__ void do_reset(const Params &p, int64_t i, bool mine, 
 #pragma unroll
         for (int k = 0; k < NDOC; ++k) docfat[k] = (float)(dc.fat[k] / 100.0);
     }
-    if (dst) flush_rows(tile, NA, 0, nrows, dst, rowmask);
+    if (dst) flush_rows<NA, 0>(tile, nrows, dst, rowmask);
     if (mine) {
 #pragma unroll
         for (int k = 0; k < NDOC; ++k) row[198 - NA + k] = docfat[k];
@@ -446,7 +464,7 @@ __device__ __forceinline__ void do_reset(const Params &p, int64_t i, bool mine, 
             for (int d = 0; d < 6; ++d) orow[45 + d] = (float)((double)(d == 5 ? 5 : 4) / 10.0);
         }
     }
-    if (dst) flush_rows(tile, NB, NA, nrows, dst, rowmask);
+    if (dst) flush_rows<NB, NA>(tile, nrows, dst, rowmask);
     (void)i0;
 }
 
@@ -584,8 +602,8 @@ __device__ __forceinline__ void wave_step(const Params &p, int64_t i, int64_t i0
     // obs chunk A -> the row's destination (terminal rows of SAME_STEP go to final_obs)
     const bool to_final = done && p.mode == CGE_AUTORESET_SAME_STEP;
     const unsigned long long m_final = __ballot(run && to_final), m_obs = __ballot(run && !to_final);
-    if (obs_dst) flush_rows(tile, NA, 0, nrows, obs_dst, m_obs);
-    if (p.final_obs && m_final) flush_rows(tile, NA, 0, nrows, p.final_obs + i0 * OBS, m_final);
+    if (obs_dst) flush_rows<NA, 0>(tile, nrows, obs_dst, m_obs);
+    if (p.final_obs && m_final) flush_rows<NA, 0>(tile, nrows, p.final_obs + i0 * OBS, m_final);
     float *my_dst = to_final ? (p.final_obs ? p.final_obs + i * OBS : nullptr) : (obs_dst ? obs_dst + (int64_t)lane * OBS : nullptr);
     if (run) {
         const uint32_t now = m.time;
@@ -698,8 +716,8 @@ __device__ __forceinline__ void wave_step(const Params &p, int64_t i, int64_t i0
             if (p.mode == CGE_AUTORESET_NEXT_STEP) m.needs_reset = 1;
         }
     }
-    if (obs_dst) flush_rows(tile, NB, NA, nrows, obs_dst, m_obs);
-    if (p.final_obs && m_final) flush_rows(tile, NB, NA, nrows, p.final_obs + i0 * OBS, m_final);
+    if (obs_dst) flush_rows<NB, NA>(tile, nrows, obs_dst, m_obs);
+    if (p.final_obs && m_final) flush_rows<NB, NA>(tile, nrows, p.final_obs + i0 * OBS, m_final);
     // ---- episode reset: SAME_STEP rows that just finished, NEXT_STEP rows that finished on the previous call
     const bool reset_now = reset_only || (run && to_final);
     const unsigned long long m_reset = __ballot(reset_now);
@@ -776,7 +794,7 @@ __device__ __forceinline__ void observe_current(const Params &p, int64_t i, bool
         util_f[0] = (float)((double)occ[0] / 8.0); util_f[1] = (float)((double)occ[1] / 6.0); util_f[2] = (float)((double)occ[2] / 4.0);
         util_f[3] = (float)((double)occ[3] / 22.0); util_f[4] = 0.0f; util_f[5] = 0.0f;
     }
-    flush_rows(tile, NA, 0, nrows, dst, rowmask);
+    flush_rows<NA, 0>(tile, nrows, dst, rowmask);
     if (mine) {
         uint32_t r[52];
         load_cols<13>(p.state, p.n, i, C_NUR, r);
@@ -823,7 +841,7 @@ __device__ __forceinline__ void observe_current(const Params &p, int64_t i, bool
         row[241 - NA] = m.outbreak ? 1.0f : 0.0f;
         row[242 - NA] = m.mass ? 1.0f : 0.0f;
     }
-    flush_rows(tile, NB, NA, nrows, dst, rowmask);
+    flush_rows<NB, NA>(tile, nrows, dst, rowmask);
 }
 
 // what: 0 = reset(mask) + obs, 1 = rewind the generator cursor after seeding, 2 = fresh-handle state

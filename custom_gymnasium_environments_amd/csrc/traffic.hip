@@ -256,11 +256,21 @@ __device__ __forceinline__ float obs_val(const Env &e, const ObsTotals &t) {
 }
 
 template <int BASE, int... Js>
+__device__ __forceinline__ void fill_chunk(const Env &e, const ObsTotals &t, float (&out)[sizeof...(Js)], std::integer_sequence<int, Js...>) {
+    ((out[Js] = obs_val<BASE + Js>(e, t)), ...);
+}
+
+template <int BASE, int... Js>
 __device__ __forceinline__ void stage_chunk(const Env &e, const ObsTotals &t, float *row, std::integer_sequence<int, Js...>) {
     ((row[Js] = obs_val<BASE + Js>(e, t)), ...);
 }
 
-// writes the wave's 64 obs rows (rows with their bit in rowmask) to dst (+ row*130 floats)
+// writes the wave's 64 obs rows (rows with their bit in rowmask) to dst (+ row*130 floats).
+// OWN (the fused rollout): every lane streams its own row in 16-byte stores straight from registers (cge_device.hpp:
+// store_own_row), 32 values at a time + the last two — 96 -> 77 us per 262,144-env rollout step (A/B on one box, round 2).
+// !OWN (step()): five 26-value chunks staged in LDS (row stride 27) and written with coalesced dword stores; the own-row form
+// was 5 % slower there (99 vs 95 us), where all waves of the launch reach their stores together.
+template <bool OWN>
 __device__ __forceinline__ void observe(const Env &e, int64_t nrows, float *__restrict__ dst, unsigned long long rowmask,
                                         uint32_t *__restrict__ tile) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -269,22 +279,39 @@ __device__ __forceinline__ void observe(const Env &e, int64_t nrows, float *__re
     for (int i = 0; i < NI; ++i) { t.tp += e.passed[i]; t.tw += e.tw[i]; }
 #pragma unroll
     for (int k = 0; k < NQ; ++k) t.tq += e.q[k] & 63u;
-    float *row = reinterpret_cast<float *>(tile) + lane * ROW;
-#define CGE_CHUNK(C)                                                                                   \
-    stage_chunk<C * CW>(e, t, row, std::make_integer_sequence<int, CW>{});                             \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
-    {                                                                                                  \
-        uint32_t r = lane / (uint32_t)CW, col = lane - r * (uint32_t)CW;                               \
-        _Pragma("unroll 1") for (int m = 0; m < CW; ++m) {                                             \
-            if ((int64_t)r < nrows && ((rowmask >> r) & 1ull))                                         \
-                reinterpret_cast<uint32_t *>(dst)[(int64_t)r * OBS + C * CW + col] = tile[r * ROW + col]; \
-            col += 64u % CW; r += 64u / CW;                                                            \
-            if (col >= (uint32_t)CW) { col -= CW; r += 1u; }                                           \
-        }                                                                                              \
-    }                                                                                                  \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    CGE_CHUNK(0) CGE_CHUNK(1) CGE_CHUNK(2) CGE_CHUNK(3) CGE_CHUNK(4)
+    if constexpr (OWN) {
+        const bool mine = (int64_t)lane < nrows && ((rowmask >> lane) & 1ull);
+        float *row = dst + (int64_t)lane * OBS;
+        static_assert(OBS == 4 * 32 + 2, "the chunk sequence below covers 130 values");
+#define CGE_CHUNK(C)                                                                   \
+        {                                                                              \
+            float out[32];                                                             \
+            fill_chunk<C * 32>(e, t, out, std::make_integer_sequence<int, 32>{});      \
+            store_own_row<32>(row, C * 32, out, mine);                                 \
+        }
+        CGE_CHUNK(0) CGE_CHUNK(1) CGE_CHUNK(2) CGE_CHUNK(3)
 #undef CGE_CHUNK
+        float last[2];
+        fill_chunk<128>(e, t, last, std::make_integer_sequence<int, 2>{});
+        store_own_row<2>(row, 128, last, mine);
+    } else {
+        float *row = reinterpret_cast<float *>(tile) + lane * ROW;
+#define CGE_CHUNK(C)                                                                                   \
+        stage_chunk<C * CW>(e, t, row, std::make_integer_sequence<int, CW>{});                         \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
+        {                                                                                              \
+            uint32_t r = lane / (uint32_t)CW, col = lane - r * (uint32_t)CW;                           \
+            _Pragma("unroll 1") for (int m = 0; m < CW; ++m) {                                         \
+                if ((int64_t)r < nrows && ((rowmask >> r) & 1ull))                                     \
+                    reinterpret_cast<uint32_t *>(dst)[(int64_t)r * OBS + C * CW + col] = tile[r * ROW + col]; \
+                col += 64u % CW; r += 64u / CW;                                                        \
+                if (col >= (uint32_t)CW) { col -= CW; r += 1u; }                                       \
+            }                                                                                          \
+        }                                                                                              \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        CGE_CHUNK(0) CGE_CHUNK(1) CGE_CHUNK(2) CGE_CHUNK(3) CGE_CHUNK(4)
+#undef CGE_CHUNK
+    }
 }
 
 template <bool ROLLOUT>
@@ -334,9 +361,9 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
             }
         }
         const unsigned long long fin_mask = __ballot(live && term && reset_now);
-        if (fin_mask && p.final_obs) observe(e, nrows, p.final_obs + i0 * OBS, fin_mask, tile);   // terminal obs (SAME_STEP)
+        if (fin_mask && p.final_obs) observe<ROLLOUT>(e, nrows, p.final_obs + i0 * OBS, fin_mask, tile);   // terminal obs (SAME_STEP)
         if (reset_now) e.reset();
-        if (p.obs) observe(e, nrows, p.obs + (int64_t)t * p.obs_step_stride + i0 * OBS, ~0ull, tile);
+        if (p.obs) observe<ROLLOUT>(e, nrows, p.obs + (int64_t)t * p.obs_step_stride + i0 * OBS, ~0ull, tile);
         if (live) {
             if (ROLLOUT) {
                 rsum += reward;
@@ -373,7 +400,7 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(Params p) {
         e.reset();
         e.store(p.state, p.n, i);
     }
-    if (p.obs) observe(e, nrows, p.obs + i0 * OBS, ~0ull, tile);
+    if (p.obs) observe<false>(e, nrows, p.obs + i0 * OBS, ~0ull, tile);
 }
 
 __global__ __launch_bounds__(256) void rewind_kernel(uint4 *state, int64_t n) {
