@@ -310,6 +310,8 @@ struct LdsDrawsCall {
 // (fleet's dense reset kernel): one rolled-loop fill parks W <= 227 twisted words per lane (no word of such a
 // window depends on another), so a whole episode reset normally needs a single, wave-convergent fill per
 // stream.  Same (pos, pretw) cursor contract as LdsDraws; flush() commits only the consumed words.
+// An LDS row is 2W words: [0,W) the twisted state words (what flush() writes back), [W,2W) the same words
+// tempered at fill time, by all lanes in parallel — next() on the serial chain is then one LDS read.
 template <int W>
 struct LdsBulkDraws {
     static_assert(W <= MT_N - MT_M, "window words must be mutually independent");
@@ -328,7 +330,10 @@ struct LdsBulkDraws {
             MtWindow<CH> w;                                    // loads first, unconditionally: one round trip per chunk
             w.load(blk, pos + (uint32_t)c0);
 #pragma unroll
-            for (int j = 0; j < CH; ++j) row[c0 + j] = w.twisted(j, pos + (uint32_t)c0, pretw);
+            for (int j = 0; j < CH; ++j) {
+                const uint32_t y = w.twisted(j, pos + (uint32_t)c0, pretw);
+                row[c0 + j] = y; row[W + c0 + j] = mt_temper(y);
+            }
         }
         cur = 0;
         filled = true;
@@ -361,7 +366,7 @@ struct LdsBulkDraws {
             const uint2 r = refill(row, blk, pos, pretw, cur, filled);
             pos = r.x; pretw = r.y; cur = 0; filled = true;
         }
-        return mt_temper(row[cur++]);
+        return row[W + cur++];
     }
     __device__ __forceinline__ uint32_t randbelow(uint32_t n, int kbits) {
         uint32_t r = next() >> (32 - kbits);
@@ -420,7 +425,8 @@ __device__ __forceinline__ void coop_fill(LdsBulkDraws<W> &d, int row_stride, bo
             for (int q = 0; q < NQ; ++q) {
                 const uint32_t j = 64u * q + lane;
                 const uint32_t y = mt_twist(a[g][q], b[g][q], c[g][q]), m = 0u - (uint32_t)(pos + j < pretw);
-                if (on && j < (uint32_t)W) row[j] = (a[g][q] & m) | (y & ~m);
+                const uint32_t v = (a[g][q] & m) | (y & ~m);
+                if (on && j < (uint32_t)W) { row[j] = v; row[W + j] = mt_temper(v); }
             }
         }
     }

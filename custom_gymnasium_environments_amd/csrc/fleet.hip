@@ -30,9 +30,9 @@ constexpr int MAXD = 12;
 constexpr int COLS = 10;
 // dense kernel: DL lanes (envs) per wave, one bulk window per stream sized so a whole reset normally fits
 // (L: nd + <=12 x ~8 + 58 traffic words ~ 170; P: <=12 x ~4 ~ 48), odd LDS row strides
-constexpr int DL = 8;
+constexpr int DL = 8;                                          // 2 and 4 measured: same ~50 us chain per wave, the mass redraw step 1.5-2.4x slower
 constexpr int WL = 224, WP = 96;
-constexpr int LROW = WL + 1, PROW = WP + 1;
+constexpr int LROW = 2 * WL + 1, PROW = 2 * WP + 1;            // raw + tempered copy (LdsBulkDraws), odd stride
 using DrawsL = LdsBulkDraws<WL>;
 using DrawsP = LdsBulkDraws<WP>;
 constexpr int BLOCK = 64;
@@ -54,12 +54,20 @@ struct Params {
     double *ep_ret;       // episode statistics (cge_fleet_episode_stats), nullable
     int32_t *ep_len;
     int32_t t_index, accumulate;
-    uint32_t *work_count;      // [2] alternating counters of the deferred-work list
-    uint64_t *work_list;       // [n] entries: env index << 3 | W_* flags
+    uint32_t *work_count;      // [2][NSUB] alternating counters of the deferred-work sub-lists, one per 64-byte line
+    uint64_t *work_list;       // [NSUB][sub_cap] entries: env index << 3 | W_* flags
+    int64_t sub_cap;
     int32_t parity;
 };
 
 enum : uint32_t { W_TRAFFIC = 1u, W_WEATHER = 2u, W_RESET = 4u };
+
+// The work list is NSUB sub-lists, block b appends to sub-list b % NSUB.  One list with one counter had every wave that
+// lists anything (86 % of them at 3 % of the lanes) queue on the same L2 atomic unit: step_kernel went from 22 us to
+// 40 us per 131,072-env step once episodes began to end (profiles/r02_fleet_summary.txt, the kernel trace).
+constexpr int NSUB = 64;
+constexpr int CNT_STRIDE = 16;                                  // dwords between counters
+__device__ __forceinline__ uint32_t *work_counter(uint32_t *base, int parity, uint32_t sub) { return base + ((uint32_t)parity * NSUB + sub) * CNT_STRIDE; }
 
 __device__ __forceinline__ double vrange(int k) { return k == 0 ? 80.0 : k == 1 ? 120.0 : 60.0; }     // :128-132
 __device__ __forceinline__ double vcons(int k) { return k == 0 ? 1.0 : k == 1 ? 0.5 : 2.0; }
@@ -175,7 +183,9 @@ __device__ __forceinline__ uint32_t zone_cell(uint32_t zone, uint32_t k) {      
     return x | (y << 5);
 }
 
-__device__ __forceinline__ void do_reset(Env &e, int32_t max_steps, DrawsP &P, DrawsL &L) {   // :185-234
+// `ab`: 24 words of this lane's LDS scratch — the request words are parked there by index and read back once, instead of
+// 24 compare-and-select pairs per request to keep a runtime-indexed register array in VGPRs
+__device__ __forceinline__ void do_reset(Env &e, int32_t max_steps, DrawsP &P, DrawsL &L, uint32_t *__restrict__ ab) {   // :185-234
     e.timestep = 0; e.total_reward = 0.0; e.completed = 0; e.missed = 0; e.weather = 1; e.needs_reset = 0;   // weather index 1 = 1.0
 #pragma unroll
     for (int k = 0; k < 3; ++k) { e.veh[k] = 12u | (12u << 5); e.fuel[k] = vrange(k); }
@@ -203,9 +213,10 @@ __device__ __forceinline__ void do_reset(Env &e, int32_t max_steps, DrawsP &P, D
             A = pc | (dc << 10) | (urg << 20) | (req << 22);                               // not completed, unassigned
             B = t0 | (commercial << 8) | (deadline << 9);
         }
-#pragma unroll
-        for (int k = 0; k < MAXD; ++k) { e.dA[k] = i == (uint32_t)k ? A : e.dA[k]; e.dB[k] = i == (uint32_t)k ? B : e.dB[k]; }
+        ab[i] = A; ab[MAXD + i] = B;
     }
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k) { e.dA[k] = ab[k]; e.dB[k] = ab[MAXD + k]; }
     update_traffic(e, L);
 }
 
@@ -384,8 +395,9 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
         }
         e.store(p.state, p.n, i);
         if (work) {
-            const uint32_t slot = atomicAdd(&p.work_count[p.parity], 1u);
-            p.work_list[slot] = ((uint64_t)i << 3) | work;
+            const uint32_t sub = blockIdx.x % (uint32_t)NSUB;
+            const uint32_t slot = atomicAdd(work_counter(p.work_count, p.parity, sub), 1u);
+            p.work_list[(int64_t)sub * p.sub_cap + slot] = ((uint64_t)i << 3) | work;
         }
         if (p.accumulate) {
             if (p.reward_sum) p.reward_sum[i] += reward;
@@ -407,13 +419,34 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
 // Few waves run here (1-3 % of the envs), so the kernel is bound by one lane's serial chain, not by throughput:
 // both streams' windows are filled once, wave-convergently, before any draw is consumed.
 // what: 0 work list, 1 reset(mask)+obs, 2 rewind cursors after seeding, 3 initial state of a fresh handle
+#ifdef CGE_FLEET_TIMING
+__device__ unsigned long long g_timing[16];
+#define TICK(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = wall_clock64(); \
+    if (blockIdx.x < 64 && threadIdx.x == 0 && what == 0) { atomicAdd(&g_timing[k], now_ - t_last); } t_last = now_; } while (0)
+#else
+#define TICK(k)
+#endif
 __global__ __launch_bounds__(BLOCK) void dense_kernel(Params p, int what) {
+#ifdef CGE_FLEET_TIMING
+    unsigned long long t_last = wall_clock64();
+#endif
     __shared__ uint32_t tile[DL * ROW];
     __shared__ uint32_t drawsP[DL * PROW], drawsL[DL * LROW];
     __shared__ int64_t row_env[DL];
-    const uint32_t count = what == 0 ? p.work_count[p.parity] : (uint32_t)p.n;
-    if (what == 0 && blockIdx.x == 0 && threadIdx.x == 0) p.work_count[p.parity ^ 1] = 0;       // next step's counter
     const uint32_t lane = threadIdx.x & 63u;
+    // lane s holds sub-list s's entry count and the running total up to and including it
+    uint32_t sub_n = 0, sub_end = 0;
+    if (what == 0) {
+        sub_n = *work_counter(p.work_count, p.parity, lane);
+        if (blockIdx.x == 0) *work_counter(p.work_count, p.parity ^ 1, lane) = 0;                 // next step's counters
+        sub_end = sub_n;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)sub_end, d, 64);
+            if (lane >= (uint32_t)d) sub_end += up;
+        }
+    }
+    const uint32_t count = what == 0 ? lane_u32(sub_end, 63) : (uint32_t)p.n;
     const uint32_t slot = lane < (uint32_t)DL ? lane : 0u;
 #pragma unroll 1
     for (uint32_t first = blockIdx.x * DL; first < count; first += gridDim.x * DL) {
@@ -422,7 +455,13 @@ __global__ __launch_bounds__(BLOCK) void dense_kernel(Params p, int what) {
         int64_t i;
         uint32_t work;
         if (what == 0) {
-            const uint64_t entry = p.work_list[live ? tix : first];
+            const uint32_t g = live ? tix : first;             // entry g of the concatenated sub-lists -> (sub-list, offset)
+            uint32_t sub = 0;
+#pragma unroll
+            for (int b = NSUB / 2; b; b >>= 1)
+                if ((uint32_t)__shfl((int)sub_end, (int)(sub + b - 1), 64) <= g) sub += b;
+            const uint32_t before = (uint32_t)__shfl((int)(sub_end - sub_n), (int)sub, 64);
+            const uint64_t entry = p.work_list[(int64_t)sub * p.sub_cap + (g - before)];
             i = (int64_t)(entry >> 3);
             work = live ? (uint32_t)(entry & 7u) : 0u;
         } else {
@@ -431,18 +470,22 @@ __global__ __launch_bounds__(BLOCK) void dense_kernel(Params p, int what) {
         }
         Env e;
         e.load(p.state, p.n, i);
+        TICK(0);
         if (what == 2) { if (live) { e.ppos = e.lpos = 0; e.ppretw = e.lpretw = 0; e.store(p.state, p.n, i); } continue; }
         if (what == 3) { if (live) { e.weather = 1; e.store(p.state, p.n, i); } continue; }
         DrawsP P(drawsP + slot * PROW, p.mtP + i * MT_STRIDE, e.ppos, e.ppretw);
         DrawsL L(drawsL + slot * LROW, p.mtL + i * MT_STRIDE, e.lpos, e.lpretw);
-        coop_fill<WL, DL, 4>(L, LROW, work != 0);
-        coop_fill<WP, DL, 8>(P, PROW, (work & W_RESET) != 0);
+        coop_fill<WL, DL, (DL < 4 ? DL : 4)>(L, LROW, work != 0);
+        TICK(1);
+        coop_fill<WP, DL, (DL < 8 ? DL : 8)>(P, PROW, (work & W_RESET) != 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        TICK(2);
         if (work & W_TRAFFIC) update_traffic(e, L);                                                   // :257-258
         if (work & W_WEATHER) {                                                                       // _update_weather :524-528
             const double w0 = 0.3, w1 = w0 + 0.5, w2 = w1 + 0.15, w3 = w2 + 0.05;
             e.weather = np_choice_cdf(L, w0 / w3, w1 / w3, w2 / w3, w3 / w3);
         }
+        TICK(3);
         if (lane < (uint32_t)DL) row_env[lane] = live ? i : -1;
         const int nlive = (int)(count - first < (uint32_t)DL ? count - first : (uint32_t)DL);
         const bool fin = what == 0 && (work & W_RESET) && p.mode == CGE_AUTORESET_SAME_STEP && p.final_obs;
@@ -450,7 +493,9 @@ __global__ __launch_bounds__(BLOCK) void dense_kernel(Params p, int what) {
         for (int pass = 0; pass < 2; ++pass) {
             // pass 0: terminal obs (after the redraws) of the envs that finished -> final_obs; pass 1: reset, then obs
             const bool want = pass == 0 ? fin : (what == 1 ? live : work != 0);
-            if (pass == 1 && (work & W_RESET)) do_reset(e, p.max_steps, P, L);
+            if (pass == 1) TICK(4);
+            if (pass == 1 && (work & W_RESET)) do_reset(e, p.max_steps, P, L, tile + slot * ROW);
+            if (pass == 1) TICK(5);
             float *dst = pass == 0 ? p.final_obs : (p.obs ? p.obs + (int64_t)p.t_index * p.obs_step_stride : nullptr);
             const unsigned long long m = __ballot(want);
             if (!m || !dst) continue;
@@ -465,12 +510,18 @@ __global__ __launch_bounds__(BLOCK) void dense_kernel(Params p, int what) {
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
+        TICK(6);
         coop_flush<WP, DL>(P, PROW);
         coop_flush<WL, DL>(L, LROW);
+        TICK(7);
         if (work) {
             e.ppos = P.pos; e.ppretw = P.pretw; e.lpos = L.pos; e.lpretw = L.pretw;
             e.store(p.state, p.n, i);
         }
+        TICK(8);
+#ifdef CGE_FLEET_TIMING
+        if (blockIdx.x < 64 && threadIdx.x == 0 && what == 0) atomicAdd(&g_timing[15], 1ull);
+#endif
     }
 }
 
@@ -509,13 +560,15 @@ struct cge_fleet : HandleBase {
     uint64_t *work_list = nullptr;
     int parity = 0;
     static constexpr uint32_t snap_tag = 3u;
-    std::vector<std::pair<void *, size_t>> blobs() const { return {{state, (size_t)fleet::COLS * n * sizeof(uint4)}, {mtP, (size_t)n * MT_STRIDE * 4}, {mtL, (size_t)n * MT_STRIDE * 4}, {work_count, 2 * sizeof(uint32_t)}}; }
+    std::vector<std::pair<void *, size_t>> blobs() const { return {{state, (size_t)fleet::COLS * n * sizeof(uint4)}, {mtP, (size_t)n * MT_STRIDE * 4}, {mtL, (size_t)n * MT_STRIDE * 4}, {work_count, count_bytes()}}; }
+    static size_t count_bytes() { return (size_t)2 * fleet::NSUB * fleet::CNT_STRIDE * sizeof(uint32_t); }
+    int64_t sub_cap() const { return ((int64_t)blocks() + fleet::NSUB - 1) / fleet::NSUB * fleet::BLOCK; }
     uint32_t snap_extra() const { return (uint32_t)parity; }
     void set_snap_extra(uint32_t v) { parity = (int)(v & 1u); (void)v; }
     fleet::Params params() const {
         fleet::Params p{};
         p.state = state; p.mtP = mtP; p.mtL = mtL; p.n = n; p.env0 = env0; p.mode = cfg.autoreset_mode; p.max_steps = cfg.max_timesteps;
-        p.work_count = work_count; p.work_list = work_list; p.parity = parity;
+        p.work_count = work_count; p.work_list = work_list; p.sub_cap = sub_cap(); p.parity = parity;
         p.ep_ret = ep_ret; p.ep_len = ep_len;
         return p;
     }
@@ -541,6 +594,14 @@ struct cge_fleet : HandleBase {
 
 extern "C" {
 
+#ifdef CGE_FLEET_TIMING
+int cge_fleet_debug_timing(unsigned long long *out, int clear) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fleet::g_timing), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    if (clear) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(fleet::g_timing), z, sizeof z) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
+
 int cge_fleet_create(const cge_fleet_config *cfg, int64_t n_envs, int device, int64_t env_index0, cge_fleet **out) {
     if (!cfg || !out || n_envs <= 0 || env_index0 < 0) return CGE_ERR_INVALID_ARG;
     *out = nullptr;
@@ -555,8 +616,9 @@ int cge_fleet_create(const cge_fleet_config *cfg, int64_t n_envs, int device, in
     const size_t sb = (size_t)fleet::COLS * n_envs * sizeof(uint4), mb = (size_t)n_envs * MT_STRIDE * sizeof(uint32_t);
     hipError_t e;
     if ((e = hipMalloc(&h->state, sb)) != hipSuccess || (e = hipMalloc(&h->mtP, mb)) != hipSuccess || (e = hipMalloc(&h->mtL, mb)) != hipSuccess ||
-        (e = hipMalloc(&h->work_count, 2 * sizeof(uint32_t))) != hipSuccess || (e = hipMalloc(&h->work_list, (size_t)n_envs * sizeof(uint64_t))) != hipSuccess ||
-        (e = hipMemset(h->work_count, 0, 2 * sizeof(uint32_t))) != hipSuccess || (e = hipMemset(h->state, 0, sb)) != hipSuccess) {
+        (e = hipMalloc(&h->work_count, cge_fleet::count_bytes())) != hipSuccess ||
+        (e = hipMalloc(&h->work_list, (size_t)fleet::NSUB * h->sub_cap() * sizeof(uint64_t))) != hipSuccess ||
+        (e = hipMemset(h->work_count, 0, cge_fleet::count_bytes())) != hipSuccess || (e = hipMemset(h->state, 0, sb)) != hipSuccess) {
         h->free_all();
         delete h;
         return CGE_ERR_HIP;
