@@ -317,11 +317,14 @@ struct LdsBulkDraws {
     static_assert(W <= MT_N - MT_M, "window words must be mutually independent");
     uint32_t *row;
     uint32_t *blk;
-    uint32_t pos, pretw, cur;
+#ifdef CGE_FLEET_TIMING
+    uint32_t refills = 0;
+#endif
+    uint32_t pos, pretw, cur, avail;                           // avail: parked words (W, or fewer after a partial cooperative fill)
     bool filled;
 
     __device__ __forceinline__ LdsBulkDraws(uint32_t *lds_row, uint32_t *block, uint32_t pos_, uint32_t pretw_)
-        : row(lds_row), blk(block), pos(pos_), pretw(pretw_), cur(0), filled(false) {}
+        : row(lds_row), blk(block), pos(pos_), pretw(pretw_), cur(0), avail(0), filled(false) {}
     static constexpr int CH = 32;                              // words per round trip (2*CH+1 loads in flight)
     static_assert(W % CH == 0, "window is filled in whole chunks");
     __device__ __forceinline__ void fill() {
@@ -336,6 +339,7 @@ struct LdsBulkDraws {
             }
         }
         cur = 0;
+        avail = (uint32_t)W;
         filled = true;
     }
     __device__ __forceinline__ void flush() {
@@ -362,9 +366,12 @@ struct LdsBulkDraws {
         return make_uint2(d.pos, d.pretw);
     }
     __device__ __forceinline__ uint32_t next() {
-        if (!filled || cur == (uint32_t)W) {
+        if (!filled || cur == avail) {
             const uint2 r = refill(row, blk, pos, pretw, cur, filled);
-            pos = r.x; pretw = r.y; cur = 0; filled = true;
+            pos = r.x; pretw = r.y; cur = 0; avail = (uint32_t)W; filled = true;
+#ifdef CGE_FLEET_TIMING
+            refills += 1;
+#endif
         }
         return row[W + cur++];
     }
@@ -387,50 +394,56 @@ __device__ __forceinline__ uint32_t *lane_ptr(uint32_t lo, uint32_t hi, int r) {
 
 // Wave-cooperative fill / flush of LdsBulkDraws windows.  Lane r (< DLN) owns stream r and LDS row r; the whole
 // wave then serves one stream at a time: 64 lanes load 64 CONSECUTIVE state words (one 256-byte coalesced access
-// instead of 64 lanes each walking their own 2560-byte block), twist, and park the words in row r.  Per lane the
-// own-block walk costs 2W+1 narrow loads that all hit the same 2-4 cache lines while those are still in flight.
-// RG rows per round trip: all 3 * RG * ceil(W/64) loads are issued (unconditionally, from valid addresses) before
-// the first use, then twisted and parked — written loads-first on purpose, a fused per-word loop makes the
-// compiler wait for memory once per 64 words.
-template <int W, int DLN, int RG>
-__device__ __forceinline__ void coop_fill(LdsBulkDraws<W> &d, int row_stride, bool need) {
-    static_assert(DLN % RG == 0, "row groups");
-    constexpr int NQ = (W + 63) / 64;
+// instead of 64 lanes each walking their own 2560-byte block), twist, temper and park the words in row r.  Per lane
+// the own-block walk costs 2W+1 narrow loads that all hit the same 2-4 cache lines while those are still in flight.
+// Two halves on purpose: coop_fill_issue() only issues loads (every row and quad of the window, one round trip; the
+// caller puts its other loads — the env record — right after it), coop_fill_park() twists and parks.  `quads` is the
+// per-row number of 64-word quads that row needs (0: none); quads that are not needed are not parked.
+template <int W, int DLN>
+struct CoopFillRegs {
+    static constexpr int NQ = (W + 63) / 64;
+    uint32_t a[DLN][NQ], b[DLN][NQ], c[DLN][NQ];
+};
+template <int W, int DLN>
+__device__ __forceinline__ void coop_fill_issue(const LdsBulkDraws<W> &d, CoopFillRegs<W, DLN> &f, uint32_t quads) {
+    constexpr int NQ = CoopFillRegs<W, DLN>::NQ;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t lo = (uint32_t)reinterpret_cast<uintptr_t>(d.blk), hi = (uint32_t)(reinterpret_cast<uintptr_t>(d.blk) >> 32);
-    uint32_t *rows = d.row - (lane < (uint32_t)DLN ? lane : 0u) * row_stride;      // row 0 of this wave
-    const uint32_t needw = need ? 1u : 0u;
-#pragma unroll 1
-    for (int r0 = 0; r0 < DLN; r0 += RG) {
-        uint32_t a[RG][NQ], b[RG][NQ], c[RG][NQ];
 #pragma unroll
-        for (int g = 0; g < RG; ++g) {
-            const uint32_t *blk = lane_ptr(lo, hi, r0 + g);
-            const uint32_t pos = lane_u32(d.pos, r0 + g);
+    for (int g = 0; g < DLN; ++g) {
+        const uint32_t *blk = lane_ptr(lo, hi, g);
+        const uint32_t pos = lane_u32(d.pos, g), nq = lane_u32(quads, g);
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                uint32_t k = pos + 64u * q + lane;                                  // < 624 + 256: one wrap
-                k -= k >= (uint32_t)MT_N ? MT_N : 0;
-                const uint32_t k1 = k + 1 == (uint32_t)MT_N ? 0 : k + 1;
-                const uint32_t km = k + MT_M >= (uint32_t)MT_N ? k + MT_M - MT_N : k + MT_M;
-                a[g][q] = blk[k]; b[g][q] = blk[k1]; c[g][q] = blk[km];
-            }
-        }
-#pragma unroll
-        for (int g = 0; g < RG; ++g) {
-            const uint32_t pos = lane_u32(d.pos, r0 + g), pretw = lane_u32(d.pretw, r0 + g);
-            const bool on = lane_u32(needw, r0 + g) != 0;
-            uint32_t *row = rows + (r0 + g) * row_stride;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const uint32_t j = 64u * q + lane;
-                const uint32_t y = mt_twist(a[g][q], b[g][q], c[g][q]), m = 0u - (uint32_t)(pos + j < pretw);
-                const uint32_t v = (a[g][q] & m) | (y & ~m);
-                if (on && j < (uint32_t)W) { row[j] = v; row[W + j] = mt_temper(v); }
-            }
+        for (int q = 0; q < NQ; ++q) {
+            // a quad that is not needed re-reads quad 0 (same lines, cache hits) instead of branching around its loads:
+            // the compiler closes every conditional block of loads with s_waitcnt vmcnt(0) — one round trip per quad
+            uint32_t k = pos + ((uint32_t)q < nq ? 64u * q : 0u) + lane;            // < 624 + 256: one wrap
+            k -= k >= (uint32_t)MT_N ? MT_N : 0;
+            const uint32_t k1 = k + 1 == (uint32_t)MT_N ? 0 : k + 1;
+            const uint32_t km = k + MT_M >= (uint32_t)MT_N ? k + MT_M - MT_N : k + MT_M;
+            f.a[g][q] = blk[k]; f.b[g][q] = blk[k1]; f.c[g][q] = blk[km];
         }
     }
-    if (need) { d.cur = 0; d.filled = true; }
+}
+template <int W, int DLN>
+__device__ __forceinline__ void coop_fill_park(LdsBulkDraws<W> &d, const CoopFillRegs<W, DLN> &f, int row_stride, uint32_t quads) {
+    constexpr int NQ = CoopFillRegs<W, DLN>::NQ;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t *rows = d.row - (lane < (uint32_t)DLN ? lane : 0u) * row_stride;      // row 0 of this wave
+#pragma unroll
+    for (int g = 0; g < DLN; ++g) {
+        const uint32_t pos = lane_u32(d.pos, g), pretw = lane_u32(d.pretw, g), nq = lane_u32(quads, g);
+        uint32_t *row = rows + g * row_stride;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (nq <= (uint32_t)q) continue;
+            const uint32_t j = 64u * q + lane;
+            const uint32_t y = mt_twist(f.a[g][q], f.b[g][q], f.c[g][q]), m = 0u - (uint32_t)(pos + j < pretw);
+            const uint32_t v = (f.a[g][q] & m) | (y & ~m);
+            if (j < (uint32_t)W) { row[j] = v; row[W + j] = mt_temper(v); }
+        }
+    }
+    if (quads) { d.cur = 0; d.filled = true; d.avail = quads * 64u < (uint32_t)W ? quads * 64u : (uint32_t)W; }
 }
 template <int W, int DLN>
 __device__ __forceinline__ void coop_flush(LdsBulkDraws<W> &d, int row_stride) {

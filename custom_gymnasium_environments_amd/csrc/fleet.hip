@@ -13,8 +13,8 @@
 // over two interleaved streams: NumPy-legacy masked randint / choice(p) / random and CPython random.choice over
 // 144 cells).  step_kernel therefore draws NOTHING: it lists the 1-3 % of envs that need draws, and dense_kernel
 // serves that list with full waves and one bulk LDS window per stream (LdsBulkDraws).
-// The (N,76) float32 obs is staged whole in LDS ([64][77] per wave) and written in one linear pass, so every
-// 128-byte line of the output is completed within a few instructions.
+// The (N,76) float32 obs: every lane of step_kernel streams its own 304-byte row with 16-byte stores; dense_kernel
+// stages its few rows in LDS ([DL][77]) and writes each with two 64-lane stores.
 #include <cstring>
 #include <vector>
 
@@ -55,7 +55,7 @@ struct Params {
     int32_t *ep_len;
     int32_t t_index, accumulate;
     uint32_t *work_count;      // [2][NSUB] alternating counters of the deferred-work sub-lists, one per 64-byte line
-    uint64_t *work_list;       // [NSUB][sub_cap] entries: env index << 3 | W_* flags
+    uint64_t *work_list;       // [NSUB][sub_cap] entries, see work_entry()
     int64_t sub_cap;
     int32_t parity;
 };
@@ -65,6 +65,11 @@ enum : uint32_t { W_TRAFFIC = 1u, W_WEATHER = 2u, W_RESET = 4u };
 // The work list is NSUB sub-lists, block b appends to sub-list b % NSUB.  One list with one counter had every wave that
 // lists anything (86 % of them at 3 % of the lanes) queue on the same L2 atomic unit: step_kernel went from 22 us to
 // 40 us per 131,072-env step once episodes began to end (profiles/r02_fleet_summary.txt, the kernel trace).
+// entry: env index << 25 | L cursor (pos:10, pretw flag) << 14 | P cursor << 3 | W_* flags.  The cursors ride along so that
+// dense_kernel can address the generator blocks straight from the entry, in the same round trip as the env record.
+__device__ __forceinline__ uint64_t work_entry(int64_t i, uint32_t work, uint32_t lpos, uint32_t lpretw, uint32_t ppos, uint32_t ppretw) {
+    return ((uint64_t)i << 25) | ((uint64_t)(lpos | (lpretw ? 1024u : 0u)) << 14) | ((uint64_t)(ppos | (ppretw ? 1024u : 0u)) << 3) | work;
+}
 constexpr int NSUB = 64;
 constexpr int CNT_STRIDE = 16;                                  // dwords between counters
 __device__ __forceinline__ uint32_t *work_counter(uint32_t *base, int parity, uint32_t sub) { return base + ((uint32_t)parity * NSUB + sub) * CNT_STRIDE; }
@@ -177,10 +182,97 @@ __device__ __forceinline__ void update_traffic(Env &e, DrawsL &L) {             
     e.traffic[0] = t0; e.traffic[1] = t1;
 }
 
+// The same redraw for up to DL envs of a dense wave at once: lane c < 29 serves draw c (two window words each) of one row
+// at a time, the 2-bit levels are OR-ed together in LDS (`tr`, two words per row).  Rows whose window cannot hold the 58
+// words take the serial path above.
+__device__ __forceinline__ void coop_update_traffic(Env &e, DrawsL &L, bool need, uint32_t *__restrict__ rows, uint32_t *__restrict__ tr) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool fits = L.filled && L.cur + 58u <= L.avail;
+    if (need && !fits) update_traffic(e, L);
+    const bool coop = need && fits;
+    const unsigned long long m = __ballot(coop);
+    if (!m) return;
+    if (coop) { tr[2 * lane] = 0; tr[2 * lane + 1] = 0; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const double a0 = 0.6, a1 = a0 + 0.3, a2 = a1 + 0.1;
+    const double c0 = a0 / a2, c1 = a1 / a2, c2 = a2 / a2;
+    const double b0 = 0.4, b1 = b0 + 0.6;
+    const double d0 = b0 / b1, d1 = b1 / b1;
+    const bool hot = lane >= 25u;                                                   // draws 25..28 -> cells 3, 4, 8, 9
+    const uint32_t cell = hot ? (lane == 25u ? 3u : lane == 26u ? 4u : lane == 27u ? 8u : 9u) : lane;
+    const bool mine = lane < 29u && (hot || !(cell == 3u || cell == 4u || cell == 8u || cell == 9u));
+#pragma unroll 1
+    for (int r = 0; r < DL; ++r) {
+        if (!((m >> r) & 1ull)) continue;
+        const uint32_t *t = rows + r * LROW + WL + lane_u32(L.cur, r);
+        if (lane < 29u) {
+            const uint32_t a = t[2 * lane] >> 5, b = t[2 * lane + 1] >> 6;
+            const double u = (a * 67108864.0 + b) / 9007199254740992.0;
+            const uint32_t v = hot ? 1u + (uint32_t)(d0 <= u) + (uint32_t)(d1 <= u) : (uint32_t)(c0 <= u) + (uint32_t)(c1 <= u) + (uint32_t)(c2 <= u);
+            if (mine) atomicOr(&tr[2 * r + (cell >= 16u ? 1 : 0)], v << ((cell & 15u) * 2u));
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (coop) { e.traffic[0] = tr[2 * lane]; e.traffic[1] = tr[2 * lane + 1]; L.cur += 58u; }
+}
+
 __device__ __forceinline__ uint32_t zone_cell(uint32_t zone, uint32_t k) {                    // customer_zones :135-140 -> x | y << 5
     const uint32_t i = k / 12u, j = k - i * 12u;
     const uint32_t x = (zone == 1u || zone == 3u) ? 13u + i : i, y = (zone == 2u || zone == 3u) ? 13u + j : j;
     return x | (y << 5);
+}
+
+// One delivery request (:456-512), the general path: every draw is a serial LDS read behind a window check.
+__device__ __forceinline__ void request_serial(DrawsP &P, DrawsL &L, uint32_t &pz, uint32_t &dz, uint32_t &pc, uint32_t &dc, uint32_t &urg, uint32_t &req,
+                                               uint32_t &t0) {
+    const double u0 = 0.3, u1 = u0 + 0.4, u2 = u1 + 0.2, u3 = u2 + 0.1;
+    pz = np_randint(L, 0u, 4u); dz = np_randint(L, 0u, 4u);                                 // np.random.choice(list(CustomerZone))
+    pc = zone_cell(pz, P.randbelow(144u, 8));                                               // random.choice(positions)
+    dc = zone_cell(dz, P.randbelow(144u, 8));
+    while (dc == pc) dc = zone_cell(dz, P.randbelow(144u, 8));
+    urg = np_choice_cdf(L, u0 / u3, u1 / u3, u2 / u3, u3 / u3);
+    req = 0;                                                                                // 0 none, 1 motorcycle, 2 truck
+    if (dz == 3u) req = 1;
+    else if (dz == 2u) { if (L.random53() < 0.6) req = 2; }
+    t0 = 0;
+    if (dz == 1u) t0 = np_randint(L, 50u, 200u);
+}
+
+// The same request when the next NL / NP tempered words of both windows are parked (all but ~0.5 % of them): every word it
+// can consume is read up front — one LDS latency instead of ten serial ones — and the rejection loops become bit scans
+// over acceptance masks.  Returns false, consuming nothing, if the request needs more than that (fewer than two accepted
+// position words among NP, six rejected time-window words, pickup == delivery cell): the caller runs request_serial().
+__device__ __forceinline__ bool request_windowed(DrawsP &P, DrawsL &L, uint32_t &pz, uint32_t &dz, uint32_t &pc, uint32_t &dc, uint32_t &urg, uint32_t &req,
+                                                 uint32_t &t0) {
+    constexpr uint32_t NL = 10, NP = 12;
+    if (!(L.filled && P.filled && L.cur + NL <= L.avail && P.cur + NP <= P.avail)) return false;
+    const uint32_t *lw = L.row + WL + L.cur, *pw = P.row + WP + P.cur;
+    uint32_t l[NL], q[NP];
+#pragma unroll
+    for (uint32_t j = 0; j < NL; ++j) l[j] = lw[j];
+#pragma unroll
+    for (uint32_t j = 0; j < NP; ++j) q[j] = pw[j];
+    pz = l[0] & 3u; dz = l[1] & 3u;                                                         // randint(0, 4): mask 3, never rejects
+    uint32_t pm = 0, tm = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < NP; ++j) pm |= ((q[j] >> 24) < 144u ? 1u : 0u) << j;           // _randbelow(144): top 8 bits, accept < 144
+#pragma unroll
+    for (uint32_t j = 4; j < NL; ++j) tm |= ((l[j] & 255u) <= 149u ? 1u : 0u) << (j - 4u);  // randint(50, 200): mask 255, accept <= 149
+    const uint32_t pm2 = pm & (pm - 1u);
+    if (!pm2 || (dz == 1u && !tm)) return false;
+    const uint32_t ia = (uint32_t)__builtin_ctz(pm), ib = (uint32_t)__builtin_ctz(pm2), it = dz == 1u ? (uint32_t)__builtin_ctz(tm) : 0u;
+    const uint32_t ka = pw[ia] >> 24, kb = pw[ib] >> 24, tw = lw[4u + it] & 255u;          // re-read by index: cheaper than 12-way selects
+    pc = zone_cell(pz, ka); dc = zone_cell(dz, kb);
+    if (dc == pc) return false;
+    const double u0 = 0.3, u1 = u0 + 0.4, u2 = u1 + 0.2, u3 = u2 + 0.1;
+    const double uu = ((l[2] >> 5) * 67108864.0 + (l[3] >> 6)) / 9007199254740992.0;
+    urg = (uint32_t)(u0 / u3 <= uu) + (uint32_t)(u1 / u3 <= uu) + (uint32_t)(u2 / u3 <= uu) + (uint32_t)(u3 / u3 <= uu);
+    const double ur = ((l[4] >> 5) * 67108864.0 + (l[5] >> 6)) / 9007199254740992.0;
+    req = dz == 3u ? 1u : (dz == 2u && ur < 0.6) ? 2u : 0u;
+    t0 = dz == 1u ? 50u + tw : 0u;
+    L.cur += dz == 2u ? 6u : dz == 1u ? 5u + it : 4u;
+    P.cur += ib + 1u;
+    return true;
 }
 
 // `ab`: 24 words of this lane's LDS scratch — the request words are parked there by index and read back once, instead of
@@ -190,34 +282,25 @@ __device__ __forceinline__ void do_reset(Env &e, int32_t max_steps, DrawsP &P, D
 #pragma unroll
     for (int k = 0; k < 3; ++k) { e.veh[k] = 12u | (12u << 5); e.fuel[k] = vrange(k); }
     // _generate_delivery_requests :450-514
-    const double u0 = 0.3, u1 = u0 + 0.4, u2 = u1 + 0.2, u3 = u2 + 0.1;
     e.nd = np_randint(L, 8u, 13u);
 #pragma unroll 1
     for (uint32_t i = 0; i < (uint32_t)MAXD; ++i) {
         uint32_t A = 0, B = 0;
         if (i < e.nd) {
-            const uint32_t pz = np_randint(L, 0u, 4u), dz = np_randint(L, 0u, 4u);          // np.random.choice(list(CustomerZone))
-            const uint32_t pc = zone_cell(pz, P.randbelow(144u, 8));                        // random.choice(positions)
-            uint32_t dc = zone_cell(dz, P.randbelow(144u, 8));
-            while (dc == pc) dc = zone_cell(dz, P.randbelow(144u, 8));
-            const uint32_t urg = np_choice_cdf(L, u0 / u3, u1 / u3, u2 / u3, u3 / u3);
-            uint32_t req = 0;                                                               // 0 none, 1 motorcycle, 2 truck
-            if (dz == 3u) req = 1;
-            else if (dz == 2u) { if (L.random53() < 0.6) req = 2; }
-            uint32_t t0 = 0, commercial = 0;
-            if (dz == 1u) { t0 = np_randint(L, 50u, 200u); commercial = 1; }
+            uint32_t pz, dz, pc, dc, urg, req, t0;
+            if (!request_windowed(P, L, pz, dz, pc, dc, urg, req, t0)) request_serial(P, L, pz, dz, pc, dc, urg, req, t0);
             const int px = (int)(pc & 31u), py = (int)(pc >> 5), dx = (int)(dc & 31u), dy = (int)(dc >> 5);
             const int base = abs(px - dx) + abs(py - dy);
             const double mult = urg == 0 ? 4.0 : urg == 1 ? 3.0 : urg == 2 ? 2.0 : 1.5;
             const uint32_t deadline = (uint32_t)((int)((double)base * mult) + 50);
             A = pc | (dc << 10) | (urg << 20) | (req << 22);                               // not completed, unassigned
-            B = t0 | (commercial << 8) | (deadline << 9);
+            B = t0 | ((dz == 1u ? 1u : 0u) << 8) | (deadline << 9);                        // commercial zone: time window
         }
         ab[i] = A; ab[MAXD + i] = B;
     }
 #pragma unroll
     for (int k = 0; k < MAXD; ++k) { e.dA[k] = ab[k]; e.dB[k] = ab[MAXD + k]; }
-    update_traffic(e, L);
+    // the traffic redraw that ends reset() is the caller's (coop_update_traffic)
 }
 
 __device__ __forceinline__ double weather_value(uint32_t w) { return w == 0 ? 0.8 : w == 1 ? 1.0 : w == 2 ? 1.2 : 1.5; }
@@ -317,8 +400,7 @@ __device__ __forceinline__ uint32_t env_step(Env &e, int32_t max_steps, int32_t 
     return (term ? 1u : 0u) | (e.timestep >= (uint32_t)max_steps ? 2u : 0u);
 }
 
-__device__ __forceinline__ void stage_row(const Env &e, uint32_t *__restrict__ tile_row) {
-    float *row = reinterpret_cast<float *>(tile_row);                                                // :555-593
+__device__ __forceinline__ void stage_row(const Env &e, float *__restrict__ row) {                    // :555-593
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         row[2 * k] = (float)(e.veh[k] & 31u); row[2 * k + 1] = (float)((e.veh[k] >> 5) & 31u);
@@ -338,36 +420,31 @@ __device__ __forceinline__ void stage_row(const Env &e, uint32_t *__restrict__ t
     for (int c = 0; c < 25; ++c) row[51 + c] = (float)(((c < 16 ? e.traffic[0] : e.traffic[1]) >> ((c & 15) * 2)) & 3u);
 }
 
-__device__ __forceinline__ void observe(const Env &e, int64_t nrows, float *__restrict__ dst, unsigned long long rowmask, uint32_t *__restrict__ tile) {
-    const uint32_t lane = threadIdx.x & 63u;
-    stage_row(e, tile + lane * ROW);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    uint32_t r = lane / (uint32_t)OBS, col = lane - r * (uint32_t)OBS;
-#pragma unroll 1
-    for (int m = 0; m < OBS; ++m) {
-        if ((int64_t)r < nrows && ((rowmask >> r) & 1ull)) reinterpret_cast<uint32_t *>(dst)[(int64_t)r * OBS + col] = tile[r * ROW + col];
-        col += 64u % OBS; r += 64u / OBS;
-        if (col >= (uint32_t)OBS) { col -= OBS; r += 1u; }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
-
 // One lane per env, NO random draws: vehicle actions, deadlines, termination, and the obs row of the state as it
 // stands.  Everything that needs the generators — the traffic/weather redraws and the 8-12 new delivery requests
 // of an episode reset (~150 draws over two interleaved streams, ~10k instructions) — happens for ~1-3 % of the
 // lanes per step; executed in place it cost every wave that whole path at 1/64 lane utilisation (234 us per
 // 131k-env step, profiles/r01_fleet_step_v1_summary.txt).  Those envs are appended to a work list instead and
 // dense_kernel processes them with full waves.
+#ifdef CGE_FLEET_TIMING
+__device__ unsigned long long g_timing_step[4096 * 8];
+#define STICK(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = wall_clock64(); \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) { g_timing_step[blockIdx.x * 8 + k] += now_ - t_last; } t_last = now_; } while (0)
+#else
+#define STICK(k)
+#endif
 __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
-    __shared__ uint32_t tile[64 * ROW];
+#ifdef CGE_FLEET_TIMING
+    unsigned long long t_last = wall_clock64();
+#endif
     const int64_t i0 = (int64_t)blockIdx.x * BLOCK;
     const int64_t i = i0 + threadIdx.x;
     const bool live = i < p.n;
     const int64_t li = live ? i : i0;
-    const int64_t nrows = p.n - i0 < 64 ? p.n - i0 : 64;
     const int t = p.t_index;
     Env e;
     e.load(p.state, p.n, li);
+    STICK(0);
     double reward = 0.0;
     uint32_t flags = 0, work = 0;
     if (live) {
@@ -384,7 +461,9 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
                 a1 = (int32_t)hash_action_from_key(key, (uint64_t)(p.t0 + t), 8u, 1u);
                 a2 = (int32_t)hash_action_from_key(key, (uint64_t)(p.t0 + t), 8u, 2u);
             }
+            STICK(1);
             flags = env_step(e, p.max_steps, a0, a1, a2, work, reward);
+            STICK(2);
             if (flags) {
                 e.episodes += 1;
                 if (p.ep_ret) p.ep_ret[i] = e.total_reward;                // fleet_env.py accumulates it in step(), reset() zeroes it
@@ -397,7 +476,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
         if (work) {
             const uint32_t sub = blockIdx.x % (uint32_t)NSUB;
             const uint32_t slot = atomicAdd(work_counter(p.work_count, p.parity, sub), 1u);
-            p.work_list[(int64_t)sub * p.sub_cap + slot] = ((uint64_t)i << 3) | work;
+            p.work_list[(int64_t)sub * p.sub_cap + slot] = work_entry(i, work, e.lpos, e.lpretw, e.ppos, e.ppretw);
         }
         if (p.accumulate) {
             if (p.reward_sum) p.reward_sum[i] += reward;
@@ -410,8 +489,19 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
             p.truncated[i] = (uint8_t)((flags >> 1) & 1u);
         }
     }
-    // rows of envs on the work list are rewritten by dense_kernel (also their final_obs row)
-    if (p.obs) observe(e, nrows, p.obs + (int64_t)t * p.obs_step_stride + i0 * OBS, ~0ull, tile);
+    STICK(3);
+    // rows of envs on the work list are rewritten by dense_kernel (also their final_obs row).  Each lane streams its own
+    // 304-byte row from registers, 19 16-byte stores (store_own_row); round 1 staged the wave's rows in LDS and wrote them
+    // dword by dword in a 76-trip loop, 8 of this kernel's 20 us per wave.
+    if (p.obs) {
+        float row[OBS];
+        stage_row(e, row);
+        store_own_row<OBS>(p.obs + (int64_t)t * p.obs_step_stride + li * OBS, 0, row, live);
+    }
+    STICK(4);
+#ifdef CGE_FLEET_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_timing_step[blockIdx.x * 8 + 7] += 1;
+#endif
 }
 
 // DL lanes per wave, one work-list entry each (dense): traffic / weather redraw, terminal obs -> final_obs, episode
@@ -420,19 +510,22 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
 // both streams' windows are filled once, wave-convergently, before any draw is consumed.
 // what: 0 work list, 1 reset(mask)+obs, 2 rewind cursors after seeding, 3 initial state of a fresh handle
 #ifdef CGE_FLEET_TIMING
-__device__ unsigned long long g_timing[16];
+__device__ unsigned long long g_timing[1024 * 16];          // one slot row per block: no contention between the timed waves
 #define TICK(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = wall_clock64(); \
-    if (blockIdx.x < 64 && threadIdx.x == 0 && what == 0) { atomicAdd(&g_timing[k], now_ - t_last); } t_last = now_; } while (0)
+    if (timed) { g_timing[blockIdx.x * 16 + k] += now_ - t_last; } t_last = now_; } while (0)
 #else
 #define TICK(k)
 #endif
 __global__ __launch_bounds__(BLOCK) void dense_kernel(Params p, int what) {
 #ifdef CGE_FLEET_TIMING
     unsigned long long t_last = wall_clock64();
+    const unsigned long long t_begin = t_last;
+    bool timed = false;
 #endif
     __shared__ uint32_t tile[DL * ROW];
     __shared__ uint32_t drawsP[DL * PROW], drawsL[DL * LROW];
     __shared__ int64_t row_env[DL];
+    __shared__ uint32_t traffic_acc[2 * DL];
     const uint32_t lane = threadIdx.x & 63u;
     // lane s holds sub-list s's entry count and the running total up to and including it
     uint32_t sub_n = 0, sub_end = 0;
@@ -448,12 +541,16 @@ __global__ __launch_bounds__(BLOCK) void dense_kernel(Params p, int what) {
     }
     const uint32_t count = what == 0 ? lane_u32(sub_end, 63) : (uint32_t)p.n;
     const uint32_t slot = lane < (uint32_t)DL ? lane : 0u;
+#ifdef CGE_FLEET_TIMING
+    timed = threadIdx.x == 0 && what == 0 && count < 16384u && count > 64u;      // ordinary steps only, not the mass redraws
+    TICK(9);
+#endif
 #pragma unroll 1
     for (uint32_t first = blockIdx.x * DL; first < count; first += gridDim.x * DL) {
         const uint32_t tix = first + lane;
         const bool live = lane < (uint32_t)DL && tix < count;
         int64_t i;
-        uint32_t work;
+        uint32_t work, lcur = 0, pcur = 0;                     // cursors: pos | pretw flag << 10
         if (what == 0) {
             const uint32_t g = live ? tix : first;             // entry g of the concatenated sub-lists -> (sub-list, offset)
             uint32_t sub = 0;
@@ -462,25 +559,41 @@ __global__ __launch_bounds__(BLOCK) void dense_kernel(Params p, int what) {
                 if ((uint32_t)__shfl((int)sub_end, (int)(sub + b - 1), 64) <= g) sub += b;
             const uint32_t before = (uint32_t)__shfl((int)(sub_end - sub_n), (int)sub, 64);
             const uint64_t entry = p.work_list[(int64_t)sub * p.sub_cap + (g - before)];
-            i = (int64_t)(entry >> 3);
+            i = (int64_t)(entry >> 25);
             work = live ? (uint32_t)(entry & 7u) : 0u;
+            lcur = (uint32_t)(entry >> 14) & 2047u; pcur = (uint32_t)(entry >> 3) & 2047u;
         } else {
             i = live ? (int64_t)tix : (int64_t)first;
             work = (live && what == 1 && (!p.mask || p.mask[i])) ? W_RESET : 0u;
         }
         Env e;
-        e.load(p.state, p.n, i);
+        if (what != 0) {                                       // whole-population passes: the cursors come from the record
+            e.load(p.state, p.n, i);
+            if (what == 2) { if (live) { e.ppos = e.lpos = 0; e.ppretw = e.lpretw = 0; e.store(p.state, p.n, i); } continue; }
+            if (what == 3) { if (live) { e.weather = 1; e.store(p.state, p.n, i); } continue; }
+            lcur = e.lpos | (e.lpretw ? 1024u : 0u); pcur = e.ppos | (e.ppretw ? 1024u : 0u);
+        }
+        DrawsP P(drawsP + slot * PROW, p.mtP + i * MT_STRIDE, pcur & 1023u, (pcur & 1024u) ? (uint32_t)MT_N : 0u);
+        DrawsL L(drawsL + slot * LROW, p.mtL + i * MT_STRIDE, lcur & 1023u, (lcur & 1024u) ? (uint32_t)MT_N : 0u);
+        // one round trip: both windows of every listed env and (work list) the env records.  A redraw-only entry needs
+        // 60 words of the L stream, a reset the whole window of both.
+        const uint32_t quadsL = !work ? 0u : (work & W_RESET) ? (uint32_t)((WL + 63) / 64) : 1u;
+        const uint32_t quadsP = (work & W_RESET) ? (uint32_t)((WP + 63) / 64) : 0u;
+        CoopFillRegs<WL, DL> fl;
+        CoopFillRegs<WP, DL> fp;
+        TICK(12);
+        coop_fill_issue<WL, DL>(L, fl, quadsL);
+        TICK(13);
+        coop_fill_issue<WP, DL>(P, fp, quadsP);
+        TICK(14);
+        if (what == 0) e.load(p.state, p.n, i);
         TICK(0);
-        if (what == 2) { if (live) { e.ppos = e.lpos = 0; e.ppretw = e.lpretw = 0; e.store(p.state, p.n, i); } continue; }
-        if (what == 3) { if (live) { e.weather = 1; e.store(p.state, p.n, i); } continue; }
-        DrawsP P(drawsP + slot * PROW, p.mtP + i * MT_STRIDE, e.ppos, e.ppretw);
-        DrawsL L(drawsL + slot * LROW, p.mtL + i * MT_STRIDE, e.lpos, e.lpretw);
-        coop_fill<WL, DL, (DL < 4 ? DL : 4)>(L, LROW, work != 0);
+        coop_fill_park<WL, DL>(L, fl, LROW, quadsL);
         TICK(1);
-        coop_fill<WP, DL, (DL < 8 ? DL : 8)>(P, PROW, (work & W_RESET) != 0);
+        coop_fill_park<WP, DL>(P, fp, PROW, quadsP);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         TICK(2);
-        if (work & W_TRAFFIC) update_traffic(e, L);                                                   // :257-258
+        coop_update_traffic(e, L, (work & W_TRAFFIC) != 0, drawsL, traffic_acc);                      // :257-258
         if (work & W_WEATHER) {                                                                       // _update_weather :524-528
             const double w0 = 0.3, w1 = w0 + 0.5, w2 = w1 + 0.15, w3 = w2 + 0.05;
             e.weather = np_choice_cdf(L, w0 / w3, w1 / w3, w2 / w3, w3 / w3);
@@ -494,12 +607,15 @@ __global__ __launch_bounds__(BLOCK) void dense_kernel(Params p, int what) {
             // pass 0: terminal obs (after the redraws) of the envs that finished -> final_obs; pass 1: reset, then obs
             const bool want = pass == 0 ? fin : (what == 1 ? live : work != 0);
             if (pass == 1) TICK(4);
-            if (pass == 1 && (work & W_RESET)) do_reset(e, p.max_steps, P, L, tile + slot * ROW);
+            if (pass == 1) {
+                if (work & W_RESET) do_reset(e, p.max_steps, P, L, tile + slot * ROW);
+                coop_update_traffic(e, L, (work & W_RESET) != 0, drawsL, traffic_acc);
+            }
             if (pass == 1) TICK(5);
             float *dst = pass == 0 ? p.final_obs : (p.obs ? p.obs + (int64_t)p.t_index * p.obs_step_stride : nullptr);
             const unsigned long long m = __ballot(want);
             if (!m || !dst) continue;
-            if (lane < (uint32_t)DL) stage_row(e, tile + lane * ROW);
+            if (lane < (uint32_t)DL) stage_row(e, reinterpret_cast<float *>(tile + lane * ROW));
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll 1
             for (int r = 0; r < nlive; ++r) {                  // each listed env's 304-byte row: two 64-lane stores
@@ -520,7 +636,7 @@ __global__ __launch_bounds__(BLOCK) void dense_kernel(Params p, int what) {
         }
         TICK(8);
 #ifdef CGE_FLEET_TIMING
-        if (blockIdx.x < 64 && threadIdx.x == 0 && what == 0) atomicAdd(&g_timing[15], 1ull);
+        if (timed) { unsigned long long *tm = g_timing + blockIdx.x * 16; tm[15] += 1; const unsigned long long el = wall_clock64() - t_begin; if (el > tm[10]) tm[10] = el; if (P.refills + L.refills) tm[11] += 1; }
 #endif
     }
 }
@@ -562,7 +678,9 @@ struct cge_fleet : HandleBase {
     static constexpr uint32_t snap_tag = 3u;
     std::vector<std::pair<void *, size_t>> blobs() const { return {{state, (size_t)fleet::COLS * n * sizeof(uint4)}, {mtP, (size_t)n * MT_STRIDE * 4}, {mtL, (size_t)n * MT_STRIDE * 4}, {work_count, count_bytes()}}; }
     static size_t count_bytes() { return (size_t)2 * fleet::NSUB * fleet::CNT_STRIDE * sizeof(uint32_t); }
+    unsigned blocks() const { return (unsigned)((n + fleet::BLOCK - 1) / fleet::BLOCK); }
     int64_t sub_cap() const { return ((int64_t)blocks() + fleet::NSUB - 1) / fleet::NSUB * fleet::BLOCK; }
+    size_t list_entries() const { return (size_t)fleet::NSUB * (size_t)sub_cap(); }
     uint32_t snap_extra() const { return (uint32_t)parity; }
     void set_snap_extra(uint32_t v) { parity = (int)(v & 1u); (void)v; }
     fleet::Params params() const {
@@ -572,22 +690,24 @@ struct cge_fleet : HandleBase {
         p.ep_ret = ep_ret; p.ep_len = ep_len;
         return p;
     }
-    unsigned blocks() const { return (unsigned)((n + fleet::BLOCK - 1) / fleet::BLOCK); }
     void free_all() { (void)hipFree(state); (void)hipFree(mtP); (void)hipFree(mtL); (void)hipFree(work_count); (void)hipFree(work_list); }
-    // one env step = the RNG-free step kernel + the dense kernel over the envs it listed
-    hipError_t launch_step(fleet::Params &p, hipStream_t s) {
-        p.parity = parity;
-        hipLaunchKernelGGL(fleet::step_kernel, dim3(blocks()), dim3(fleet::BLOCK), 0, s, p);
-        hipLaunchKernelGGL(fleet::dense_kernel, dim3(dense_blocks(1024u)), dim3(fleet::BLOCK), 0, s, p, 0);
-        parity ^= 1;
+    // k env steps = k x (the RNG-free step kernel + the dense kernel over the envs it listed), one stream.  (Measured and dropped:
+    // 2-4 partitions of the envs on forked streams, so that one partition's dense kernel overlaps the others' step kernels —
+    // 51.7 vs 53.5 us per step: both kernels are bound by one wave's latency at this batch size, not by throughput, and the
+    // fork/join events cost step() 23 us per extra stream.)
+    hipError_t launch_steps(fleet::Params &p, int k, hipStream_t s) {
+        const unsigned db = (unsigned)((n + fleet::DL - 1) / fleet::DL);
+        for (int t = 0; t < k; ++t) {
+            p.t_index = t; p.parity = parity;
+            hipLaunchKernelGGL(fleet::step_kernel, dim3(blocks()), dim3(fleet::BLOCK), 0, s, p);
+            hipLaunchKernelGGL(fleet::dense_kernel, dim3(db < 1024u ? db : 1024u), dim3(fleet::BLOCK), 0, s, p, 0);
+            parity ^= 1;
+        }
         return hipGetLastError();
     }
-    unsigned dense_blocks(unsigned cap) const {
-        const unsigned b = (unsigned)((n + fleet::DL - 1) / fleet::DL);
-        return b < cap ? b : cap;
-    }
     hipError_t launch_all(fleet::Params &p, int what, hipStream_t s) {
-        hipLaunchKernelGGL(fleet::dense_kernel, dim3(dense_blocks(1u << 20)), dim3(fleet::BLOCK), 0, s, p, what);
+        const unsigned b = (unsigned)((n + fleet::DL - 1) / fleet::DL);
+        hipLaunchKernelGGL(fleet::dense_kernel, dim3(b < (1u << 20) ? b : (1u << 20)), dim3(fleet::BLOCK), 0, s, p, what);
         return hipGetLastError();
     }
 };
@@ -595,9 +715,22 @@ struct cge_fleet : HandleBase {
 extern "C" {
 
 #ifdef CGE_FLEET_TIMING
+int cge_fleet_debug_timing_step(unsigned long long *out, int clear) {
+    static unsigned long long all[4096 * 8];
+    if (hipMemcpyFromSymbol(all, HIP_SYMBOL(fleet::g_timing_step), sizeof all) != hipSuccess) return 1;
+    for (int k = 0; k < 8; ++k) out[k] = 0;
+    for (int b = 0; b < 4096; ++b)
+        for (int k = 0; k < 8; ++k) out[k] += all[b * 8 + k];
+    if (clear) { memset(all, 0, sizeof all); if (hipMemcpyToSymbol(HIP_SYMBOL(fleet::g_timing_step), all, sizeof all) != hipSuccess) return 1; }
+    return 0;
+}
 int cge_fleet_debug_timing(unsigned long long *out, int clear) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fleet::g_timing), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
-    if (clear) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(fleet::g_timing), z, sizeof z) != hipSuccess) return 1; }
+    static unsigned long long all[1024 * 16];
+    if (hipMemcpyFromSymbol(all, HIP_SYMBOL(fleet::g_timing), sizeof all) != hipSuccess) return 1;
+    for (int k = 0; k < 16; ++k) out[k] = 0;
+    for (int b = 0; b < 1024; ++b)
+        for (int k = 0; k < 16; ++k) { if (k == 10) { if (all[b * 16 + k] > out[k]) out[k] = all[b * 16 + k]; } else out[k] += all[b * 16 + k]; }
+    if (clear) { memset(all, 0, sizeof all); if (hipMemcpyToSymbol(HIP_SYMBOL(fleet::g_timing), all, sizeof all) != hipSuccess) return 1; }
     return 0;
 }
 #endif
@@ -617,13 +750,13 @@ int cge_fleet_create(const cge_fleet_config *cfg, int64_t n_envs, int device, in
     hipError_t e;
     if ((e = hipMalloc(&h->state, sb)) != hipSuccess || (e = hipMalloc(&h->mtP, mb)) != hipSuccess || (e = hipMalloc(&h->mtL, mb)) != hipSuccess ||
         (e = hipMalloc(&h->work_count, cge_fleet::count_bytes())) != hipSuccess ||
-        (e = hipMalloc(&h->work_list, (size_t)fleet::NSUB * h->sub_cap() * sizeof(uint64_t))) != hipSuccess ||
+        (e = hipMalloc(&h->work_list, h->list_entries() * sizeof(uint64_t))) != hipSuccess ||
         (e = hipMemset(h->work_count, 0, cge_fleet::count_bytes())) != hipSuccess || (e = hipMemset(h->state, 0, sb)) != hipSuccess) {
         h->free_all();
         delete h;
         return CGE_ERR_HIP;
     }
-    h->device_bytes = sb + 2 * mb + (size_t)n_envs * sizeof(uint64_t) + 2 * sizeof(uint32_t);
+    h->device_bytes = sb + 2 * mb + h->list_entries() * sizeof(uint64_t) + cge_fleet::count_bytes();
     e = launch_mt_seed(h->mtP, MT_STRIDE, n_envs, nullptr, 0, env_index0, 0, nullptr);
     if (e == hipSuccess) e = launch_mt_seed(h->mtL, MT_STRIDE, n_envs, nullptr, 0, env_index0, 1, nullptr);
     if (e == hipSuccess) {
@@ -679,7 +812,7 @@ int cge_fleet_step(cge_fleet *h, const int32_t *actions, float *obs_out, float *
     fleet::Params p = h->params();
     p.actions = actions; p.obs = obs_out; p.reward = reward_out; p.terminated = terminated_out; p.truncated = truncated_out;
     p.final_obs = final_obs_out; p.k_steps = 1;
-    CGE_TRY(h, h->launch_step(p, as_stream(stream)));
+    CGE_TRY(h, h->launch_steps(p, 1, as_stream(stream)));
     return CGE_OK;
 }
 
@@ -697,10 +830,7 @@ int cge_fleet_rollout(cge_fleet *h, int32_t k_steps, const int32_t *actions, uin
     p.accumulate = 1;
     if (reward_sum_out) CGE_TRY(h, hipMemsetAsync(reward_sum_out, 0, (size_t)h->n * sizeof(double), as_stream(stream)));
     if (done_count_out) CGE_TRY(h, hipMemsetAsync(done_count_out, 0, (size_t)h->n * sizeof(int32_t), as_stream(stream)));
-    for (int32_t t = 0; t < k_steps; ++t) {                    // K x (step, dense): the state stays in HBM/L2 between launches
-        p.t_index = t;
-        CGE_TRY(h, h->launch_step(p, as_stream(stream)));
-    }
+    CGE_TRY(h, h->launch_steps(p, k_steps, as_stream(stream)));   // K x (step, dense) per partition: the state stays in HBM/L2 between launches
     return CGE_OK;
 }
 

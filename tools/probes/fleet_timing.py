@@ -9,7 +9,7 @@ L = ctypes.CDLL(_native.LIB_PATH)
 env = cge.FleetVectorEnv(131072, device="cuda:0")
 env.reset(seed=1)
 buf = (ctypes.c_ulonglong * 16)()
-names = ["entry+load", "fill L", "fill P", "traffic/weather", "final_obs pass", "do_reset", "obs pass", "flush", "store"]
+names = ["entry+load", "fill L", "fill P", "traffic/weather", "final_obs pass", "do_reset", "obs pass", "flush", "store", "counters scan", "", "", "entry", "L loads", "P loads"]
 for chunk in range(4):
     env.rollout(40, action_seed=7, t0=chunk * 40, trajectory=True)
     torch.cuda.synchronize()
@@ -17,4 +17,10 @@ for chunk in range(4):
     n = max(1, buf[15])
     print(f"steps {chunk*40}..{chunk*40+39}: wave-iterations {buf[15]}")
     for k, nm in enumerate(names):
+        if not nm: continue
         print(f"   {nm:18s} {buf[k] * 10.0 / n / 1e3:8.2f} us per wave iteration")
+    sb = (ctypes.c_ulonglong * 8)()
+    L.cge_fleet_debug_timing_step(sb, 1)
+    ns = max(1, sb[7])
+    print("   step kernel per wave: " + ", ".join(f"{nm} {sb[k] * 10.0 / ns / 1e3:.2f} us" for k, nm in enumerate(["load", "actions", "env_step", "store+list+outputs", "obs"])))
+    print(f"   slowest wave {buf[10] * 10.0 / 1e3:.1f} us; wave iterations with a serial refill: {buf[11]}")
