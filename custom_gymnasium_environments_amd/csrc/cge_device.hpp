@@ -203,20 +203,88 @@ struct LdsDraws {
     __device__ __forceinline__ LdsDraws(uint32_t *lds_row, uint32_t *block, uint32_t pos_, uint32_t pretw_)
         : row(lds_row), blk(block), pos(pos_), pretw(pretw_), cur(0), filled(false) {}
     __device__ __forceinline__ void fill() {
-        MtWindow<W> w;
-        w.load(blk, pos);
+        if constexpr (W <= MT_PAD) {
+            MtWindow<W> w;
+            w.load(blk, pos);
 #pragma unroll
-        for (int j = 0; j < W; ++j) row[j] = w.twisted(j, pos, pretw);
+            for (int j = 0; j < W; ++j) row[j] = w.twisted(j, pos, pretw);
+        } else {
+            // long windows: MT_PAD-word runs, NB of them per round trip (a bounded register footprint; every 128-byte line
+            // of the block is fetched once per window instead of once per 16-word refill)
+            static_assert(W % MT_PAD == 0 && W <= MT_N - MT_M, "whole runs, mutually independent words");
+            constexpr int NB = W % (3 * MT_PAD) == 0 ? 3 : W % (2 * MT_PAD) == 0 ? 2 : 1;   // (all six runs of a 96-word window at once: slower, 23 vs 17 us)
+#pragma unroll 1
+            for (int c0 = 0; c0 < W; c0 += NB * MT_PAD) {
+                MtWindow<MT_PAD> w[NB];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    uint32_t start = pos + (uint32_t)(c0 + b * MT_PAD);
+                    start -= start >= (uint32_t)MT_N ? MT_N : 0;
+                    w[b].load(blk, start);
+                }
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int j = 0; j < MT_PAD; ++j) row[c0 + b * MT_PAD + j] = w[b].twisted(j, pos + (uint32_t)(c0 + b * MT_PAD), pretw);
+            }
+        }
         cur = 0;
         filled = true;
     }
     __device__ __forceinline__ void flush() {
         if (!filled) return;
-        for (uint32_t j = 0; j < cur; ++j) {
-            uint32_t k = pos + j;
-            if (k >= pretw) {
-                k -= k >= (uint32_t)MT_N ? MT_N : 0;
-                mt_store(blk, k, row[j]);
+        uint32_t j = 0;
+        if constexpr (W > MT_PAD) {
+            // whole runs of MT_PAD consumed words that lie clear of the mirror (words 0..15 <-> 624..639) and of the wrap go
+            // back as four 16-byte stores, or not at all while the block is still in its seeded generation (k < pretw)
+#pragma unroll 1
+            for (; j + (uint32_t)MT_PAD <= cur; j += MT_PAD) {
+                const uint32_t k = pos + j;
+                uint32_t kp = k;
+                kp -= kp >= (uint32_t)MT_N ? MT_N : 0;
+                if (k + (uint32_t)MT_PAD <= pretw) continue;
+                if (k >= pretw && kp >= (uint32_t)MT_PAD && kp + (uint32_t)MT_PAD <= (uint32_t)MT_N) {
+                    uint32_t v[MT_PAD];
+#pragma unroll
+                    for (int q = 0; q < MT_PAD; ++q) v[q] = row[j + q];
+#pragma unroll
+                    for (int q = 0; q < MT_PAD; q += 4) *reinterpret_cast<MtQuad *>(blk + kp + q) = MtQuad{v[q], v[q + 1], v[q + 2], v[q + 3]};
+                } else {
+#pragma unroll 1
+                    for (uint32_t q = 0; q < (uint32_t)MT_PAD; ++q) {
+                        uint32_t kq = k + q;
+                        if (kq >= pretw) {
+                            kq -= kq >= (uint32_t)MT_N ? MT_N : 0;
+                            mt_store(blk, kq, row[j + q]);
+                        }
+                    }
+                }
+            }
+        }
+        if constexpr (W > MT_PAD) {
+            // the last partial run: all its words read at once, stored one by one under their own predicate
+            if (j < cur) {
+                const uint32_t jn = j + (uint32_t)MT_PAD <= (uint32_t)W ? j : (uint32_t)W - (uint32_t)MT_PAD;    // keep the reads inside the row
+                uint32_t v[MT_PAD];
+#pragma unroll
+                for (int q = 0; q < MT_PAD; ++q) v[q] = row[jn + q];
+#pragma unroll
+                for (int q = 0; q < MT_PAD; ++q) {
+                    const uint32_t jq = jn + (uint32_t)q;
+                    uint32_t k = pos + jq;
+                    if (jq >= j && jq < cur && k >= pretw) {
+                        k -= k >= (uint32_t)MT_N ? MT_N : 0;
+                        mt_store(blk, k, v[q]);
+                    }
+                }
+            }
+        } else {
+            for (; j < cur; ++j) {
+                uint32_t k = pos + j;
+                if (k >= pretw) {
+                    k -= k >= (uint32_t)MT_N ? MT_N : 0;
+                    mt_store(blk, k, row[j]);
+                }
             }
         }
         uint32_t p = pos + cur;
@@ -277,6 +345,11 @@ struct LdsDrawsCall {
         const uint2 r = refill(row, blk, pos, pretw, cur, filled);
         pos = r.x; pretw = r.y; cur = 0; filled = true;
     }
+    // Look-ahead for draw sequences whose word OFFSETS can be computed up front: has(n) says the next n words are parked,
+    // peek(j) is the tempered word j places ahead of the cursor (any order, as often as needed), skip(n) consumes n words.
+    __device__ __forceinline__ bool has(uint32_t n) const { return filled && cur + n <= (uint32_t)W; }
+    __device__ __forceinline__ uint32_t peek(uint32_t j) const { return mt_temper(row[cur + j]); }
+    __device__ __forceinline__ void skip(uint32_t n) { cur += n; }
     __device__ __forceinline__ uint32_t next() {
         if (!filled || cur == (uint32_t)W) {
             const uint2 r = refill(row, blk, pos, pretw, cur, filled);
@@ -293,6 +366,18 @@ struct LdsDrawsCall {
         if (__ballot(shortfall) != 0ull) {
             const uint2 r = refill(row, blk, pos, pretw, cur, filled);
             pos = r.x; pretw = r.y; cur = 0; filled = true;
+        }
+    }
+    // The same top-up with the flush and the fill expanded in place: for the ONE site per step that refills every time (the
+    // call costs the callee's register saves and the caller's spills around it, all scratch traffic).
+    __device__ __forceinline__ void ensure_inline(uint32_t need) {
+        const bool shortfall = !filled || (uint32_t)W - cur < need;
+        if (__ballot(shortfall) != 0ull) {
+            LdsDraws<W> d(row, blk, pos, pretw);
+            d.cur = cur; d.filled = filled;
+            d.flush();
+            d.fill();
+            pos = d.pos; pretw = d.pretw; cur = 0; filled = true;
         }
     }
     __device__ __forceinline__ uint32_t randbelow(uint32_t n, int kbits) {

@@ -18,8 +18,8 @@
 // marker; only severity-5 patients waiting > 60 (a death roll each, in deque order) are visited one by one.
 // RNG: CPython `random` (the env never seeds it; :186 seeds only the unused gymnasium generator): one MT19937 stream per
 // env, ~50-80 words per step (equipment and medicine loops) through an LDS-parked window.
-// Observation (N,243): assembled in two LDS chunks (columns 0-130, 131-242) as the groups pass through registers, each
-// written with coalesced stores; integer rewards -> exact; float32 obs bit-identical to the reference.
+// Observation (N,243): every lane streams its own row from registers as the groups pass through (emit_cols); integer
+// rewards -> exact; float32 obs bit-identical to the reference.
 #include <cstring>
 #include <vector>
 
@@ -35,9 +35,11 @@ constexpr int COLS = 48;
 constexpr int C_MISC = 0, C_DOC = 6, C_NUR = 18, C_BED = 31, C_EQ = 41;
 constexpr int NDOC = 15, NNUR = 25, NBED = 40, NEQ = 10, NMED = 15;
 constexpr int RING = 3008;
-constexpr int NA = 131, NB = OBS - NA;      // obs chunks: columns [0,131) and [131,243)
-constexpr int TILE = 131;                   // LDS dwords per lane (odd stride)
-constexpr int DW = 16, DROW = 17;
+// Generator window: 96 words per env parked in LDS, topped up ONCE per step (a step draws ~55-80 words: <= 10 for the
+// arrival, 2-4 per machine, ~1.3 per medicine, 4-6 for the special events).  Round 1 used 16-word windows behind ~20
+// wave-convergent ensure() points per step: 5-8 refills (a flush loop and a memory round trip each) per wave-step.
+constexpr int DW = 96, DROW = DW + 1;
+constexpr uint32_t STEP_WORDS = 88;         // refill at the top of a step unless this many words are left
 using Draws = LdsDrawsCall<DW>;
 
 // sub-queues: 0 (E,3) 1 (E,4) 2 (E,5) 3 (ICU,5) 4 (WARD,1) 5 (WARD,2)
@@ -329,68 +331,93 @@ __device__ __forceinline__ void update_queue(Misc &m, const Ring &rg, Draws &D, 
     m.wait[G] = len1 > 0u ? (double)total_wait / (double)len1 : 0.0;
 }
 
-// ------------------------------------------------------------------ obs tile -> HBM
-// Rows of `ncols` dwords (LDS stride TILE) go to columns [col0, col0 + ncols) of the (N, 243) output; rows selected by mask.
-// Columns 45..50 (nurse counts) are skipped: they are written directly once the nurse group has been processed.
-// columns [C0, C1) of this lane's row: LDS -> registers -> 16-byte stores, 16 values at a time (a bounded register footprint)
-template <int C0, int C1, int COL0>
-__device__ __forceinline__ void copy_segment(const float *trow, float *drow, bool mine) {
-    if constexpr (C1 - C0 >= 16) {
+// ------------------------------------------------------------------ obs row -> HBM
+// Every lane streams its OWN 972-byte row straight from registers, 16 columns (four 16-byte stores, cge_device.hpp:
+// store_own_row) at a time as the groups pass through: no LDS staging.  (Round 1 staged two column chunks of the wave's 64
+// rows in a 33.5 KB LDS tile; that tile capped the kernel at 4 waves per CU — 2,048 waves ran as two rounds of one wave per
+// SIMD.)  value(j) must be callable with a constant j: the loops below unroll completely.
+template <int COL0, int N, class F>
+__device__ __forceinline__ void emit_cols(float *drow, bool mine, F value) {
+#pragma unroll
+    for (int c = 0; c + 16 <= N; c += 16) {
         float v[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = trow[C0 - COL0 + j];
-        store_own_row<16>(drow, C0, v, mine);
-        copy_segment<C0 + 16, C1, COL0>(trow, drow, mine);
-    } else if constexpr (C1 > C0) {
-        float v[C1 - C0];
+        for (int j = 0; j < 16; ++j) v[j] = value(c + j);
+        store_own_row<16>(drow, COL0 + c, v, mine);
+    }
+    if constexpr (N % 16 != 0) {
+        constexpr int C = N - N % 16;
+        float v[N % 16];
 #pragma unroll
-        for (int j = 0; j < C1 - C0; ++j) v[j] = trow[C0 - COL0 + j];
-        store_own_row<C1 - C0>(drow, C0, v, mine);
+        for (int j = 0; j < N % 16; ++j) v[j] = value(C + j);
+        store_own_row<N % 16>(drow, COL0 + C, v, mine);
     }
 }
 
-// The staged chunk [64 rows][NC columns] (LDS, row stride TILE) -> columns [COL0, COL0+NC) of the (N, 243) output: every lane
-// streams its OWN row in 16-byte stores (cge_device.hpp: store_own_row); columns 45..50 (nurse counts) are written directly by
-// wave_step and skipped here.  Round 1 walked the 64 rows one after the other with 2-3 masked dword stores each (~320 store
-// instructions per wave-step for the two chunks); this is 58 sixteen-byte stores and 7 dwords.
-template <int NC, int COL0>
-__device__ __forceinline__ void flush_rows(const uint32_t *tile, int64_t nrows, float *__restrict__ dst, unsigned long long rowmask) {
-    const uint32_t lane = threadIdx.x & 63u;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const bool mine = (int64_t)lane < nrows && ((rowmask >> lane) & 1ull);
-    const float *trow = reinterpret_cast<const float *>(tile) + lane * TILE;
-    float *drow = dst + (int64_t)lane * OBS;
-    // segments of consecutive columns that this chunk owns: [COL0, COL0+NC) minus [45, 51)
-    constexpr int A0 = COL0, A1 = (COL0 < 45 && COL0 + NC > 45) ? 45 : COL0 + NC;          // first segment [A0, A1)
-    constexpr int B0 = (COL0 < 45 && COL0 + NC > 51) ? 51 : COL0 + NC, B1 = COL0 + NC;    // second segment [B0, B1), empty for chunk B
-    copy_segment<A0, A1, COL0>(trow, drow, mine);
-    if constexpr (B1 > B0) copy_segment<B0, B1, COL0>(trow, drow, mine);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+__device__ __forceinline__ void emit_doctors_beds(const Doctors &dc, const Beds &bd, uint32_t now, float *drow, bool mine) {   // obs[0:45], [51:131]
+    emit_cols<0, 45>(drow, mine, [&](int c) {
+        const int k = c / 3, r = c % 3;
+        return r == 0 ? (float)((double)(dc.meta[k] & 15u) / 20.0) : r == 1 ? (float)((double)((dc.meta[k] >> 4) & 15u) / 20.0)
+                                                                           : (doc_busy(dc.meta[k]) > now ? 1.0f : 0.0f);
+    });
+    emit_cols<51, 80>(drow, mine, [&](int c) {
+        const int b = c / 2;
+        return c % 2 == 0 ? ((bd.b[b] & 1u) ? 1.0f : 0.0f) : (float)((double)((bd.b[b] >> 1) & 7u) / 5.0);
+    });
 }
-
-__device__ __forceinline__ void stage_doctors_beds(const Doctors &dc, const Beds &bd, uint32_t now, float *row) {   // obs[0:45], [51:131]
+// everything the row takes from the DOC and BED groups: the columns above, doctor fatigue [198:213], utilisation [186:192] (:713-724)
+__device__ __forceinline__ void emit_doctor_side(const Doctors &dc, const Beds &bd, uint32_t now, float *drow, bool mine) {
+    emit_doctors_beds(dc, bd, now, drow, mine);
+    emit_cols<198, NDOC>(drow, mine, [&](int c) { return (float)(dc.fat[c] / 100.0); });
+    uint32_t occ[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int k = 0; k < NDOC; ++k) {
-        row[3 * k] = (float)((double)(dc.meta[k] & 15u) / 20.0); row[3 * k + 1] = (float)((double)((dc.meta[k] >> 4) & 15u) / 20.0);
-        row[3 * k + 2] = doc_busy(dc.meta[k]) > now ? 1.0f : 0.0f;
-    }
+    for (int b = 0; b < NBED; ++b) occ[b < 8 ? 0 : b < 14 ? 1 : b < 18 ? 2 : 3] += bd.b[b] & 1u;
+    emit_cols<186, 6>(drow, mine, [&](int c) {
+        return c == 0 ? (float)((double)occ[0] / 8.0) : c == 1 ? (float)((double)occ[1] / 6.0) : c == 2 ? (float)((double)occ[2] / 4.0)
+               : c == 3 ? (float)((double)occ[3] / 22.0) : 0.0f;
+    });
+}
+__device__ __forceinline__ void emit_nurse_counts(const uint32_t (&counts)[6], float *drow, bool mine) {                 // obs[45:51]
+    if (!mine) return;
 #pragma unroll
-    for (int b = 0; b < NBED; ++b) {
-        row[51 + 2 * b] = (bd.b[b] & 1u) ? 1.0f : 0.0f;
-        row[52 + 2 * b] = (float)((double)((bd.b[b] >> 1) & 7u) / 5.0);
-    }
+    for (int d = 0; d < 6; ++d) drow[45 + d] = (float)((double)counts[d] / 10.0);
+}
+__device__ __forceinline__ void emit_nurses(const float (&nurfat)[NNUR], float *drow, bool mine) {                      // obs[213:238]
+    emit_cols<213, NNUR>(drow, mine, [&](int c) { return nurfat[c]; });
+}
+__device__ __forceinline__ void emit_equipment(const Equip &eq, float *drow, bool mine) {                               // obs[161:186]
+    emit_cols<161, NEQ + NMED>(drow, mine, [&](int c) {
+        return c < NEQ ? (float)eq.status[c < NEQ ? c : 0] : (float)((double)eq.med[c >= NEQ ? c - NEQ : 0] / 100.0);
+    });
+}
+// queue histogram [131:161], waits [192:198], extras [238:243]
+__device__ __forceinline__ void emit_misc(const Misc &m, int32_t max_steps, float *drow, bool mine) {
+    emit_cols<131, 30>(drow, mine, [&](int c) {
+        const int d = c / 5, s = c % 5 + 1;
+        uint32_t q = 0;
+        if (d == 0) q = s == 3 ? m.qc[0] : s == 4 ? m.qc[1] : s == 5 ? m.qc[2] : 0u;
+        else if (d == 1) q = s == 5 ? m.qc[3] : 0u;
+        else if (d == 3) q = s == 1 ? m.qc[4] : s == 2 ? m.qc[5] : 0u;
+        const double v = (double)q / 10.0;
+        return (float)(v < 1.0 ? v : 1.0);
+    });
+    emit_cols<192, 6>(drow, mine, [&](int d) {
+        const double w = d == 0 ? m.wait[0] : d == 1 ? m.wait[1] : d == 3 ? m.wait[2] : 0.0, v = w / 60.0;
+        return (float)(v < 1.0 ? v : 1.0);
+    });
+    emit_cols<238, 5>(drow, mine, [&](int c) {
+        return c == 0 ? (float)((double)m.deaths / 10.0) : c == 1 ? (float)((double)m.treated / 100.0) : c == 2 ? (float)((double)m.time / (double)max_steps)
+               : c == 3 ? (m.outbreak ? 1.0f : 0.0f) : (m.mass ? 1.0f : 0.0f);
+    });
 }
 
 // ------------------------------------------------------------------ reset :184-254
 // Draws, in order: 15 doctors x {department, x, y, fatigue}, 25 nurse fatigues, 10 equipment, 15 medicine counts.
-// Writes the four big groups straight to memory and stages / flushes both obs chunks for the rows in `rowmask`
-// (dst = row 0 of this workgroup in the output, or null when no observation is wanted).
-__device__ __forceinline__ void do_reset(const Params &p, int64_t i, bool mine, Misc &m, Draws &D, uint32_t *tile, int64_t i0, int64_t nrows,
-                                         float *dst, unsigned long long rowmask) {
-    const uint32_t lane = threadIdx.x & 63u;
-    float *row = reinterpret_cast<float *>(tile) + lane * TILE;
-    float docfat[NDOC];
-    if (mine) {
+// Writes the four big groups straight to memory and, when `drow` is not null, the env's observation row.
+__device__ __forceinline__ void do_reset(const Params &p, int64_t i, bool mine, Misc &m, Draws &D, float *drow) {
+    if (!mine) return;
+    const bool want = drow != nullptr;
+    {
         Doctors dc;
 #pragma unroll 1
         for (int k = 0; k < NDOC; ++k) {
@@ -406,24 +433,22 @@ __device__ __forceinline__ void do_reset(const Params &p, int64_t i, bool mine, 
 #pragma unroll
         for (int b = 0; b < NBED; ++b) bd.b[b] = 0;
         bd.store(p.state, p.n, i);
-        stage_doctors_beds(dc, bd, 0u, row);
-#pragma unroll
-        for (int k = 0; k < NDOC; ++k) docfat[k] = (float)(dc.fat[k] / 100.0);
+        emit_doctor_side(dc, bd, 0u, drow, want);
     }
-    if (dst) flush_rows<NA, 0>(tile, nrows, dst, rowmask);
-    if (mine) {
-#pragma unroll
-        for (int k = 0; k < NDOC; ++k) row[198 - NA + k] = docfat[k];
+    {
         uint32_t r[52];
+        float nurfat[NNUR];
 #pragma unroll 1
         for (int k = 0; k < NNUR; ++k) {
             const double f = 0.0 + (30.0 - 0.0) * D.random53();
-            row[213 - NA + k] = (float)(f / 100.0);
 #pragma unroll
-            for (int j = 0; j < NNUR; ++j) if (j == k) { r[2 * j] = d_lo(f); r[2 * j + 1] = d_hi(f); }
+            for (int j = 0; j < NNUR; ++j) if (j == k) { r[2 * j] = d_lo(f); r[2 * j + 1] = d_hi(f); nurfat[j] = (float)(f / 100.0); }
         }
         r[50] = 0; r[51] = 0;
         store_cols<13>(p.state, p.n, i, C_NUR, r);
+        emit_nurses(nurfat, drow, want);
+    }
+    {
         Equip eq;
 #pragma unroll 1
         for (int k = 0; k < NEQ; ++k) {
@@ -439,45 +464,37 @@ __device__ __forceinline__ void do_reset(const Params &p, int64_t i, bool mine, 
         }
         eq.in_use = 0;
         eq.store(p.state, p.n, i);
-#pragma unroll
-        for (int k = 0; k < NEQ; ++k) row[161 - NA + k] = (float)eq.status[k];
-#pragma unroll
-        for (int k = 0; k < NMED; ++k) row[171 - NA + k] = (float)((double)eq.med[k] / 100.0);
-#pragma unroll
-        for (int k = 0; k < 30; ++k) row[131 - NA + k] = 0.0f;                 // queues
-#pragma unroll
-        for (int k = 0; k < 12; ++k) row[186 - NA + k] = 0.0f;                 // utilisation, waits
-#pragma unroll
-        for (int k = 0; k < 5; ++k) row[238 - NA + k] = 0.0f;
-        // MISC
-        m.time = 0; m.deaths = 0; m.treated = 0; m.total_wait = 0; m.next_id = 0; m.outbreak = 0; m.mass = 0; m.needs_reset = 0; m.navail = NNUR; m.ep_return = 0;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) { m.wait[d] = 0.0; m.sumarr[d] = 0; }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) { m.qh[k] = 0; m.qc[k] = 0; m.ql[k] = 0; }
-        m.ndept[0] = 0; m.ndept[1] = 0; m.ndept[2] = 0;
-#pragma unroll
-        for (int k = 0; k < NNUR; ++k) m.ndept[k / 10] |= (uint32_t)(k / 4 < 6 ? k / 4 : 5) << (3 * (k % 10));
-        if (dst) {
-            float *orow = dst + (int64_t)lane * OBS;                               // nurse counts: 4,4,4,4,4,5 (:213-220)
-#pragma unroll
-            for (int d = 0; d < 6; ++d) orow[45 + d] = (float)((double)(d == 5 ? 5 : 4) / 10.0);
-        }
+        emit_equipment(eq, drow, want);
     }
-    if (dst) flush_rows<NB, NA>(tile, nrows, dst, rowmask);
-    (void)i0;
+    // MISC
+    m.time = 0; m.deaths = 0; m.treated = 0; m.total_wait = 0; m.next_id = 0; m.outbreak = 0; m.mass = 0; m.needs_reset = 0; m.navail = NNUR; m.ep_return = 0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { m.wait[d] = 0.0; m.sumarr[d] = 0; }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { m.qh[k] = 0; m.qc[k] = 0; m.ql[k] = 0; }
+    m.ndept[0] = 0; m.ndept[1] = 0; m.ndept[2] = 0;
+#pragma unroll
+    for (int k = 0; k < NNUR; ++k) m.ndept[k / 10] |= (uint32_t)(k / 4 < 6 ? k / 4 : 5) << (3 * (k % 10));
+    const uint32_t counts[6] = {4, 4, 4, 4, 4, 5};                                  // nurse counts :213-220
+    emit_nurse_counts(counts, drow, want);
+    emit_misc(m, p.max_steps, drow, want);                                          // empty queues, zero waits and counters
 }
 
+#ifdef CGE_HOSP_TIMING
+__device__ unsigned long long g_timing[2048 * 16];
+#define TICK(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = wall_clock64(); \
+    if (threadIdx.x == 0 && blockIdx.x < 2048) { g_timing[blockIdx.x * 16 + k] += now_ - t_last; } t_last = now_; } while (0)
+#else
+#define TICK(k)
+#endif
 // ------------------------------------------------------------------ one step for the whole wave
 struct StepOut {
     int32_t reward;
     uint32_t flags;
 };
 
-__device__ __forceinline__ void wave_step(const Params &p, int64_t i, int64_t i0, int64_t nrows, bool live, int32_t action, Misc &m, Draws &D,
-                                          uint32_t *tile, float *obs_dst, StepOut &out) {
-    const uint32_t lane = threadIdx.x & 63u;
-    float *row = reinterpret_cast<float *>(tile) + lane * TILE;
+// obs_row: this env's row of the obs output (null: no observation wanted)
+__device__ __forceinline__ void wave_step(const Params &p, int64_t i, bool live, int32_t action, Misc &m, Draws &D, float *obs_row, StepOut &out) {
     const Ring rg{p.ring + i * RING, p.ringtt + i * RING};
     const bool reset_only = live && p.mode == CGE_AUTORESET_NEXT_STEP && m.needs_reset;
     const bool run = live && !reset_only;
@@ -487,12 +504,16 @@ __device__ __forceinline__ void wave_step(const Params &p, int64_t i, int64_t i0
     uint32_t nurse_pick = 0xFFFFFFFFu, doc_pick = 0xFFFFFFFFu, doc_new = 0;
     const int32_t a = (action >= 0 && action <= 34) ? action : -1;
     uint32_t tired = 0;
-    float util_f[6], docfat_f[NDOC];
     bool done = false;
+    float *my_dst = nullptr;                                   // where this step's row goes: obs, or final_obs for a SAME_STEP terminal row
+#ifdef CGE_HOSP_TIMING
+    unsigned long long t_last = wall_clock64();
+#endif
     if (run) {
         m.time += 1;
         const uint32_t now = m.time;
-        D.ensure(6);
+        D.ensure_inline(STEP_WORDS);
+        TICK(13);
         // ---- _process_action :371-464 (draws first; effects on DOC / NUR / BED / EQ are applied when those groups are loaded)
         if (a >= 0 && a <= 5) {
             if (m.navail > 0) { nurse_pick = D.randbelow(m.navail, bit_length(m.navail)); reward += 10; }
@@ -513,13 +534,11 @@ __device__ __forceinline__ void wave_step(const Params &p, int64_t i, int64_t i0
         } else if (a == 33) { m.mass = 1; reward -= 100; }
         else if (a == 34) { m.mass = 0; reward += 5; }
         // ---- _generate_patients :466-525
-        D.ensure(4);
         {
             double base = (double)(20u + D.randbelow(16u, 5)) / 60.0;
             if (m.outbreak) base *= 1.5;
             if (m.mass) base *= 2.0;
             if (D.random53() < base) {
-                D.ensure(4);
                 const double roll = D.random53();
                 double cum = 0.0;
                 uint32_t sev = 1;
@@ -529,11 +548,9 @@ __device__ __forceinline__ void wave_step(const Params &p, int64_t i, int64_t i0
                 cum += 0.35; const bool c2 = roll < cum;
                 sev = c5 ? 5u : c4 ? 4u : c3 ? 3u : c2 ? 2u : 1u;                                // the last bucket (MINOR) is also the default
                 (void)D.randbelow(90u, 7);                                                      // age
-                D.ensure(4);
                 if (m.outbreak) { if (!(D.random53() < 0.6)) (void)D.randbelow(15u, 4); }       // disease type
                 else (void)D.randbelow(15u, 4);
                 uint32_t ins = 0;
-                D.ensure(4);
                 if (D.random53() < 0.2) ins = 10u + D.randbelow(21u, 5);
                 const uint32_t tt = treatment_time(sev);
                 if (sev == 5u) q_push<3>(m, rg, now, ins, tt);
@@ -543,11 +560,13 @@ __device__ __forceinline__ void wave_step(const Params &p, int64_t i, int64_t i0
                 else q_push<4>(m, rg, now, ins, tt);
             }
         }
+        TICK(0);
         // ---- DOC + BED in registers: deferred action effects, _process_treatments :527-605, doctor fatigue :654-658
         Doctors dc;
         Beds bd;
         dc.load(p.state, p.n, i);
         bd.load(p.state, p.n, i);
+        TICK(1);
         if (a == 30) {
 #pragma unroll
             for (int k = 0; k < NDOC; ++k) dc.fat[k] = dmax(0.0, dc.fat[k] - 10.0);
@@ -573,38 +592,45 @@ __device__ __forceinline__ void wave_step(const Params &p, int64_t i, int64_t i0
                 m.treated += 1;
             }
         }
+        TICK(2);
         // queue -> bed assignment per department (EMERGENCY beds 0-7, ICU 8-13, WARD 18-39; SURGERY's queue is always empty)
         assign_dept<0>(m, rg, dc, bd, now); assign_dept<1>(m, rg, dc, bd, now); assign_dept<2>(m, rg, dc, bd, now);
+        TICK(3);
 #pragma unroll
         for (int k = 0; k < NDOC; ++k) {                                                        // doctor fatigue, termination count
             dc.fat[k] = doc_busy(dc.meta[k]) > now ? dmin(100.0, dc.fat[k] + 0.5) : dmax(0.0, dc.fat[k] - 0.2);
             tired += dc.fat[k] > 95.0 ? 1u : 0u;
-            docfat_f[k] = (float)(dc.fat[k] / 100.0);
-        }
-        {                                                                                       // _update_department_metrics :713-724
-            uint32_t occ[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int b = 0; b < NBED; ++b) occ[b < 8 ? 0 : b < 14 ? 1 : b < 18 ? 2 : 3] += bd.b[b] & 1u;
-            util_f[0] = (float)((double)occ[0] / 8.0); util_f[1] = (float)((double)occ[1] / 6.0); util_f[2] = (float)((double)occ[2] / 4.0);
-            util_f[3] = (float)((double)occ[3] / 22.0); util_f[4] = 0.0f; util_f[5] = 0.0f;
         }
         dc.store(p.state, p.n, i);
         bd.store(p.state, p.n, i);
-        stage_doctors_beds(dc, bd, now, row);
+        // the columns these two groups own go to the obs row while they are in registers; a SAME_STEP terminal row — which
+        // belongs in final_obs, known only after the queues below — gets them again from the stored groups (rare), and its
+        // obs row is rewritten by the episode reset anyway
+        emit_doctor_side(dc, bd, now, obs_row, obs_row != nullptr);
+        TICK(4);
+    }
+    if (run) {
+        const uint32_t now = m.time;
         // ---- _update_queues :607-649
-        D.ensure(4);
         update_queue<0>(m, rg, D, now, reward); update_queue<1>(m, rg, D, now, reward); update_queue<2>(m, rg, D, now, reward);
         const bool term = m.deaths >= 3u || tired == (uint32_t)NDOC;                            // _check_termination :726-742 (utilisation never exceeds 1)
         const bool trunc = m.time >= (uint32_t)p.max_steps;
         flags = (term ? 1u : 0u) | (trunc ? 2u : 0u);
         done = flags != 0u;
+        my_dst = obs_row;
+        if (done && p.mode == CGE_AUTORESET_SAME_STEP) {
+            my_dst = p.final_obs ? p.final_obs + i * OBS : nullptr;
+            if (my_dst) {
+                Doctors dc;
+                Beds bd;
+                dc.load(p.state, p.n, i);
+                bd.load(p.state, p.n, i);
+                emit_doctor_side(dc, bd, now, my_dst, true);
+            }
+        }
     }
-    // obs chunk A -> the row's destination (terminal rows of SAME_STEP go to final_obs)
     const bool to_final = done && p.mode == CGE_AUTORESET_SAME_STEP;
-    const unsigned long long m_final = __ballot(run && to_final), m_obs = __ballot(run && !to_final);
-    if (obs_dst) flush_rows<NA, 0>(tile, nrows, obs_dst, m_obs);
-    if (p.final_obs && m_final) flush_rows<NA, 0>(tile, nrows, p.final_obs + i0 * OBS, m_final);
-    float *my_dst = to_final ? (p.final_obs ? p.final_obs + i * OBS : nullptr) : (obs_dst ? obs_dst + (int64_t)lane * OBS : nullptr);
+    TICK(5);
     if (run) {
         const uint32_t now = m.time;
         // ---- NUR: action 0-5 / 30, nurse fatigue :660-667, nurse counts obs[45:51]
@@ -612,6 +638,7 @@ __device__ __forceinline__ void wave_step(const Params &p, int64_t i, int64_t i0
             uint32_t r[52];
             load_cols<13>(p.state, p.n, i, C_NUR, r);
             uint32_t seen = 0, navail = 0, counts[6] = {0, 0, 0, 0, 0, 0};
+            float nurfat_f[NNUR];
             const uint32_t ql[3] = {m.qlen(0), m.qlen(1), m.qlen(2)};
 #pragma unroll
             for (int k = 0; k < NNUR; ++k) {
@@ -629,23 +656,19 @@ __device__ __forceinline__ void wave_step(const Params &p, int64_t i, int64_t i0
 #pragma unroll
                 for (int dd = 0; dd < 6; ++dd) counts[dd] += d == (uint32_t)dd ? 1u : 0u;
                 r[2 * k] = d_lo(f); r[2 * k + 1] = d_hi(f);
-                row[213 - NA + k] = (float)(f / 100.0);
+                nurfat_f[k] = (float)(f / 100.0);
             }
             m.navail = navail;
             store_cols<13>(p.state, p.n, i, C_NUR, r);
-            if (my_dst) {
-#pragma unroll
-                for (int d = 0; d < 6; ++d) my_dst[45 + d] = (float)((double)counts[d] / 10.0);
-            }
+            emit_nurse_counts(counts, my_dst, my_dst != nullptr);
+            emit_nurses(nurfat_f, my_dst, my_dst != nullptr);
         }
-#pragma unroll
-        for (int k = 0; k < NDOC; ++k) row[198 - NA + k] = docfat_f[k];
-#pragma unroll
-        for (int d = 0; d < 6; ++d) row[186 - NA + d] = util_f[d];
+        TICK(6);
         // ---- EQ: action 18-29, _update_equipment :669-686
         {
             Equip eq;
             eq.load(p.state, p.n, i);
+            TICK(10);
             if (a >= 18 && a <= 23) {
 #pragma unroll
                 for (int k = 0; k < 6; ++k)
@@ -654,29 +677,75 @@ __device__ __forceinline__ void wave_step(const Params &p, int64_t i, int64_t i0
 #pragma unroll
                 for (int k = 0; k < 6; ++k) if (a - 24 == k) eq.med[k] = eq.med[k] + 20u < 100u ? eq.med[k] + 20u : 100u;
             }
+            // :669-679.  Machine k draws 4 words if it is in use (failure roll, then the usage toggle) and 2 if not, and only
+            // its own toggle changes its bit: every machine's offset in the window is known up front, so all the words are read
+            // at once instead of one serial LDS round trip (and a window check) per draw.
+            {
+                const uint32_t inuse0 = eq.in_use & ((1u << NEQ) - 1u), need = 2u * NEQ + 2u * (uint32_t)__popc(inuse0);
+                if (D.has(need + 2u)) {                        // +2: the second pair is read (not used) for idle machines too
 #pragma unroll
-            for (int k = 0; k < NEQ; ++k) {
-                D.ensure(4);                                                                // <= 4 words per machine
-                if ((eq.in_use >> k) & 1u) {
-                    eq.status[k] = dmax(0.0, eq.status[k] - 0.01);
-                    if (D.random53() < 0.001) eq.status[k] = 0.0;
+                    for (int k = 0; k < NEQ; ++k) {
+                        const uint32_t off = 2u * k + 2u * (uint32_t)__popc(inuse0 & ((1u << k) - 1u));
+                        const bool used = (inuse0 >> k) & 1u;
+                        const double u1 = ((D.peek(off) >> 5) * 67108864.0 + (D.peek(off + 1u) >> 6)) / 9007199254740992.0;
+                        const double u2 = ((D.peek(off + 2u) >> 5) * 67108864.0 + (D.peek(off + 3u) >> 6)) / 9007199254740992.0;
+                        if (used) {
+                            eq.status[k] = dmax(0.0, eq.status[k] - 0.01);
+                            if (u1 < 0.001) eq.status[k] = 0.0;
+                        }
+                        if ((used ? u2 : u1) < 0.1) eq.in_use ^= 1u << k;
+                    }
+                    D.skip(need);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NEQ; ++k) {
+                        if ((eq.in_use >> k) & 1u) {
+                            eq.status[k] = dmax(0.0, eq.status[k] - 0.01);
+                            if (D.random53() < 0.001) eq.status[k] = 0.0;
+                        }
+                        if (D.random53() < 0.1) eq.in_use ^= 1u << k;
+                    }
                 }
-                if (D.random53() < 0.1) eq.in_use ^= 1u << k;
-                row[161 - NA + k] = (float)eq.status[k];
             }
+            TICK(11);
+            // :681-686.  randint(0, 2) = _randbelow(3): top two bits of a word, 3 rejected.  The 15 accepted words are found
+            // by a bit scan over the acceptance mask of the next 32.
+            if (m.treated > 0u) {
+                bool fast = D.has(32u);
+                uint32_t acc = 0;
+                unsigned long long vals = 0;
+                if (fast) {
 #pragma unroll
-            for (int k = 0; k < NMED; ++k) {
-                if (k % 2 == 0) D.ensure(4);                                                // ~1.3 words per medicine
-                if (m.treated > 0u) { const uint32_t c = D.randbelow(3u, 2); eq.med[k] = eq.med[k] > c ? eq.med[k] - c : 0u; }
-                row[171 - NA + k] = (float)((double)eq.med[k] / 100.0);
+                    for (uint32_t j = 0; j < 32u; ++j) {
+                        const uint32_t c = D.peek(j) >> 30;
+                        acc |= (c < 3u ? 1u : 0u) << j;
+                        vals |= (unsigned long long)c << (2u * j);
+                    }
+                    fast = __popc(acc) >= NMED;
+                }
+                if (fast) {
+                    uint32_t last = 0;
+#pragma unroll
+                    for (int k = 0; k < NMED; ++k) {
+                        last = (uint32_t)__builtin_ctz(acc);
+                        acc &= acc - 1u;
+                        const uint32_t c = (uint32_t)(vals >> (2u * last)) & 3u;
+                        eq.med[k] = eq.med[k] > c ? eq.med[k] - c : 0u;
+                    }
+                    D.skip(last + 1u);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NMED; ++k) { const uint32_t c = D.randbelow(3u, 2); eq.med[k] = eq.med[k] > c ? eq.med[k] - c : 0u; }
+                }
             }
+            TICK(12);
             eq.store(p.state, p.n, i);
+            emit_equipment(eq, my_dst, my_dst != nullptr);
         }
+        TICK(7);
         // ---- _check_special_events :688-711
-        D.ensure(4);
         if (!m.outbreak) { if (D.random53() < 0.001) { m.outbreak = 1; (void)D.randbelow(4u, 3); } }
         else if (D.random53() < 0.01) m.outbreak = 0;
-        D.ensure(4);
         if (!m.mass && D.random53() < 0.0005) {
             m.mass = 1;
             const uint32_t cnt = 5u + D.randbelow(6u, 3);
@@ -686,28 +755,8 @@ __device__ __forceinline__ void wave_step(const Params &p, int64_t i, int64_t i0
                 if (sev == 3u) q_push<0>(m, rg, now, 0u, tt); else if (sev == 4u) q_push<1>(m, rg, now, 0u, tt); else q_push<2>(m, rg, now, 0u, tt);
             }
         }
-        // ---- the rest of obs chunk B: queue histogram [131:161], waits [192:198], extras [238:243]
-#pragma unroll
-        for (int d = 0; d < 6; ++d)
-#pragma unroll
-            for (int s = 1; s <= 5; ++s) {
-                uint32_t c = 0;
-                if (d == 0) c = s == 3 ? m.qc[0] : s == 4 ? m.qc[1] : s == 5 ? m.qc[2] : 0u;
-                else if (d == 1) c = s == 5 ? m.qc[3] : 0u;
-                else if (d == 3) c = s == 1 ? m.qc[4] : s == 2 ? m.qc[5] : 0u;
-                const double v = (double)c / 10.0;
-                row[131 - NA + 5 * d + (s - 1)] = (float)(v < 1.0 ? v : 1.0);
-            }
-#pragma unroll
-        for (int d = 0; d < 6; ++d) {
-            const double w = d == 0 ? m.wait[0] : d == 1 ? m.wait[1] : d == 3 ? m.wait[2] : 0.0, v = w / 60.0;
-            row[192 - NA + d] = (float)(v < 1.0 ? v : 1.0);
-        }
-        row[238 - NA] = (float)((double)m.deaths / 10.0);
-        row[239 - NA] = (float)((double)m.treated / 100.0);
-        row[240 - NA] = (float)((double)m.time / (double)p.max_steps);
-        row[241 - NA] = m.outbreak ? 1.0f : 0.0f;
-        row[242 - NA] = m.mass ? 1.0f : 0.0f;
+        // ---- the rest of the row: queue histogram [131:161], waits [192:198], extras [238:243]
+        emit_misc(m, p.max_steps, my_dst, my_dst != nullptr);
         m.ep_return += reward;                                 // every contribution to this step's reward is in by now
         if (done) {
             m.episodes += 1;
@@ -716,25 +765,25 @@ __device__ __forceinline__ void wave_step(const Params &p, int64_t i, int64_t i0
             if (p.mode == CGE_AUTORESET_NEXT_STEP) m.needs_reset = 1;
         }
     }
-    if (obs_dst) flush_rows<NB, NA>(tile, nrows, obs_dst, m_obs);
-    if (p.final_obs && m_final) flush_rows<NB, NA>(tile, nrows, p.final_obs + i0 * OBS, m_final);
+    TICK(8);
     // ---- episode reset: SAME_STEP rows that just finished, NEXT_STEP rows that finished on the previous call
     const bool reset_now = reset_only || (run && to_final);
-    const unsigned long long m_reset = __ballot(reset_now);
-    if (m_reset) do_reset(p, i, reset_now, m, D, tile, i0, nrows, obs_dst, m_reset);
+    if (__ballot(reset_now)) do_reset(p, i, reset_now, m, D, obs_row);
+    TICK(9);
+#ifdef CGE_HOSP_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < 2048) g_timing[blockIdx.x * 16 + 15] += 1;
+#endif
     out.reward = reward;
     out.flags = flags;
 }
 
 template <bool ROLLOUT>
 __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
-    __shared__ uint32_t tile[64 * TILE];
     __shared__ uint32_t draws[64 * DROW];
     const int64_t i0 = (int64_t)blockIdx.x * BLOCK;
     const int64_t i = i0 + threadIdx.x;
     const bool live = i < p.n;
     const int64_t li = live ? i : i0;
-    const int64_t nrows = p.n - i0 < 64 ? p.n - i0 : 64;
     const uint32_t lane = threadIdx.x & 63u;
     Misc m;
     m.load(p.state, p.n, li);
@@ -747,8 +796,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
     for (int t = 0; t < ksteps; ++t) {
         const int32_t a = !live ? 0 : p.actions ? p.actions[(int64_t)t * p.n + i] : (int32_t)hash_action_from_key(key, (uint64_t)(p.t0 + t), 35u, 0u);
         StepOut o;
-        float *obs_dst = p.obs ? p.obs + (int64_t)t * p.obs_step_stride + i0 * OBS : nullptr;
-        wave_step(p, li, i0, nrows, live, a, m, D, tile, obs_dst, o);
+        float *obs_row = (p.obs && live) ? p.obs + (int64_t)t * p.obs_step_stride + i * OBS : nullptr;
+        int64_t lt = li;
+        if (ROLLOUT) asm volatile("" : "+v"(lt));              // opaque per iteration: keeps the 48 column addresses from being hoisted out of the t loop (+72 VGPRs)
+        wave_step(p, lt, live, a, m, D, obs_row, o);
         if (live) {
             if (ROLLOUT) {
                 rsum += (double)o.reward;
@@ -775,84 +826,43 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
 
 // Current observation of an env that is NOT being reset (reset(mask) must return every row): the same assembly as in
 // wave_step, from the stored groups.
-__device__ __forceinline__ void observe_current(const Params &p, int64_t i, bool mine, const Misc &m, uint32_t *tile, int64_t nrows, float *dst,
-                                                unsigned long long rowmask) {
-    const uint32_t lane = threadIdx.x & 63u;
-    float *row = reinterpret_cast<float *>(tile) + lane * TILE;
-    float docfat[NDOC], util_f[6];
-    if (mine) {
+__device__ __forceinline__ void observe_current(const Params &p, int64_t i, bool mine, const Misc &m, float *drow) {
+    if (!mine) return;
+    {
         Doctors dc;
         Beds bd;
         dc.load(p.state, p.n, i);
         bd.load(p.state, p.n, i);
-        stage_doctors_beds(dc, bd, m.time, row);
-#pragma unroll
-        for (int k = 0; k < NDOC; ++k) docfat[k] = (float)(dc.fat[k] / 100.0);
-        uint32_t occ[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int b = 0; b < NBED; ++b) occ[b < 8 ? 0 : b < 14 ? 1 : b < 18 ? 2 : 3] += bd.b[b] & 1u;
-        util_f[0] = (float)((double)occ[0] / 8.0); util_f[1] = (float)((double)occ[1] / 6.0); util_f[2] = (float)((double)occ[2] / 4.0);
-        util_f[3] = (float)((double)occ[3] / 22.0); util_f[4] = 0.0f; util_f[5] = 0.0f;
+        emit_doctor_side(dc, bd, m.time, drow, true);
     }
-    flush_rows<NA, 0>(tile, nrows, dst, rowmask);
-    if (mine) {
+    {
         uint32_t r[52];
+        float nurfat[NNUR];
         load_cols<13>(p.state, p.n, i, C_NUR, r);
         uint32_t counts[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int k = 0; k < NNUR; ++k) {
-            row[213 - NA + k] = (float)(mk_double(r[2 * k], r[2 * k + 1]) / 100.0);
+            nurfat[k] = (float)(mk_double(r[2 * k], r[2 * k + 1]) / 100.0);
             const uint32_t d = m.nurse_dept(k);
 #pragma unroll
             for (int dd = 0; dd < 6; ++dd) counts[dd] += d == (uint32_t)dd ? 1u : 0u;
         }
-        float *orow = dst + (int64_t)lane * OBS;
-#pragma unroll
-        for (int d = 0; d < 6; ++d) orow[45 + d] = (float)((double)counts[d] / 10.0);
-#pragma unroll
-        for (int k = 0; k < NDOC; ++k) row[198 - NA + k] = docfat[k];
-#pragma unroll
-        for (int d = 0; d < 6; ++d) row[186 - NA + d] = util_f[d];
-        Equip eq;
-        eq.load(p.state, p.n, i);
-#pragma unroll
-        for (int k = 0; k < NEQ; ++k) row[161 - NA + k] = (float)eq.status[k];
-#pragma unroll
-        for (int k = 0; k < NMED; ++k) row[171 - NA + k] = (float)((double)eq.med[k] / 100.0);
-#pragma unroll
-        for (int d = 0; d < 6; ++d)
-#pragma unroll
-            for (int s = 1; s <= 5; ++s) {
-                uint32_t c = 0;
-                if (d == 0) c = s == 3 ? m.qc[0] : s == 4 ? m.qc[1] : s == 5 ? m.qc[2] : 0u;
-                else if (d == 1) c = s == 5 ? m.qc[3] : 0u;
-                else if (d == 3) c = s == 1 ? m.qc[4] : s == 2 ? m.qc[5] : 0u;
-                const double v = (double)c / 10.0;
-                row[131 - NA + 5 * d + (s - 1)] = (float)(v < 1.0 ? v : 1.0);
-            }
-#pragma unroll
-        for (int d = 0; d < 6; ++d) {
-            const double w = d == 0 ? m.wait[0] : d == 1 ? m.wait[1] : d == 3 ? m.wait[2] : 0.0, v = w / 60.0;
-            row[192 - NA + d] = (float)(v < 1.0 ? v : 1.0);
-        }
-        row[238 - NA] = (float)((double)m.deaths / 10.0);
-        row[239 - NA] = (float)((double)m.treated / 100.0);
-        row[240 - NA] = (float)((double)m.time / (double)p.max_steps);
-        row[241 - NA] = m.outbreak ? 1.0f : 0.0f;
-        row[242 - NA] = m.mass ? 1.0f : 0.0f;
+        emit_nurse_counts(counts, drow, true);
+        emit_nurses(nurfat, drow, true);
     }
-    flush_rows<NB, NA>(tile, nrows, dst, rowmask);
+    Equip eq;
+    eq.load(p.state, p.n, i);
+    emit_equipment(eq, drow, true);
+    emit_misc(m, p.max_steps, drow, true);
 }
 
 // what: 0 = reset(mask) + obs, 1 = rewind the generator cursor after seeding, 2 = fresh-handle state
 __global__ __launch_bounds__(BLOCK) void reset_kernel(Params p, int what) {
-    __shared__ uint32_t tile[64 * TILE];
     __shared__ uint32_t draws[64 * DROW];
     const int64_t i0 = (int64_t)blockIdx.x * BLOCK;
     const int64_t i = i0 + threadIdx.x;
     const bool live = i < p.n;
     const int64_t li = live ? i : i0;
-    const int64_t nrows = p.n - i0 < 64 ? p.n - i0 : 64;
     const uint32_t lane = threadIdx.x & 63u;
     Misc m;
     m.load(p.state, p.n, li);
@@ -871,10 +881,9 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(Params p, int what) {
     }
     Draws D(draws + lane * DROW, p.mt + li * MT_STRIDE, m.pos, m.pretw);
     const bool mine = live && (!p.mask || p.mask[i]);
-    const unsigned long long m_reset = __ballot(mine), m_keep = __ballot(live && !mine);
-    float *dst = p.obs ? p.obs + i0 * OBS : nullptr;
-    if (m_keep && dst) observe_current(p, li, live && !mine, m, tile, nrows, dst, m_keep);
-    if (m_reset) do_reset(p, li, mine, m, D, tile, i0, nrows, dst, m_reset);
+    float *drow = (p.obs && live) ? p.obs + i * OBS : nullptr;
+    if (drow) observe_current(p, li, !mine, m, drow);
+    do_reset(p, li, mine, m, D, drow);
     if (mine) {
         D.flush();
         m.pos = D.pos; m.pretw = D.pretw;
@@ -944,6 +953,18 @@ struct cge_hospital : HandleBase {
 };
 
 extern "C" {
+
+#ifdef CGE_HOSP_TIMING
+int cge_hospital_debug_timing(unsigned long long *out, int clear) {
+    static unsigned long long all[2048 * 16];
+    if (hipMemcpyFromSymbol(all, HIP_SYMBOL(hosp::g_timing), sizeof all) != hipSuccess) return 1;
+    for (int k = 0; k < 16; ++k) out[k] = 0;
+    for (int b = 0; b < 2048; ++b)
+        for (int k = 0; k < 16; ++k) out[k] += all[b * 16 + k];
+    if (clear) { memset(all, 0, sizeof all); if (hipMemcpyToSymbol(HIP_SYMBOL(hosp::g_timing), all, sizeof all) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 
 int cge_hospital_create(const cge_hospital_config *cfg, int64_t n_envs, int device, int64_t env_index0, cge_hospital **out) {
     if (!cfg || !out || n_envs <= 0 || env_index0 < 0) return CGE_ERR_INVALID_ARG;
