@@ -166,9 +166,14 @@ __device__ __forceinline__ double price_update(Env &e, const Cfg &c, double curr
 // Candle k of the fresh history goes to slot (phase + k) % 50: the env adopts the batch-wide ring phase.
 constexpr int RW_P = 32, RW_L = 16;
 static_assert(RW_P + RW_L <= ROW, "the reset's draw windows live in the lane's obs-tile row");
-__device__ __forceinline__ void do_reset(Env &e, const Params &p, int64_t i, int phase, uint32_t *lds_row) {
-    LdsDrawsCall<RW_P> sp(lds_row, p.mtP + i * MT_STRIDE, e.ppos, e.ppretw);
-    LdsDrawsCall<RW_L> sl(lds_row + RW_P, p.mtL + i * MT_STRIDE, e.lpos, e.lpretw);
+// fused rollouts keep one window per stream parked in LDS for all k steps (env_step<true>): every 128-byte line of a generator
+// block is then fetched once per ~4 (CPython stream) / ~12 (NumPy stream) steps instead of 2-3 partial lines per step and stream
+constexpr int KW_P = 48, KW_L = 32, KROW = KW_P + KW_L + 1;
+using RollP = LdsDrawsCall<KW_P>;
+using RollL = LdsDrawsCall<KW_L>;
+
+template <class SP, class SL>
+__device__ __forceinline__ void reset_body(Env &e, const Params &p, int64_t i, int phase, SP &sp, SL &sl) {
     e.cash = p.cfg.initial_balance;
     e.cash_kind = 0;
     e.holdings = 0.0;
@@ -193,6 +198,11 @@ __device__ __forceinline__ void do_reset(Env &e, const Params &p, int64_t i, int
         slot = slot + 1 == HLEN ? 0 : slot + 1;
     }
     e.close = price;
+}
+__device__ __forceinline__ void do_reset(Env &e, const Params &p, int64_t i, int phase, uint32_t *lds_row) {
+    LdsDrawsCall<RW_P> sp(lds_row, p.mtP + i * MT_STRIDE, e.ppos, e.ppretw);
+    LdsDrawsCall<RW_L> sl(lds_row + RW_P, p.mtL + i * MT_STRIDE, e.lpos, e.lpretw);
+    reset_body(e, p, i, phase, sp, sl);
     sp.flush(); sl.flush();
     e.ppos = sp.pos; e.ppretw = sp.pretw; e.lpos = sl.pos; e.lpretw = sl.pretw;
 }
@@ -232,16 +242,20 @@ __device__ __forceinline__ void sell_apply(Env &e, const Cfg &c, double qty, dou
 
 // One reference step() (:342-398) for one env; writes the new candle into slot `phase`.
 // Returns terminated; reward in float64.
+// PARKED: the draws come from the rollout's LDS-parked windows (dp / dl hold >= WP / WL words: ensure_inline at the top of the step);
+// otherwise from two register windows loaded here and committed below (dp, dl unused).
+template <bool PARKED>
 __device__ __forceinline__ bool env_step(Env &e, const Params &p, int64_t i, int phase, int32_t a_disc, float a_buy, float a_sell,
-                                         double &reward) {
+                                         double &reward, RollP &dp, RollL &dl) {
     const Cfg &c = p.cfg;
     uint32_t *__restrict__ blkP = p.mtP + i * MT_STRIDE;
     uint32_t *__restrict__ blkL = p.mtL + i * MT_STRIDE;
     MtWindow<WP> wp;
-    wp.load(blkP, e.ppos);
     MtWindow<WL> wl;
-    const bool need_l = !e.has_gauss;
-    if (need_l) wl.load(blkL, e.lpos);
+    if constexpr (!PARKED) {
+        wp.load(blkP, e.ppos);
+        if (!e.has_gauss) wl.load(blkL, e.lpos);
+    }
 
     // ---- _execute_action :400-447
     const double price = e.close;
@@ -273,7 +287,8 @@ __device__ __forceinline__ bool env_step(Env &e, const Params &p, int64_t i, int
     // ---- P draws of the common path, all from the window: [slippage] volume regime-test high low
     double U[5];
 #pragma unroll
-    for (int q = 0; q < 5; ++q) U[q] = u53(wp.draw(2 * q, e.ppos, e.ppretw), wp.draw(2 * q + 1, e.ppos, e.ppretw));
+    for (int q = 0; q < 5; ++q)
+        U[q] = PARKED ? u53(dp.peek(2 * q), dp.peek(2 * q + 1)) : u53(wp.draw(2 * q, e.ppos, e.ppretw), wp.draw(2 * q + 1, e.ppos, e.ppretw));
     if (traded) {
         if (kind == 1) buy_apply(e, c, amount, amount_f32, price, U[0]);
         else sell_apply(e, c, amount, price, U[0]);
@@ -287,15 +302,23 @@ __device__ __forceinline__ bool env_step(Env &e, const Params &p, int64_t i, int
     const bool regime_switch = ureg < 0.01;                       // :135
     double u_hi = traded ? U[3] : U[2], u_lo = traded ? U[4] : U[3];
     if (regime_switch) {
-        // rare: persist the window up to the regime test, continue on the serial stream
-        wp.commit(blkP, e.ppos, e.ppretw, 2u * (tq + 2u));
-        MtStream sp(blkP, e.ppos, e.ppretw);
-        update_regime(e, sp);
-        u_hi = sp.random53();
-        u_lo = sp.random53();
-        e.ppos = sp.pos; e.ppretw = sp.pretw;
+        // rare: consume the window up to the regime test, continue draw by draw
+        if constexpr (PARKED) {
+            dp.skip(2u * (tq + 2u));
+            update_regime(e, dp);
+            u_hi = dp.random53();
+            u_lo = dp.random53();
+        } else {
+            wp.commit(blkP, e.ppos, e.ppretw, 2u * (tq + 2u));
+            MtStream sp(blkP, e.ppos, e.ppretw);
+            update_regime(e, sp);
+            u_hi = sp.random53();
+            u_lo = sp.random53();
+            e.ppos = sp.pos; e.ppretw = sp.pretw;
+        }
     } else {
-        wp.commit(blkP, e.ppos, e.ppretw, 2u * (tq + 4u));
+        if constexpr (PARKED) dp.skip(2u * (tq + 4u));
+        else wp.commit(blkP, e.ppos, e.ppretw, 2u * (tq + 4u));
     }
     // ---- gaussian (family L): cached half, or up to two polar attempts from the window, else serial
     double g;
@@ -304,27 +327,41 @@ __device__ __forceinline__ bool env_step(Env &e, const Params &p, int64_t i, int
         g = e.gauss;
         e.gauss = 0.0;
     } else {
-        double x1 = 2.0 * u53(wl.draw(0, e.lpos, e.lpretw), wl.draw(1, e.lpos, e.lpretw)) - 1.0;
-        double x2 = 2.0 * u53(wl.draw(2, e.lpos, e.lpretw), wl.draw(3, e.lpos, e.lpretw)) - 1.0;
+        uint32_t lw[WL];
+#pragma unroll
+        for (int j = 0; j < WL; ++j) lw[j] = PARKED ? dl.peek(j) : wl.draw(j, e.lpos, e.lpretw);
+        double x1 = 2.0 * u53(lw[0], lw[1]) - 1.0;
+        double x2 = 2.0 * u53(lw[2], lw[3]) - 1.0;
         double r2 = x1 * x1 + x2 * x2;
         uint32_t used = 4;
         bool ok = !(r2 >= 1.0 || r2 == 0.0);
         if (!ok) {
-            x1 = 2.0 * u53(wl.draw(4, e.lpos, e.lpretw), wl.draw(5, e.lpos, e.lpretw)) - 1.0;
-            x2 = 2.0 * u53(wl.draw(6, e.lpos, e.lpretw), wl.draw(7, e.lpos, e.lpretw)) - 1.0;
+            x1 = 2.0 * u53(lw[4], lw[5]) - 1.0;
+            x2 = 2.0 * u53(lw[6], lw[7]) - 1.0;
             r2 = x1 * x1 + x2 * x2;
             used = 8;
             ok = !(r2 >= 1.0 || r2 == 0.0);
         }
-        wl.commit(blkL, e.lpos, e.lpretw, used);
-        if (!ok) {
-            MtStream sl(blkL, e.lpos, e.lpretw);
-            do {
-                x1 = 2.0 * sl.random53() - 1.0;
-                x2 = 2.0 * sl.random53() - 1.0;
-                r2 = x1 * x1 + x2 * x2;
-            } while (r2 >= 1.0 || r2 == 0.0);
-            e.lpos = sl.pos; e.lpretw = sl.pretw;
+        if constexpr (PARKED) {
+            dl.skip(used);
+            if (!ok) {
+                do {
+                    x1 = 2.0 * dl.random53() - 1.0;
+                    x2 = 2.0 * dl.random53() - 1.0;
+                    r2 = x1 * x1 + x2 * x2;
+                } while (r2 >= 1.0 || r2 == 0.0);
+            }
+        } else {
+            wl.commit(blkL, e.lpos, e.lpretw, used);
+            if (!ok) {
+                MtStream sl(blkL, e.lpos, e.lpretw);
+                do {
+                    x1 = 2.0 * sl.random53() - 1.0;
+                    x2 = 2.0 * sl.random53() - 1.0;
+                    r2 = x1 * x1 + x2 * x2;
+                } while (r2 >= 1.0 || r2 == 0.0);
+                e.lpos = sl.pos; e.lpretw = sl.pretw;
+            }
         }
         const double f = sqrt(-2.0 * log(r2) / r2);
         e.gauss = f * x1;
@@ -496,12 +533,16 @@ __device__ __forceinline__ void hash_cont(uint64_t key, uint64_t t, float &b, fl
 template <bool ROLLOUT>
 __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
     __shared__ uint32_t tile[64 * ROW];
+    __shared__ uint32_t win[ROLLOUT ? 64 * KROW : 1];
     const int64_t i0 = (int64_t)blockIdx.x * BLOCK;
     const int64_t i = i0 + threadIdx.x;
     const bool live = i < p.n;
     const int64_t li = live ? i : i0;
     Env e;
     e.load(p.scal, p.n, li);
+    uint32_t *wrow = win + (ROLLOUT ? (threadIdx.x & 63u) * KROW : 0u);
+    RollP dp(wrow, p.mtP + li * MT_STRIDE, e.ppos, e.ppretw);
+    RollL dl(wrow + (ROLLOUT ? KW_P : 0), p.mtL + li * MT_STRIDE, e.lpos, e.lpretw);
     uint64_t key = ROLLOUT ? hash_env_key(p.a_seed, (uint64_t)(p.env0 + li)) : 0;
     double rsum = 0.0;
     int32_t dcount = 0;
@@ -512,6 +553,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
         double reward = 0.0;
         bool term = false, reset_now = false;
         const int next_phase = phase + 1 == HLEN ? 0 : phase + 1;
+        if (ROLLOUT) { dp.ensure_inline(WP); dl.ensure_inline(WL); }          // wave-convergent top-up: this step's words are parked
         if (live) {
             if (p.mode == CGE_AUTORESET_NEXT_STEP && e.needs_reset) {
                 reset_now = true;
@@ -525,7 +567,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
                     a = p.actions ? reinterpret_cast<const int32_t *>(p.actions)[(int64_t)t * p.n + i]
                                   : (int32_t)hash_action_from_key(key, (uint64_t)(p.t0 + t), 5u, 0u);
                 }
-                term = env_step(e, p, i, phase, a, ab, as, reward);
+                term = env_step<ROLLOUT>(e, p, i, phase, a, ab, as, reward, dp, dl);
                 e.ep_return += reward;
                 if (term) {
                     e.episodes += 1;
@@ -541,7 +583,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
         float *obs_t = p.obs ? p.obs + (int64_t)t * p.obs_step_stride + i0 * OBS : nullptr;
 #pragma unroll 1
         for (int pass = (fin_mask && p.final_obs) ? 0 : 1; pass < 2; ++pass) {
-            if (pass == 1 && reset_now) do_reset(e, p, i, next_phase, tile + (threadIdx.x & 63u) * ROW);
+            if (pass == 1 && reset_now) {
+                if (ROLLOUT) reset_body(e, p, i, next_phase, dp, dl);
+                else do_reset(e, p, i, next_phase, tile + (threadIdx.x & 63u) * ROW);
+            }
             float *dst = pass == 0 ? p.final_obs + i0 * OBS : obs_t;
             if (dst) observe(e, p, i0, i, live, next_phase, dst, pass == 0 ? fin_mask : ~0ull, tile);
         }
@@ -560,6 +605,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
         phase = next_phase;
     }
     if (live) {
+        if (ROLLOUT) {                                         // consumed words back to the generator blocks, cursors to the record
+            dp.flush(); dl.flush();
+            e.ppos = dp.pos; e.ppretw = dp.pretw; e.lpos = dl.pos; e.lpretw = dl.pretw;
+        }
         e.store(p.scal, p.n, i);
         if (ROLLOUT) {
             if (p.reward_sum) p.reward_sum[i] = rsum;
