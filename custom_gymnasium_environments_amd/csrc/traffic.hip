@@ -169,11 +169,25 @@ __device__ __forceinline__ void spawn(Env &e, const Cfg &c, DRAWS &d) {
     e.nveh += 1;
 }
 
+#ifdef CGE_TRAFFIC_TIMING
+__device__ unsigned long long g_timing[4096 * 16];
+#define TICK(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = wall_clock64(); \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) { g_timing[blockIdx.x * 16 + k] += now_ - t_last; } t_last = now_; } while (0)
+#define TICK_DECL unsigned long long t_last = wall_clock64();
+#define TICK_ARG , unsigned long long &t_last
+#define TICK_PASS , t_last
+#else
+#define TICK(k)
+#define TICK_DECL
+#define TICK_ARG
+#define TICK_PASS
+#endif
 // one reference step() (:168-203); returns terminated, reward in float64
 template <class DRAWS>
-__device__ __forceinline__ bool env_step(Env &e, const Cfg &c, const uint32_t (&a)[NI], DRAWS &d, double &reward) {
+__device__ __forceinline__ bool env_step(Env &e, const Cfg &c, const uint32_t (&a)[NI], DRAWS &d, double &reward TICK_ARG) {
     e.timestep += 1;
-    d.ensure(12);                                                                      // typical step: 1-2 light timers + a spawn with 1-4 hops
+    d.ensure_inline(12);
+    TICK(1);                                                                      // typical step: 1-2 light timers + a spawn with 1-4 hops
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         uint32_t phase = e.light[i] & 3u, timer = e.light[i] >> 2;
@@ -191,7 +205,9 @@ __device__ __forceinline__ bool env_step(Env &e, const Cfg &c, const uint32_t (&
         }
         e.light[i] = phase | ((uint32_t)timer << 2);
     }
+    TICK(2);
     if (e.nveh < (uint32_t)c.max_vehicles) spawn(e, c, d);                             // returns BEFORE drawing when full
+    TICK(3);
     uint32_t tp = 0, twsum = 0, tq = 0, qt[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {                                                     // process_vehicles utils.py:141-163
@@ -231,6 +247,7 @@ __device__ __forceinline__ bool env_step(Env &e, const Cfg &c, const uint32_t (&
     r += 0.5 / (1.0 + var);
     e.total_reward += r;
     reward = r;
+    TICK(4);
     return e.timestep >= (uint32_t)c.max_steps;
 }
 
@@ -331,6 +348,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
     double rsum = 0.0;
     int32_t dcount = 0;
     const int ksteps = ROLLOUT ? p.k_steps : 1;
+    TICK_DECL
 #pragma unroll 1
     for (int t = 0; t < ksteps; ++t) {
         double reward = 0.0;
@@ -348,8 +366,9 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
 #pragma unroll
                     for (int j = 0; j < NI; ++j) a[j] = hash_action_from_key(key, (uint64_t)(p.t0 + t), 3u, (uint32_t)j);
                 }
+                TICK(0);
                 if (!ROLLOUT && e.nveh < (uint32_t)p.cfg.max_vehicles) d.fill();      // a spawn attempt always draws: fetch the window now
-                term = env_step(e, p.cfg, a, d, reward);
+                term = env_step(e, p.cfg, a, d, reward TICK_PASS);
                 if (!ROLLOUT) d.flush();                          // a rollout keeps its window across steps
                 if (term) {
                     e.episodes += 1;
@@ -363,7 +382,12 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
         const unsigned long long fin_mask = __ballot(live && term && reset_now);
         if (fin_mask && p.final_obs) observe<ROLLOUT>(e, nrows, p.final_obs + i0 * OBS, fin_mask, tile);   // terminal obs (SAME_STEP)
         if (reset_now) e.reset();
+        TICK(5);
         if (p.obs) observe<ROLLOUT>(e, nrows, p.obs + (int64_t)t * p.obs_step_stride + i0 * OBS, ~0ull, tile);
+        TICK(6);
+#ifdef CGE_TRAFFIC_TIMING
+        if (threadIdx.x == 0 && blockIdx.x < 4096) g_timing[blockIdx.x * 16 + 15] += 1;
+#endif
         if (live) {
             if (ROLLOUT) {
                 rsum += reward;
@@ -462,6 +486,18 @@ struct cge_traffic : HandleBase {
 };
 
 extern "C" {
+
+#ifdef CGE_TRAFFIC_TIMING
+int cge_traffic_debug_timing(unsigned long long *out, int clear) {
+    static unsigned long long all[4096 * 16];
+    if (hipMemcpyFromSymbol(all, HIP_SYMBOL(traffic::g_timing), sizeof all) != hipSuccess) return 1;
+    for (int k = 0; k < 16; ++k) out[k] = 0;
+    for (int b = 0; b < 4096; ++b)
+        for (int k = 0; k < 16; ++k) out[k] += all[b * 16 + k];
+    if (clear) { memset(all, 0, sizeof all); if (hipMemcpyToSymbol(HIP_SYMBOL(traffic::g_timing), all, sizeof all) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 
 void cge_traffic_default_config(cge_traffic_config *c) {
     if (c) *c = cge_traffic_config{5, 5, 9, 50, 0.3, 1000, CGE_AUTORESET_NEXT_STEP};

@@ -1,0 +1,19 @@
+"""Per-phase wall-clock of traffic's rollout step (build with -DCGE_TRAFFIC_TIMING into tools/ab/libcge_ttiming.so)."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import custom_gymnasium_environments_amd as cge
+from custom_gymnasium_environments_amd import _native
+L = ctypes.CDLL(_native.LIB_PATH)
+env = cge.TrafficVectorEnv(262144, device="cuda:0")
+env.reset(seed=1)
+buf = (ctypes.c_ulonglong * 16)()
+names = ["actions (hash) + outputs of the previous step", "ensure (window top-up)", "lights", "spawn", "process vehicles + reward", "final_obs / reset", "observe"]
+for chunk in range(3):
+    env.rollout(30, action_seed=7, t0=chunk * 30, trajectory=True)
+    torch.cuda.synchronize()
+    L.cge_traffic_debug_timing(buf, 1)
+    n = max(1, buf[15])
+    print(f"steps {chunk*30}..{chunk*30+29}: wave-steps {buf[15]}, total {sum(buf[k] for k in range(7)) * 10.0 / n / 1e3:.1f} us per wave-step")
+    for k, nm in enumerate(names):
+        print(f"   {nm:48s} {buf[k] * 10.0 / n / 1e3:8.2f} us")
