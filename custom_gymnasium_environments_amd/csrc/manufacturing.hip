@@ -565,6 +565,13 @@ __device__ __forceinline__ void store_rows(int64_t nrows, float *__restrict__ ds
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
+#ifdef CGE_MFG_TIMING
+__device__ unsigned long long g_timing[2048 * 8];
+#define TICK(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = wall_clock64(); \
+    if (threadIdx.x == 0 && blockIdx.x < 2048) { g_timing[blockIdx.x * 8 + k] += now_ - t_last; } t_last = now_; } while (0)
+#else
+#define TICK(k)
+#endif
 template <bool ROLLOUT>
 __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
     __shared__ double lds[64 * ACCROW];                        // accumulators during the slot walk, then the obs tile
@@ -582,6 +589,9 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
     double rsum = 0.0;
     int32_t dcount = 0;
     const int ksteps = ROLLOUT ? p.k_steps : 1;
+#ifdef CGE_MFG_TIMING
+    unsigned long long t_last = wall_clock64();
+#endif
 #pragma unroll 1
     for (int t = 0; t < ksteps; ++t) {
         int32_t reward = 0;
@@ -592,7 +602,9 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
                 do_reset(e);
             } else {
                 const int32_t a = p.actions ? p.actions[(int64_t)t * p.n + i] : (int32_t)hash_action_from_key(key, (uint64_t)(p.t0 + t), 25u, 0u);
+                TICK(0);
                 flags = env_step(e, tb, p.max_steps, a, reward);
+                TICK(1);
                 if (flags) {
                     e.episodes += 1;
                     if (p.ep_ret) p.ep_ret[i] = (double)e.total_reward;    // integer rewards (:291), exact in float64
@@ -608,6 +620,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
             double mean[6];
             type_means(e, tb, live, lds + lane * ACCROW, mean);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            TICK(2);
             if (fin_mask && p.final_obs) {
                 stage_row(e, mean, reinterpret_cast<float *>(tile) + lane * OBS);
                 store_rows(nrows, p.final_obs + i0 * OBS, fin_mask, tile);
@@ -620,6 +633,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
         } else if (reset_now) {
             do_reset(e);
         }
+        TICK(3);
+#ifdef CGE_MFG_TIMING
+        if (threadIdx.x == 0 && blockIdx.x < 2048) g_timing[blockIdx.x * 8 + 7] += 1;
+#endif
         if (live) {
             if (ROLLOUT) {
                 rsum += (double)reward;
@@ -739,6 +756,18 @@ struct cge_manufacturing : HandleBase {
 };
 
 extern "C" {
+
+#ifdef CGE_MFG_TIMING
+int cge_manufacturing_debug_timing(unsigned long long *out, int clear) {
+    static unsigned long long all[2048 * 8];
+    if (hipMemcpyFromSymbol(all, HIP_SYMBOL(mfg::g_timing), sizeof all) != hipSuccess) return 1;
+    for (int k = 0; k < 8; ++k) out[k] = 0;
+    for (int b = 0; b < 2048; ++b)
+        for (int k = 0; k < 8; ++k) out[k] += all[b * 8 + k];
+    if (clear) { memset(all, 0, sizeof all); if (hipMemcpyToSymbol(HIP_SYMBOL(mfg::g_timing), all, sizeof all) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 
 int cge_manufacturing_create(const cge_manufacturing_config *cfg, int64_t n_envs, int device, int64_t env_index0, cge_manufacturing **out) {
     if (!cfg || !out || n_envs <= 0 || env_index0 < 0) return CGE_ERR_INVALID_ARG;

@@ -1,0 +1,18 @@
+"""Per-phase wall-clock of manufacturing's rollout step (build with -DCGE_MFG_TIMING into tools/ab/libcge_mtiming.so)."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import custom_gymnasium_environments_amd as cge
+from custom_gymnasium_environments_amd import _native
+L = ctypes.CDLL(_native.LIB_PATH)
+env = cge.ManufacturingVectorEnv(131072, device="cuda:0")
+env.reset(seed=1)
+buf = (ctypes.c_ulonglong * 8)()
+names = ["action (hash) + outputs of the previous step", "env_step", "type_means", "stage + store rows"]
+for chunk in range(5):
+    env.rollout(50, action_seed=7, t0=chunk * 50, trajectory=True)
+    torch.cuda.synchronize()
+    L.cge_manufacturing_debug_timing(buf, 1)
+    n = max(1, buf[7])
+    print(f"steps {chunk*50}..{chunk*50+49}: wave-steps {buf[7]}, total {sum(buf[k] for k in range(4)) * 10.0 / n / 1e3:.1f} us per wave-step: " +
+          ", ".join(f"{nm} {buf[k] * 10.0 / n / 1e3:.2f}" for k, nm in enumerate(names)))
