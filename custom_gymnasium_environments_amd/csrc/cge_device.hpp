@@ -471,6 +471,155 @@ struct LdsBulkDraws {
     }
 };
 
+// Ring window for fused rollouts: W twisted words per env parked in the lane's LDS row as a circular buffer of MT_PAD-word
+// runs.  A top-up replaces only the runs that were consumed completely — the run goes back to the generator block (four
+// 16-byte stores) and the run W words ahead takes its slots — so every word of the block is fetched once and written once,
+// where LdsDraws<W> refetches the whole window (and re-reads every 128-byte line it straddles) whenever it runs low.
+// ensure() is the wave-convergent top-up for the top of a step; after it at least W - MT_PAD + 1 words are parked.
+// Same (pos, pretw) cursor contract as the other queues: pos is the stream position of the ring's base.
+template <int W>
+struct RingDraws {
+    static_assert(W % MT_PAD == 0 && W >= 2 * MT_PAD && W + 2 * MT_PAD <= MT_N - MT_M, "whole runs; the two runs fetched ahead are independent of the parked ones");
+    static constexpr int NRUN = W / MT_PAD;
+    uint32_t *row, *blk;
+    uint32_t pos, pretw, head, cur;                            // head: slot of the base (a multiple of MT_PAD); cur: words consumed since the base
+    bool filled;
+
+    __device__ __forceinline__ RingDraws(uint32_t *lds_row, uint32_t *block, uint32_t pos_, uint32_t pretw_)
+        : row(lds_row), blk(block), pos(pos_), pretw(pretw_), head(0), cur(0), filled(false) {}
+    // twisted words [logical, logical + MT_PAD) -> slots [slot0, slot0 + MT_PAD)
+    __device__ __forceinline__ void fill_run(uint32_t slot0, uint32_t logical) {
+        MtWindow<MT_PAD> w;
+        uint32_t start = logical;
+        start -= start >= (uint32_t)MT_N ? MT_N : 0;
+        w.load(blk, start);
+#pragma unroll
+        for (int j = 0; j < MT_PAD; ++j) row[slot0 + j] = w.twisted(j, logical, pretw);
+    }
+    // words [logical, logical + count) of the run parked at slot0 go back to the block (count <= MT_PAD)
+    __device__ __forceinline__ void flush_run(uint32_t slot0, uint32_t logical, uint32_t count) {
+        uint32_t kp = logical;
+        kp -= kp >= (uint32_t)MT_N ? MT_N : 0;
+        if (logical + count <= pretw) return;                  // seeded generation: nothing was twisted
+        uint32_t v[MT_PAD];
+#pragma unroll
+        for (int q = 0; q < MT_PAD; ++q) v[q] = row[slot0 + q];
+        if (count == (uint32_t)MT_PAD && logical >= pretw && kp >= (uint32_t)MT_PAD && kp + (uint32_t)MT_PAD <= (uint32_t)MT_N) {
+#pragma unroll
+            for (int q = 0; q < MT_PAD; q += 4) *reinterpret_cast<MtQuad *>(blk + kp + q) = MtQuad{v[q], v[q + 1], v[q + 2], v[q + 3]};
+        } else {
+#pragma unroll
+            for (int q = 0; q < MT_PAD; ++q) {
+                uint32_t k = logical + (uint32_t)q;
+                if ((uint32_t)q < count && k >= pretw) {
+                    k -= k >= (uint32_t)MT_N ? MT_N : 0;
+                    mt_store(blk, k, v[q]);
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ void advance(uint32_t n) {
+        pos += n;
+        if (pos >= (uint32_t)MT_N) { pos -= MT_N; pretw = 0; }
+    }
+    // NB runs per round trip: loads of all of them first, then twist and park
+    template <int NB>
+    __device__ __forceinline__ void fill_runs(uint32_t slot0, uint32_t logical, uint32_t nruns) {
+        MtWindow<MT_PAD> w[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            uint32_t start = logical + (uint32_t)(b * MT_PAD);
+            start -= start >= (uint32_t)MT_N ? MT_N : 0;
+            if ((uint32_t)b < nruns) w[b].load(blk, start);
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if ((uint32_t)b < nruns) {
+                uint32_t sl = slot0 + (uint32_t)(b * MT_PAD);
+                sl -= sl >= (uint32_t)W ? W : 0;
+#pragma unroll
+                for (int j = 0; j < MT_PAD; ++j) row[sl + j] = w[b].twisted(j, logical + (uint32_t)(b * MT_PAD), pretw);
+            }
+        }
+    }
+    __device__ __forceinline__ void fill_all() {
+        constexpr int NB = 3;
+#pragma unroll 1
+        for (int r = 0; r < NRUN; r += NB)
+            fill_runs<NB>((uint32_t)(r * MT_PAD), pos + (uint32_t)(r * MT_PAD), (uint32_t)(NRUN - r < NB ? NRUN - r : NB));
+        head = 0; cur = 0; filled = true;
+    }
+    // every completely consumed run is written back and replaced by the run W words ahead, two runs per round trip
+    __device__ __forceinline__ void top_up() {
+        if (!filled) { fill_all(); return; }
+#pragma unroll 1
+        while (cur >= (uint32_t)MT_PAD) {
+            const uint32_t n = cur >= 2u * MT_PAD ? 2u : 1u;
+            uint32_t h2 = head + (uint32_t)MT_PAD;
+            h2 -= h2 >= (uint32_t)W ? W : 0;
+            flush_run(head, pos, MT_PAD);
+            if (n == 2u) flush_run(h2, pos + (uint32_t)MT_PAD, MT_PAD);
+            fill_runs<2>(head, pos + (uint32_t)W, n);
+            head = n == 2u ? h2 + (uint32_t)MT_PAD : h2;
+            head -= head >= (uint32_t)W ? W : 0;
+            advance(n * MT_PAD);
+            cur -= n * MT_PAD;
+        }
+    }
+    __device__ __forceinline__ void ensure() {                 // wave-convergent: lanes with nothing to do idle through it
+        const bool want = !filled || cur >= (uint32_t)MT_PAD;
+        if (__ballot(want) != 0ull) { if (want) top_up(); }
+    }
+    __device__ __forceinline__ void ensure_inline(uint32_t) { ensure(); }          // the other queues' spellings (need <= W - MT_PAD + 1)
+    __device__ __forceinline__ void ensure(uint32_t) { ensure(); }
+    __device__ __forceinline__ void flush() {                  // end of the rollout: everything consumed goes back, the ring is dropped
+        if (!filled) return;
+#pragma unroll 1
+        while (cur >= (uint32_t)MT_PAD) {
+            flush_run(head, pos, MT_PAD);
+            head = head + (uint32_t)MT_PAD == (uint32_t)W ? 0u : head + (uint32_t)MT_PAD;
+            advance(MT_PAD);
+            cur -= MT_PAD;
+        }
+        if (cur) { flush_run(head, pos, cur); advance(cur); }
+        head = 0; cur = 0; filled = false;
+    }
+    // rare (more than W - MT_PAD words in one step): a real call, by value
+    static __device__ __attribute__((noinline)) uint2 restart(uint32_t *row, uint32_t *blk, uint32_t pos, uint32_t pretw, uint32_t head, uint32_t cur, bool filled) {
+        RingDraws d(row, blk, pos, pretw);
+        d.head = head; d.cur = cur; d.filled = filled;
+        d.flush();
+        d.fill_all();
+        return make_uint2(d.pos, d.pretw);
+    }
+    __device__ __forceinline__ uint32_t slot_of(uint32_t j) const {
+        uint32_t sl = head + cur + j;
+        sl -= sl >= (uint32_t)W ? W : 0;
+        return sl;
+    }
+    __device__ __forceinline__ bool has(uint32_t n) const { return filled && cur + n <= (uint32_t)W; }
+    __device__ __forceinline__ uint32_t peek(uint32_t j) const { return mt_temper(row[slot_of(j)]); }
+    __device__ __forceinline__ void skip(uint32_t n) { cur += n; }
+    __device__ __forceinline__ uint32_t next() {
+        if (!filled || cur == (uint32_t)W) {
+            const uint2 r = restart(row, blk, pos, pretw, head, cur, filled);
+            pos = r.x; pretw = r.y; head = 0; cur = 0; filled = true;
+        }
+        const uint32_t y = mt_temper(row[slot_of(0)]);
+        cur += 1;
+        return y;
+    }
+    __device__ __forceinline__ uint32_t randbelow(uint32_t n, int kbits) {
+        uint32_t r = next() >> (32 - kbits);
+        while (r >= n) r = next() >> (32 - kbits);
+        return r;
+    }
+    __device__ __forceinline__ double random53() {
+        const uint32_t a = next() >> 5, b = next() >> 6;
+        return (a * 67108864.0 + b) / 9007199254740992.0;
+    }
+};
+
 // readlane with a wave-uniform lane index; the builtin is typed int, so cast back before widening
 __device__ __forceinline__ uint32_t lane_u32(uint32_t v, int r) { return (uint32_t)__builtin_amdgcn_readlane((int)v, r); }
 __device__ __forceinline__ uint32_t *lane_ptr(uint32_t lo, uint32_t hi, int r) {

@@ -35,12 +35,14 @@ constexpr int COLS = 48;
 constexpr int C_MISC = 0, C_DOC = 6, C_NUR = 18, C_BED = 31, C_EQ = 41;
 constexpr int NDOC = 15, NNUR = 25, NBED = 40, NEQ = 10, NMED = 15;
 constexpr int RING = 3008;
-// Generator window: 96 words per env parked in LDS, topped up ONCE per step (a step draws ~55-80 words: <= 10 for the
-// arrival, 2-4 per machine, ~1.3 per medicine, 4-6 for the special events).  Round 1 used 16-word windows behind ~20
-// wave-convergent ensure() points per step: 5-8 refills (a flush loop and a memory round trip each) per wave-step.
-constexpr int DW = 96, DROW = DW + 1;
-constexpr uint32_t STEP_WORDS = 88;         // refill at the top of a step unless this many words are left
-using Draws = LdsDrawsCall<DW>;
+// Generator window: a ring of seven 16-word runs per env parked in LDS (RingDraws, cge_device.hpp), topped up ONCE per step:
+// the runs a step consumed completely go back to the block and the runs 112 words ahead take their slots (a step draws
+// ~55-80 words: <= 10 for the arrival, 2-4 per machine, ~1.3 per medicine, 4-6 for the special events; after the top-up at
+// least 97 are parked).  Round 1 used 16-word windows behind ~20 wave-convergent ensure() points per step: 5-8 refills (a
+// flush loop and a memory round trip each) per wave-step.
+constexpr int DW = 112, DROW = DW + 1;
+constexpr uint32_t STEP_WORDS = 88;         // what a step is guaranteed to find parked after the top-up (<= DW - 15)
+using Draws = RingDraws<DW>;
 
 // sub-queues: 0 (E,3) 1 (E,4) 2 (E,5) 3 (ICU,5) 4 (WARD,1) 5 (WARD,2)
 __host__ __device__ constexpr int q_cap(int k) { return k == 0 ? 512 : k == 1 ? 256 : k == 2 ? 64 : k == 3 ? 128 : 1024; }
