@@ -368,6 +368,13 @@ struct LdsDrawsCall {
             pos = r.x; pretw = r.y; cur = 0; filled = true;
         }
     }
+    __device__ __forceinline__ void fill_inline() {            // fill() expanded in place (one site per kernel)
+        LdsDraws<W> d(row, blk, pos, pretw);
+        d.cur = cur; d.filled = filled;
+        d.flush();
+        d.fill();
+        pos = d.pos; pretw = d.pretw; cur = 0; filled = true;
+    }
     // The same top-up with the flush and the fill expanded in place: for the ONE site per step that refills every time (the
     // call costs the callee's register saves and the caller's spills around it, all scratch traffic).
     __device__ __forceinline__ void ensure_inline(uint32_t need) {

@@ -367,7 +367,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
                     for (int j = 0; j < NI; ++j) a[j] = hash_action_from_key(key, (uint64_t)(p.t0 + t), 3u, (uint32_t)j);
                 }
                 TICK(0);
-                if (!ROLLOUT && e.nveh < (uint32_t)p.cfg.max_vehicles) d.fill();      // a spawn attempt always draws: fetch the window now
+                if (!ROLLOUT && e.nveh < (uint32_t)p.cfg.max_vehicles) d.fill_inline();      // a spawn attempt always draws: fetch the window now
                 term = env_step(e, p.cfg, a, d, reward TICK_PASS);
                 if (!ROLLOUT) d.flush();                          // a rollout keeps its window across steps
                 if (term) {
