@@ -25,6 +25,7 @@
 // candles x 64 envs in LDS (row stride 51 dwords -> conflict-free) and streams the 200-byte row
 // segments out with fully used 256-byte store instructions.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -172,8 +173,27 @@ constexpr int KW_P = 48, KW_L = 32, KROW = KW_P + KW_L + 1;
 using RollP = LdsDrawsCall<KW_P>;
 using RollL = LdsDrawsCall<KW_L>;
 
-template <class SP, class SL>
-__device__ __forceinline__ void reset_body(Env &e, const Params &p, int64_t i, int phase, SP &sp, SL &sl) {
+// Where the 50-candle window lives.  HistGlobal: the [50][N] arrays in HBM (step(), the parked-window rollout).  HistLds: the
+// resident rollout's copy in LDS ([50][64] per wave, loaded once per launch), with every new candle also written through to HBM.
+struct HistGlobal {
+    double *closes;
+    float4 *ohlv;
+    int64_t n, i;
+    __device__ __forceinline__ double close(int slot) const { return closes[(int64_t)slot * n + i]; }
+    __device__ __forceinline__ float4 rest(int slot) const { return ohlv[(int64_t)slot * n + i]; }
+    __device__ __forceinline__ void put(int slot, double c, float4 o) const { closes[(int64_t)slot * n + i] = c; ohlv[(int64_t)slot * n + i] = o; }
+};
+struct HistLds {
+    double *lc;            // this lane's column: lc[slot * 64]
+    float4 *lo;
+    HistGlobal g;
+    __device__ __forceinline__ double close(int slot) const { return lc[slot * 64]; }
+    __device__ __forceinline__ float4 rest(int slot) const { return lo[slot * 64]; }
+    __device__ __forceinline__ void put(int slot, double c, float4 o) const { lc[slot * 64] = c; lo[slot * 64] = o; g.put(slot, c, o); }
+};
+
+template <class SP, class SL, class H>
+__device__ __forceinline__ void reset_body(Env &e, const Params &p, H &hist, int phase, SP &sp, SL &sl) {
     e.cash = p.cfg.initial_balance;
     e.cash_kind = 0;
     e.holdings = 0.0;
@@ -193,8 +213,7 @@ __device__ __forceinline__ void reset_body(Env &e, const Params &p, int64_t i, i
         const double hi = price * (1.0 + (1.02 - 1.0) * sp.random53());
         const double lo = price * (0.98 + (1.0 - 0.98) * sp.random53());
         const double op = price * (0.99 + (1.01 - 0.99) * sp.random53());
-        p.closes[(int64_t)slot * p.n + i] = price;
-        p.ohlv[(int64_t)slot * p.n + i] = make_float4((float)op, (float)hi, (float)lo, (float)volume);
+        hist.put(slot, price, make_float4((float)op, (float)hi, (float)lo, (float)volume));
         slot = slot + 1 == HLEN ? 0 : slot + 1;
     }
     e.close = price;
@@ -202,7 +221,8 @@ __device__ __forceinline__ void reset_body(Env &e, const Params &p, int64_t i, i
 __device__ __forceinline__ void do_reset(Env &e, const Params &p, int64_t i, int phase, uint32_t *lds_row) {
     LdsDrawsCall<RW_P> sp(lds_row, p.mtP + i * MT_STRIDE, e.ppos, e.ppretw);
     LdsDrawsCall<RW_L> sl(lds_row + RW_P, p.mtL + i * MT_STRIDE, e.lpos, e.lpretw);
-    reset_body(e, p, i, phase, sp, sl);
+    HistGlobal hist{p.closes, p.ohlv, p.n, i};
+    reset_body(e, p, hist, phase, sp, sl);
     sp.flush(); sl.flush();
     e.ppos = sp.pos; e.ppretw = sp.pretw; e.lpos = sl.pos; e.lpretw = sl.pretw;
 }
@@ -242,17 +262,19 @@ __device__ __forceinline__ void sell_apply(Env &e, const Cfg &c, double qty, dou
 
 // One reference step() (:342-398) for one env; writes the new candle into slot `phase`.
 // Returns terminated; reward in float64.
-// PARKED: the draws come from the rollout's LDS-parked windows (dp / dl hold >= WP / WL words: ensure_inline at the top of the step);
-// otherwise from two register windows loaded here and committed below (dp, dl unused).
-template <bool PARKED>
-__device__ __forceinline__ bool env_step(Env &e, const Params &p, int64_t i, int phase, int32_t a_disc, float a_buy, float a_sell,
-                                         double &reward, RollP &dp, RollL &dl) {
+// MODE 0 (step()): two register windows loaded here and committed below.  MODE 1 (PARKED): the draws come from the rollout's
+// LDS-parked windows (dp / dl hold >= WP / WL words: ensure_inline at the top of the step).  MODE 2 (resident rollout): the register
+// windows arrive loaded — issued at the end of the previous step, ahead of that step's observation stores, so that the in-order
+// vmcnt never makes this step wait for them — and the next step's are issued before returning.
+constexpr int M_STEP = 0, M_PARKED = 1, M_RESIDENT = 2;
+template <int MODE, class H>
+__device__ __forceinline__ bool env_step(Env &e, const Params &p, int64_t i, H &hist, int phase, int32_t a_disc, float a_buy, float a_sell,
+                                         double &reward, RollP &dp, RollL &dl, MtWindow<WP> &wp, MtWindow<WL> &wl) {
+    constexpr bool PARKED = MODE == M_PARKED;
     const Cfg &c = p.cfg;
     uint32_t *__restrict__ blkP = p.mtP + i * MT_STRIDE;
     uint32_t *__restrict__ blkL = p.mtL + i * MT_STRIDE;
-    MtWindow<WP> wp;
-    MtWindow<WL> wl;
-    if constexpr (!PARKED) {
+    if constexpr (MODE == M_STEP) {
         wp.load(blkP, e.ppos);
         if (!e.has_gauss) wl.load(blkL, e.lpos);
     }
@@ -371,9 +393,12 @@ __device__ __forceinline__ bool env_step(Env &e, const Params &p, int64_t i, int
     const double np_ = price_update(e, c, price, volume, g);
     const double hi = np_ * (1.0 + (1.02 - 1.0) * u_hi);          // :353
     const double lo = np_ * (0.98 + (1.0 - 0.98) * u_lo);         // :354
-    p.closes[(int64_t)phase * p.n + i] = np_;                     // append + pop(0), :359-365; open = previous close :355
-    p.ohlv[(int64_t)phase * p.n + i] = make_float4((float)price, (float)hi, (float)lo, (float)volume);
+    hist.put(phase, np_, make_float4((float)price, (float)hi, (float)lo, (float)volume));   // append + pop(0), :359-365; open = previous close :355
     e.close = np_;
+    if constexpr (MODE == M_RESIDENT) {                            // the next step's windows (cursors are final for this step)
+        wp.load(blkP, e.ppos);
+        if (!e.has_gauss) wl.load(blkL, e.lpos);
+    }
     const double pv = e.cash + e.holdings * np_;
     e.step += 1;
     return e.step >= (uint32_t)c.max_steps || pv <= 0.0 || pv >= c.initial_balance * 10.0;   // :382-386
@@ -430,20 +455,20 @@ constexpr int NFULL = HLEN / CH;            // 4 chunks of CH candles ...
 constexpr int CT = HLEN - NFULL * CH;       // ... and 2 candles that travel with the 11 scalar features
 static_assert(CH % 4 == 0 && CT * 5 + 11 == 21 && NFULL * CH * 5 + CT * 5 + 11 == OBS, "column bookkeeping of the observation row");
 
-template <int C, int NC>
-__device__ __forceinline__ void load_candles(const Params &p, int64_t li, int oldest, double (&cl)[CH], float4 (&oh)[CH]) {
+template <int C, int NC, int CHN, class H>
+__device__ __forceinline__ void load_candles(const H &hist, int oldest, double (&cl)[CHN], float4 (&oh)[CHN]) {
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
-        int slot = oldest + C * CH + j;
+        int slot = oldest + C * CHN + j;
         slot -= slot >= HLEN ? HLEN : 0;
-        cl[j] = p.closes[(int64_t)slot * p.n + li];
-        oh[j] = p.ohlv[(int64_t)slot * p.n + li];
+        cl[j] = hist.close(slot);
+        oh[j] = hist.rest(slot);
     }
 }
 
 // candles K0+J.. of the chunk -> observation columns 5*(K0+J).. : the five ratios of a candle (:513-515, [O,H,L,C,V] / current close)
-template <int K0, int J, int NC, int NF>
-__device__ __forceinline__ void ratios(Indicators &ind, double inv, const double (&cl)[CH], const float4 (&oh)[CH], float (&out)[NF]) {
+template <int K0, int J, int NC, int NF, int CHN>
+__device__ __forceinline__ void ratios(Indicators &ind, double inv, const double (&cl)[CHN], const float4 (&oh)[CHN], float (&out)[NF]) {
     if constexpr (J < NC) {
         const double x = cl[J];
         out[5 * J + 0] = (float)((double)oh[J].x * inv);
@@ -452,41 +477,14 @@ __device__ __forceinline__ void ratios(Indicators &ind, double inv, const double
         out[5 * J + 3] = (float)(x * inv);
         out[5 * J + 4] = (float)((double)oh[J].w * inv);
         ind.template close<K0 + J>(x);
-        ratios<K0, J + 1, NC, NF>(ind, inv, cl, oh, out);
+        ratios<K0, J + 1, NC, NF, CHN>(ind, inv, cl, oh, out);
     }
 }
 
 // _get_observation :505-561 for the wave's 64 envs.  `oldest` = slot of logical candle 0.  Rows of
 // lanes whose bit is set in `rowmask` are written to dst (+ row*261 floats).
-__device__ __forceinline__ void observe(const Env &e, const Params &p, int64_t i0, int64_t i, bool live, int oldest,
-                                        float *__restrict__ dst, unsigned long long rowmask, uint32_t *__restrict__ tile) {
-    (void)tile;
-    const uint32_t lane = threadIdx.x & 63u;
-    const int64_t li = live ? i : i0;            // dead lanes of a partial last wave read a valid column, write nothing
-    const bool mine = live && ((rowmask >> lane) & 1ull);
-    float *row = dst + (int64_t)lane * OBS;
-    const double cur = e.close;
-    const double inv = 1.0 / cur;
-    Indicators ind;
-    ind.ef = ind.es = ind.sig = ind.macd = ind.mx = ind.mn = ind.prev = 0.0;
-    ind.pg.res = ind.pl.res = ind.pm.res = 0.0;
-    double cl[CH];
-    float4 oh[CH];
-    load_candles<0, CH>(p, li, oldest, cl, oh);
-    static_assert(NFULL == 4, "the chunk sequence below is written out for 4 full chunks + tail");
-#define CGE_CHUNK(C, NEXT_NC)                                                                           \
-    {                                                                                                   \
-        float out[CH * 5];                                                                              \
-        ratios<C * CH, 0, CH, CH * 5>(ind, inv, cl, oh, out);                                           \
-        load_candles<C + 1, NEXT_NC>(p, li, oldest, cl, oh);          /* next chunk's loads, then */    \
-        store_own_row<CH * 5>(row, C * CH * 5, out, mine);            /* this chunk's 15 stores   */    \
-    }
-    CGE_CHUNK(0, CH) CGE_CHUNK(1, CH) CGE_CHUNK(2, CH) CGE_CHUNK(3, CT)
-#undef CGE_CHUNK
-    // ---- the last CT candles and the 11 scalar features: columns 240..260
-    float tail[CT * 5 + 11];
-    ratios<NFULL * CH, 0, CT, CT * 5 + 11>(ind, inv, cl, oh, tail);
-    float *ft = tail + CT * 5;
+// the 11 scalar features, columns 250..260 (:517-561), from the indicator state after all 50 closes
+__device__ __forceinline__ void scalar_features(const Env &e, const Params &p, const Indicators &ind, double cur, float *ft) {
     const double pv = e.cash + e.holdings * cur;
     ft[0] = e.cash_kind == 1 ? (float)e.cash / (float)p.cfg.initial_balance : (float)(e.cash / p.cfg.initial_balance);   // :524
     ft[1] = (float)(e.holdings * cur / p.cfg.initial_balance);
@@ -520,7 +518,71 @@ __device__ __forceinline__ void observe(const Env &e, const Params &p, int64_t i
         ft[9] = (float)(sma > 0.0 ? (cur - sma) / sma : 0.0);
     }
     ft[10] = (float)e.psych;
+}
+
+__device__ __forceinline__ void observe(const Env &e, const Params &p, int64_t i0, int64_t i, bool live, int oldest,
+                                        float *__restrict__ dst, unsigned long long rowmask, uint32_t *__restrict__ tile) {
+    (void)tile;
+    const uint32_t lane = threadIdx.x & 63u;
+    const int64_t li = live ? i : i0;            // dead lanes of a partial last wave read a valid column, write nothing
+    const bool mine = live && ((rowmask >> lane) & 1ull);
+    float *row = dst + (int64_t)lane * OBS;
+    const double cur = e.close;
+    const double inv = 1.0 / cur;
+    const HistGlobal hist{p.closes, p.ohlv, p.n, li};
+    Indicators ind;
+    ind.ef = ind.es = ind.sig = ind.macd = ind.mx = ind.mn = ind.prev = 0.0;
+    ind.pg.res = ind.pl.res = ind.pm.res = 0.0;
+    double cl[CH];
+    float4 oh[CH];
+    load_candles<0, CH, CH>(hist, oldest, cl, oh);
+    static_assert(NFULL == 4, "the chunk sequence below is written out for 4 full chunks + tail");
+#define CGE_CHUNK(C, NEXT_NC)                                                                           \
+    {                                                                                                   \
+        float out[CH * 5];                                                                              \
+        ratios<C * CH, 0, CH, CH * 5, CH>(ind, inv, cl, oh, out);                                       \
+        load_candles<C + 1, NEXT_NC, CH>(hist, oldest, cl, oh);       /* next chunk's loads, then */    \
+        store_own_row<CH * 5>(row, C * CH * 5, out, mine);            /* this chunk's 15 stores   */    \
+    }
+    CGE_CHUNK(0, CH) CGE_CHUNK(1, CH) CGE_CHUNK(2, CH) CGE_CHUNK(3, CT)
+#undef CGE_CHUNK
+    // ---- the last CT candles and the 11 scalar features: columns 240..260
+    float tail[CT * 5 + 11];
+    ratios<NFULL * CH, 0, CT, CT * 5 + 11, CH>(ind, inv, cl, oh, tail);
+    scalar_features(e, p, ind, cur, tail + CT * 5);
     store_own_row<CT * 5 + 11>(row, NFULL * CH * 5, tail, mine);
+}
+
+// The resident rollout's observation: the candles come from the wave's LDS copy, four at a time (no prefetch buffers to keep
+// alive: 20 floats of row and 4 candles in registers instead of 60 and 12).
+constexpr int RCH = 4;
+static_assert((HLEN - CT) % RCH == 0, "whole chunks before the two candles that travel with the scalar features");
+template <int C>
+__device__ __forceinline__ void resident_chunks(Indicators &ind, double inv, const HistLds &hist, int oldest, float *row, bool mine) {
+    if constexpr (C < (HLEN - CT) / RCH) {
+        double cl[RCH];
+        float4 oh[RCH];
+        load_candles<C, RCH, RCH>(hist, oldest, cl, oh);
+        float out[RCH * 5];
+        ratios<C * RCH, 0, RCH, RCH * 5, RCH>(ind, inv, cl, oh, out);
+        store_own_row<RCH * 5>(row, C * RCH * 5, out, mine);
+        resident_chunks<C + 1>(ind, inv, hist, oldest, row, mine);
+    }
+}
+__device__ __forceinline__ void observe_resident(const Env &e, const Params &p, const HistLds &hist, int oldest, float *row, bool mine) {
+    const double cur = e.close;
+    const double inv = 1.0 / cur;
+    Indicators ind;
+    ind.ef = ind.es = ind.sig = ind.macd = ind.mx = ind.mn = ind.prev = 0.0;
+    ind.pg.res = ind.pl.res = ind.pm.res = 0.0;
+    resident_chunks<0>(ind, inv, hist, oldest, row, mine);
+    double cl[RCH];
+    float4 oh[RCH];
+    load_candles<(HLEN - CT) / RCH, CT, RCH>(hist, oldest, cl, oh);
+    float tail[CT * 5 + 11];
+    ratios<HLEN - CT, 0, CT, CT * 5 + 11, RCH>(ind, inv, cl, oh, tail);
+    scalar_features(e, p, ind, cur, tail + CT * 5);
+    store_own_row<CT * 5 + 11>(row, (HLEN - CT) * 5, tail, mine);
 }
 
 __device__ __forceinline__ void hash_cont(uint64_t key, uint64_t t, float &b, float &s) {
@@ -567,7 +629,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
                     a = p.actions ? reinterpret_cast<const int32_t *>(p.actions)[(int64_t)t * p.n + i]
                                   : (int32_t)hash_action_from_key(key, (uint64_t)(p.t0 + t), 5u, 0u);
                 }
-                term = env_step<ROLLOUT>(e, p, i, phase, a, ab, as, reward, dp, dl);
+                MtWindow<WP> wp;
+                MtWindow<WL> wl;
+                HistGlobal hist{p.closes, p.ohlv, p.n, i};
+                term = env_step<ROLLOUT ? M_PARKED : M_STEP>(e, p, i, hist, phase, a, ab, as, reward, dp, dl, wp, wl);
                 e.ep_return += reward;
                 if (term) {
                     e.episodes += 1;
@@ -584,7 +649,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
 #pragma unroll 1
         for (int pass = (fin_mask && p.final_obs) ? 0 : 1; pass < 2; ++pass) {
             if (pass == 1 && reset_now) {
-                if (ROLLOUT) reset_body(e, p, i, next_phase, dp, dl);
+                if (ROLLOUT) { HistGlobal hist{p.closes, p.ohlv, p.n, i}; reset_body(e, p, hist, next_phase, dp, dl); }
                 else do_reset(e, p, i, next_phase, tile + (threadIdx.x & 63u) * ROW);
             }
             float *dst = pass == 0 ? p.final_obs + i0 * OBS : obs_t;
@@ -614,6 +679,115 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
             if (p.reward_sum) p.reward_sum[i] = rsum;
             if (p.done_count) p.done_count[i] = dcount;
         }
+    }
+}
+
+// ------------------------------------------------------------------ resident rollout
+// k fused steps with the wave's 64 x 50-candle window resident in LDS (76.8 KB: closes [50][64] f64 + ohlv [50][64] float4,
+// two waves per CU): the window is read from HBM once per launch instead of once per step (1,200 of a step's ~2,900 bytes), a
+// step's only loads from memory are its two generator windows — issued at the end of the previous step, ahead of that step's
+// row stores — and the 65 row stores of a step drain while the next step computes.  Every new candle is also written through
+// to the [50][N] arrays, so nothing has to be copied back.  An episode reset (50 candles, ~700 draws) borrows one of four
+// 96-word draw-window slots of the wave (resets are rare: 0.1 % of the env-steps; a fifth simultaneous one waits a round).
+constexpr int RES_SLOTS = 4, RES_SLOT_WORDS = 96;
+constexpr size_t RES_LDS = (size_t)HLEN * 64 * (sizeof(double) + sizeof(float4)) + (size_t)RES_SLOTS * RES_SLOT_WORDS * 4;
+__global__ __launch_bounds__(BLOCK) void resident_kernel(Params p) {
+    extern __shared__ __align__(16) unsigned char res_lds[];
+    const uint32_t lane = threadIdx.x & 63u;
+    double *lc = reinterpret_cast<double *>(res_lds) + lane;
+    float4 *lo = reinterpret_cast<float4 *>(res_lds + (size_t)HLEN * 64 * sizeof(double)) + lane;
+    uint32_t *slots = reinterpret_cast<uint32_t *>(res_lds + (size_t)HLEN * 64 * (sizeof(double) + sizeof(float4)));
+    const int64_t i0 = (int64_t)blockIdx.x * BLOCK;
+    const int64_t i = i0 + threadIdx.x;
+    const bool live = i < p.n;
+    const int64_t li = live ? i : i0;
+    Env e;
+    e.load(p.scal, p.n, li);
+    HistLds hist{lc, lo, HistGlobal{p.closes, p.ohlv, p.n, li}};
+    // the window: HBM -> LDS, ten slots per round trip
+#pragma unroll 1
+    for (int s0 = 0; s0 < HLEN; s0 += 10) {
+        double c[10];
+        float4 o[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) { c[j] = hist.g.close(s0 + j); o[j] = hist.g.rest(s0 + j); }
+#pragma unroll
+        for (int j = 0; j < 10; ++j) { lc[(s0 + j) * 64] = c[j]; lo[(s0 + j) * 64] = o[j]; }
+    }
+    RollP dp(nullptr, nullptr, 0, 0);                          // unused in this mode
+    RollL dl(nullptr, nullptr, 0, 0);
+    uint32_t *__restrict__ blkP = p.mtP + li * MT_STRIDE;
+    uint32_t *__restrict__ blkL = p.mtL + li * MT_STRIDE;
+    MtWindow<WP> wp;
+    MtWindow<WL> wl;
+    wp.load(blkP, e.ppos);
+    if (!e.has_gauss) wl.load(blkL, e.lpos);
+    const uint64_t key = hash_env_key(p.a_seed, (uint64_t)(p.env0 + li));
+    double rsum = 0.0;
+    int32_t dcount = 0;
+    int phase = p.phase;
+#pragma unroll 1
+    for (int t = 0; t < p.k_steps; ++t) {
+        double reward = 0.0;
+        bool term = false, reset_now = false;
+        const int next_phase = phase + 1 == HLEN ? 0 : phase + 1;
+        if (live) {
+            if (p.mode == CGE_AUTORESET_NEXT_STEP && e.needs_reset) {
+                reset_now = true;
+            } else {
+                int32_t a = 0;
+                float ab = 0.0f, as = 0.0f;
+                if (p.cfg.continuous) {
+                    if (p.actions) { const float2 v = reinterpret_cast<const float2 *>(p.actions)[(int64_t)t * p.n + i]; ab = v.x; as = v.y; }
+                    else hash_cont(key, (uint64_t)(p.t0 + t), ab, as);
+                } else {
+                    a = p.actions ? reinterpret_cast<const int32_t *>(p.actions)[(int64_t)t * p.n + i]
+                                  : (int32_t)hash_action_from_key(key, (uint64_t)(p.t0 + t), 5u, 0u);
+                }
+                term = env_step<M_RESIDENT>(e, p, li, hist, phase, a, ab, as, reward, dp, dl, wp, wl);
+                e.ep_return += reward;
+                if (term) {
+                    e.episodes += 1;
+                    if (p.ep_ret) p.ep_ret[i] = e.ep_return;
+                    if (p.ep_len) p.ep_len[i] = (int32_t)e.step;
+                    if (p.mode == CGE_AUTORESET_SAME_STEP) reset_now = true;
+                    else if (p.mode == CGE_AUTORESET_NEXT_STEP) e.needs_reset = 1;
+                }
+            }
+        }
+        // SAME_STEP: the terminal observation of the lanes that just finished goes to final_obs first
+        if (p.final_obs && live && term && reset_now) observe_resident(e, p, hist, next_phase, p.final_obs + i * OBS, true);
+        unsigned long long rm = __ballot(reset_now);
+        if (rm) {
+            // every resetting lane takes one of the wave's draw-window slots, RES_SLOTS lanes per round
+            const uint32_t rank = (uint32_t)__popcll(rm & ((1ull << lane) - 1ull));
+#pragma unroll 1
+            for (uint32_t round = 0; round * RES_SLOTS < (uint32_t)__popcll(rm); ++round) {
+                if (reset_now && rank / RES_SLOTS == round) {
+                    uint32_t *row = slots + (rank % RES_SLOTS) * RES_SLOT_WORDS;
+                    LdsDrawsCall<64> sp(row, blkP, e.ppos, e.ppretw);
+                    LdsDrawsCall<32> sl(row + 64, blkL, e.lpos, e.lpretw);
+                    reset_body(e, p, hist, next_phase, sp, sl);
+                    sp.flush(); sl.flush();
+                    e.ppos = sp.pos; e.ppretw = sp.pretw; e.lpos = sl.pos; e.lpretw = sl.pretw;
+                    wp.load(blkP, e.ppos);                     // the prefetched windows belonged to the finished episode's cursors
+                    if (!e.has_gauss) wl.load(blkL, e.lpos);
+                }
+            }
+        }
+        if (p.obs) observe_resident(e, p, hist, next_phase, p.obs + (int64_t)t * p.obs_step_stride + li * OBS, live);
+        if (live) {
+            rsum += reward;
+            dcount += term ? 1 : 0;
+            if (p.reward) p.reward[(int64_t)t * p.n + i] = (float)reward;
+            if (p.terminated) p.terminated[(int64_t)t * p.n + i] = term ? 1 : 0;
+        }
+        phase = next_phase;
+    }
+    if (live) {
+        e.store(p.scal, p.n, i);
+        if (p.reward_sum) p.reward_sum[i] = rsum;
+        if (p.done_count) p.done_count[i] = dcount;
     }
 }
 
@@ -682,6 +856,7 @@ struct cge_crypto : HandleBase {
     float4 *ohlv = nullptr;
     uint32_t *mtP = nullptr, *mtL = nullptr;
     int phase = 0;
+    bool resident_ready = false;   // resident_kernel's dynamic-LDS limit has been raised
 
     crypto::Params params() const {
         crypto::Params p{};
@@ -805,7 +980,17 @@ int cge_crypto_rollout(cge_crypto *h, int32_t k_steps, const void *actions, uint
     crypto::Params p = h->params();
     p.k_steps = k_steps; p.actions = actions; p.a_seed = action_seed; p.t0 = t0; p.obs = obs_out; p.obs_step_stride = obs_step_stride;
     p.reward = reward_traj_out; p.terminated = terminated_traj_out; p.reward_sum = reward_sum_out; p.done_count = done_count_out;
-    hipLaunchKernelGGL(crypto::step_kernel<true>, dim3(h->blocks()), dim3(crypto::BLOCK), 0, as_stream(stream), p);
+    // k >= 2: the resident kernel (the window is read once per launch); CGE_CRYPTO_RESIDENT=0 keeps the parked-window kernel
+    static const bool resident = [] { const char *v = getenv("CGE_CRYPTO_RESIDENT"); return !v || atoi(v) != 0; }();
+    if (resident && k_steps >= 2) {
+        if (!h->resident_ready) {
+            CGE_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(crypto::resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)crypto::RES_LDS));
+            h->resident_ready = true;
+        }
+        hipLaunchKernelGGL(crypto::resident_kernel, dim3(h->blocks()), dim3(crypto::BLOCK), crypto::RES_LDS, as_stream(stream), p);
+    } else {
+        hipLaunchKernelGGL(crypto::step_kernel<true>, dim3(h->blocks()), dim3(crypto::BLOCK), 0, as_stream(stream), p);
+    }
     CGE_TRY(h, hipGetLastError());
     h->phase = (h->phase + k_steps) % crypto::HLEN;
     return CGE_OK;
