@@ -683,37 +683,104 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
 }
 
 // ------------------------------------------------------------------ resident rollout
-// k fused steps with the wave's 64 x 50-candle window resident in LDS (76.8 KB: closes [50][64] f64 + ohlv [50][64] float4,
-// two waves per CU): the window is read from HBM once per launch instead of once per step (1,200 of a step's ~2,900 bytes), a
-// step's only loads from memory are its two generator windows — issued at the end of the previous step, ahead of that step's
-// row stores — and the 65 row stores of a step drain while the next step computes.  Every new candle is also written through
-// to the [50][N] arrays, so nothing has to be copied back.  An episode reset (50 candles, ~700 draws) borrows one of four
-// 96-word draw-window slots of the wave (resets are rare: 0.1 % of the env-steps; a fifth simultaneous one waits a round).
+// k fused steps with the 64 envs' 50-candle window resident in LDS (76.8 KB: closes [50][64] f64 + ohlv [50][64] float4): the
+// window is read from HBM once per launch instead of once per step (1,200 of a step's ~2,900 bytes), and every new candle is
+// also written through to the [50][N] arrays, so nothing has to be copied back.  LDS allows two such windows per CU; with one
+// wave per window (measured: 580 us per 1M-env step against 667 streaming) half of the CU's SIMDs idle while each wave issues
+// ~5,500 mostly float64 instructions per step.  So a workgroup is TWO waves over the same 64 envs and the same window (559 us):
+// wave A steps the market (env_step, generator windows, rewards, resets), wave B turns the window into the 261-column
+// observation row — and B's observation of step t overlaps A's dynamics of step t+1.  Hand-over per step, two barriers:
+//   bar1: B has finished reading window(t-1), A holds step t's new candle in registers;
+//         A then puts the candle and the scalars B needs (cash, holdings, psychology, close, flags) into LDS;
+//   bar2: window(t) is complete: B observes it while A goes on to step t+1.
+// A step in which any env of the wave resets takes two more barriers (B: terminal rows -> final_obs; A: the 50-candle resets into
+// the LDS window; B: the reset rows), so it is not pipelined; it is 6 % of the wave-steps in steady state.
+// A step's only loads from memory are wave A's two generator windows, issued at the end of the previous step.  An episode reset
+// (50 candles, ~700 draws) borrows one of four 96-word draw-window slots of the workgroup (resets are rare: 0.1 % of the
+// env-steps; a fifth simultaneous one waits a round).
 constexpr int RES_SLOTS = 4, RES_SLOT_WORDS = 96;
-constexpr size_t RES_LDS = (size_t)HLEN * 64 * (sizeof(double) + sizeof(float4)) + (size_t)RES_SLOTS * RES_SLOT_WORDS * 4;
-__global__ __launch_bounds__(BLOCK) void resident_kernel(Params p) {
+struct HistDefer {                                             // wave A's view during env_step: the candle waits in registers for bar1
+    double c;
+    float4 o;
+    int slot;
+    HistGlobal g;
+    __device__ __forceinline__ void put(int s, double cc, float4 oo) { slot = s; c = cc; o = oo; g.put(s, cc, oo); }
+};
+constexpr size_t RES2_HIST = (size_t)HLEN * 64 * (sizeof(double) + sizeof(float4));
+constexpr size_t RES2_MAIL = 4 * 64 * sizeof(double) + 64 * sizeof(uint32_t) + 16;
+constexpr size_t RES2_LDS = RES2_HIST + RES2_MAIL + (size_t)RES_SLOTS * RES_SLOT_WORDS * 4;
+enum : uint32_t { DEST_NONE = 0u, DEST_OBS = 1u, DEST_FINAL = 2u };
+#ifdef CGE_CRYPTO_TIMING
+__device__ unsigned long long g_timing[16384 * 8];
+#define TICK(k) do { const unsigned long long now_ = wall_clock64(); if (lane == 0) { g_timing[blockIdx.x * 8 + k] += now_ - t_last; } t_last = now_; } while (0)
+#else
+#define TICK(k)
+#endif
+__global__ __launch_bounds__(2 * BLOCK) void resident_kernel(Params p) {
     extern __shared__ __align__(16) unsigned char res_lds[];
     const uint32_t lane = threadIdx.x & 63u;
+    const bool observer = threadIdx.x >= 64u;                  // wave-uniform
     double *lc = reinterpret_cast<double *>(res_lds) + lane;
     float4 *lo = reinterpret_cast<float4 *>(res_lds + (size_t)HLEN * 64 * sizeof(double)) + lane;
-    uint32_t *slots = reinterpret_cast<uint32_t *>(res_lds + (size_t)HLEN * 64 * (sizeof(double) + sizeof(float4)));
+    double *mail = reinterpret_cast<double *>(res_lds + RES2_HIST) + lane;                       // [4][64]: cash, holdings, psych, close
+    uint32_t *mailu = reinterpret_cast<uint32_t *>(res_lds + RES2_HIST + 4 * 64 * sizeof(double)) + lane;   // cash_kind | dest << 2 | reset << 4
+    uint32_t *waveflag = reinterpret_cast<uint32_t *>(res_lds + RES2_HIST + 4 * 64 * sizeof(double) + 64 * sizeof(uint32_t));
+    uint32_t *slots = reinterpret_cast<uint32_t *>(res_lds + RES2_HIST + RES2_MAIL);
     const int64_t i0 = (int64_t)blockIdx.x * BLOCK;
-    const int64_t i = i0 + threadIdx.x;
+    const int64_t i = i0 + lane;
     const bool live = i < p.n;
     const int64_t li = live ? i : i0;
+    HistLds hist{lc, lo, HistGlobal{p.closes, p.ohlv, p.n, li}};
+    {   // the window: HBM -> LDS, each wave half of the slots
+        const int s_lo = observer ? HLEN / 2 : 0;
+#pragma unroll 1
+        for (int s0 = s_lo; s0 < s_lo + HLEN / 2; s0 += 5) {
+            double c[5];
+            float4 o[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) { c[j] = hist.g.close(s0 + j); o[j] = hist.g.rest(s0 + j); }
+#pragma unroll
+            for (int j = 0; j < 5; ++j) { lc[(s0 + j) * 64] = c[j]; lo[(s0 + j) * 64] = o[j]; }
+        }
+    }
+    int phase = p.phase;
+#ifdef CGE_CRYPTO_TIMING
+    unsigned long long t_last = wall_clock64();
+#endif
+    if (observer) {
+        // ---------------- wave B
+        Env v;                                                 // only the fields the observation reads
+        v.cash = v.holdings = v.psych = v.close = 0.0; v.cash_kind = 0;
+#pragma unroll 1
+        for (int t = 0; t < p.k_steps; ++t) {
+            const int next_phase = phase + 1 == HLEN ? 0 : phase + 1;
+            __syncthreads();                                   // bar1
+            __syncthreads();                                   // bar2
+            TICK(4);
+            const uint32_t u = *mailu;
+            const bool slow = *waveflag != 0u;
+            v.cash = mail[0]; v.holdings = mail[64]; v.psych = mail[128]; v.close = mail[192]; v.cash_kind = u & 3u;
+            const uint32_t dest = (u >> 2) & 3u;
+            float *obs_row = p.obs ? p.obs + (int64_t)t * p.obs_step_stride + li * OBS : nullptr;
+            float *row = dest == DEST_FINAL ? p.final_obs + li * OBS : obs_row;
+            const bool want = dest != DEST_NONE && row != nullptr;
+            if (__ballot(want)) observe_resident(v, p, hist, next_phase, want ? row : obs_row, want);
+            TICK(5);
+            if (slow) {
+                __syncthreads();                               // bar3: the pre-reset rows are out, A may rewrite the window
+                __syncthreads();                               // bar4: the fresh windows are in LDS
+                const bool again = ((*mailu >> 4) & 1u) != 0u && obs_row != nullptr;
+                v.cash = mail[0]; v.holdings = mail[64]; v.psych = mail[128]; v.close = mail[192]; v.cash_kind = *mailu & 3u;
+                if (__ballot(again)) observe_resident(v, p, hist, next_phase, obs_row, again);
+            }
+            phase = next_phase;
+        }
+        __syncthreads();                                       // A's closing barrier
+        return;
+    }
+    // ---------------- wave A
     Env e;
     e.load(p.scal, p.n, li);
-    HistLds hist{lc, lo, HistGlobal{p.closes, p.ohlv, p.n, li}};
-    // the window: HBM -> LDS, ten slots per round trip
-#pragma unroll 1
-    for (int s0 = 0; s0 < HLEN; s0 += 10) {
-        double c[10];
-        float4 o[10];
-#pragma unroll
-        for (int j = 0; j < 10; ++j) { c[j] = hist.g.close(s0 + j); o[j] = hist.g.rest(s0 + j); }
-#pragma unroll
-        for (int j = 0; j < 10; ++j) { lc[(s0 + j) * 64] = c[j]; lo[(s0 + j) * 64] = o[j]; }
-    }
     RollP dp(nullptr, nullptr, 0, 0);                          // unused in this mode
     RollL dl(nullptr, nullptr, 0, 0);
     uint32_t *__restrict__ blkP = p.mtP + li * MT_STRIDE;
@@ -725,12 +792,12 @@ __global__ __launch_bounds__(BLOCK) void resident_kernel(Params p) {
     const uint64_t key = hash_env_key(p.a_seed, (uint64_t)(p.env0 + li));
     double rsum = 0.0;
     int32_t dcount = 0;
-    int phase = p.phase;
 #pragma unroll 1
     for (int t = 0; t < p.k_steps; ++t) {
         double reward = 0.0;
-        bool term = false, reset_now = false;
+        bool term = false, reset_now = false, stepped = false;
         const int next_phase = phase + 1 == HLEN ? 0 : phase + 1;
+        HistDefer pend{0.0, make_float4(0.f, 0.f, 0.f, 0.f), phase, HistGlobal{p.closes, p.ohlv, p.n, li}};
         if (live) {
             if (p.mode == CGE_AUTORESET_NEXT_STEP && e.needs_reset) {
                 reset_now = true;
@@ -738,13 +805,14 @@ __global__ __launch_bounds__(BLOCK) void resident_kernel(Params p) {
                 int32_t a = 0;
                 float ab = 0.0f, as = 0.0f;
                 if (p.cfg.continuous) {
-                    if (p.actions) { const float2 v = reinterpret_cast<const float2 *>(p.actions)[(int64_t)t * p.n + i]; ab = v.x; as = v.y; }
+                    if (p.actions) { const float2 vv = reinterpret_cast<const float2 *>(p.actions)[(int64_t)t * p.n + i]; ab = vv.x; as = vv.y; }
                     else hash_cont(key, (uint64_t)(p.t0 + t), ab, as);
                 } else {
                     a = p.actions ? reinterpret_cast<const int32_t *>(p.actions)[(int64_t)t * p.n + i]
                                   : (int32_t)hash_action_from_key(key, (uint64_t)(p.t0 + t), 5u, 0u);
                 }
-                term = env_step<M_RESIDENT>(e, p, li, hist, phase, a, ab, as, reward, dp, dl, wp, wl);
+                term = env_step<M_RESIDENT>(e, p, li, pend, phase, a, ab, as, reward, dp, dl, wp, wl);
+                stepped = true;
                 e.ep_return += reward;
                 if (term) {
                     e.episodes += 1;
@@ -755,11 +823,21 @@ __global__ __launch_bounds__(BLOCK) void resident_kernel(Params p) {
                 }
             }
         }
-        // SAME_STEP: the terminal observation of the lanes that just finished goes to final_obs first
-        if (p.final_obs && live && term && reset_now) observe_resident(e, p, hist, next_phase, p.final_obs + i * OBS, true);
-        unsigned long long rm = __ballot(reset_now);
+        TICK(0);
+        const unsigned long long rm = __ballot(reset_now);
+        // rows of this step: a SAME_STEP terminal row goes to final_obs (and the reset row to obs afterwards), a NEXT_STEP
+        // reset-only row only exists after the reset
+        const uint32_t dest = !live ? DEST_NONE : (term && reset_now) ? (p.final_obs ? DEST_FINAL : DEST_NONE) : reset_now ? DEST_NONE : DEST_OBS;
+        __syncthreads();                                       // bar1: B is done with window(t-1)
+        TICK(1);
+        if (stepped) { lc[pend.slot * 64] = pend.c; lo[pend.slot * 64] = pend.o; }
+        mail[0] = e.cash; mail[64] = e.holdings; mail[128] = e.psych; mail[192] = e.close;
+        *mailu = e.cash_kind | (dest << 2) | ((reset_now ? 1u : 0u) << 4);
+        if (lane == 0) *waveflag = rm ? 1u : 0u;
+        __syncthreads();                                       // bar2: window(t) is complete
+        TICK(2);
         if (rm) {
-            // every resetting lane takes one of the wave's draw-window slots, RES_SLOTS lanes per round
+            __syncthreads();                                   // bar3
             const uint32_t rank = (uint32_t)__popcll(rm & ((1ull << lane) - 1ull));
 #pragma unroll 1
             for (uint32_t round = 0; round * RES_SLOTS < (uint32_t)__popcll(rm); ++round) {
@@ -772,18 +850,25 @@ __global__ __launch_bounds__(BLOCK) void resident_kernel(Params p) {
                     e.ppos = sp.pos; e.ppretw = sp.pretw; e.lpos = sl.pos; e.lpretw = sl.pretw;
                     wp.load(blkP, e.ppos);                     // the prefetched windows belonged to the finished episode's cursors
                     if (!e.has_gauss) wl.load(blkL, e.lpos);
+                    mail[0] = e.cash; mail[64] = e.holdings; mail[128] = e.psych; mail[192] = e.close;
+                    *mailu = e.cash_kind | (1u << 4);
                 }
             }
+            __syncthreads();                                   // bar4
         }
-        if (p.obs) observe_resident(e, p, hist, next_phase, p.obs + (int64_t)t * p.obs_step_stride + li * OBS, live);
         if (live) {
             rsum += reward;
             dcount += term ? 1 : 0;
             if (p.reward) p.reward[(int64_t)t * p.n + i] = (float)reward;
             if (p.terminated) p.terminated[(int64_t)t * p.n + i] = term ? 1 : 0;
         }
+        TICK(3);
+#ifdef CGE_CRYPTO_TIMING
+        if (lane == 0) g_timing[blockIdx.x * 8 + 7] += 1;
+#endif
         phase = next_phase;
     }
+    __syncthreads();                                           // B's last observation is out
     if (live) {
         e.store(p.scal, p.n, i);
         if (p.reward_sum) p.reward_sum[i] = rsum;
@@ -874,6 +959,18 @@ struct cge_crypto : HandleBase {
 };
 
 extern "C" {
+
+#ifdef CGE_CRYPTO_TIMING
+int cge_crypto_debug_timing(unsigned long long *out, int clear) {
+    static unsigned long long all[16384 * 8];
+    if (hipMemcpyFromSymbol(all, HIP_SYMBOL(crypto::g_timing), sizeof all) != hipSuccess) return 1;
+    for (int k = 0; k < 8; ++k) out[k] = 0;
+    for (int b = 0; b < 16384; ++b)
+        for (int k = 0; k < 8; ++k) out[k] += all[b * 8 + k];
+    if (clear) { memset(all, 0, sizeof all); if (hipMemcpyToSymbol(HIP_SYMBOL(crypto::g_timing), all, sizeof all) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 
 void cge_crypto_default_config(cge_crypto_config *c) {
     if (!c) return;
@@ -980,14 +1077,14 @@ int cge_crypto_rollout(cge_crypto *h, int32_t k_steps, const void *actions, uint
     crypto::Params p = h->params();
     p.k_steps = k_steps; p.actions = actions; p.a_seed = action_seed; p.t0 = t0; p.obs = obs_out; p.obs_step_stride = obs_step_stride;
     p.reward = reward_traj_out; p.terminated = terminated_traj_out; p.reward_sum = reward_sum_out; p.done_count = done_count_out;
-    // k >= 2: the resident kernel (the window is read once per launch); CGE_CRYPTO_RESIDENT=0 keeps the parked-window kernel
+    // k >= 2: the resident kernel (the window is read once per launch); CGE_CRYPTO_RESIDENT=0 keeps the streaming kernel
     static const bool resident = [] { const char *v = getenv("CGE_CRYPTO_RESIDENT"); return !v || atoi(v) != 0; }();
     if (resident && k_steps >= 2) {
         if (!h->resident_ready) {
-            CGE_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(crypto::resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)crypto::RES_LDS));
+            CGE_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(crypto::resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)crypto::RES2_LDS));
             h->resident_ready = true;
         }
-        hipLaunchKernelGGL(crypto::resident_kernel, dim3(h->blocks()), dim3(crypto::BLOCK), crypto::RES_LDS, as_stream(stream), p);
+        hipLaunchKernelGGL(crypto::resident_kernel, dim3(h->blocks()), dim3(2 * crypto::BLOCK), crypto::RES2_LDS, as_stream(stream), p);
     } else {
         hipLaunchKernelGGL(crypto::step_kernel<true>, dim3(h->blocks()), dim3(crypto::BLOCK), 0, as_stream(stream), p);
     }
