@@ -163,6 +163,38 @@ def test_rollout_matches_oracle(cge, oracle):
     env.close(); twin.close()
 
 
+@pytest.mark.parametrize("kind,mode", [("discrete", "SameStep"), ("discrete", "NextStep"), ("continuous", "SameStep"),
+                                       ("continuous", "NextStep"), ("discrete", "Disabled")])
+def test_resident_rollout_equals_step_by_step_through_resets(cge, kind, mode):
+    """The fused rollout's resident kernel (two waves per 64 envs around an LDS candle window, csrc/crypto.hip) against the
+    step() kernel on a twin, value for value: a 13-step time limit puts several in-kernel episode resets (the non-pipelined
+    four-barrier step), NEXT_STEP's reset-only steps and ragged last workgroups into 60 fused steps."""
+    n, k = 64 * 3 + 5, 60
+    kw = dict(action_type=kind, autoreset_mode=mode, env_index0=3, max_steps=13)
+    env, twin = cge.CryptoVectorEnv(n, **kw), cge.CryptoVectorEnv(n, **kw)
+    env.reset(seed=11); twin.reset(seed=11)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    if kind == "continuous":
+        acts = torch.rand((k, n, 2), generator=g, device="cuda", dtype=torch.float32) * 2 - 1
+    else:
+        acts = torch.randint(0, 5, (k, n), generator=g, dtype=torch.int32, device="cuda")
+    traj, rt, tt, rs, dc = env.rollout(k, actions=acts, trajectory=True, per_step=True)
+    done_total = 0
+    for t in range(k):
+        ob, r, te, tr, _ = twin.step(acts[t])
+        flags = te.to(torch.uint8) | (tr.to(torch.uint8) << 1)
+        assert torch.equal(flags, tt[t]), t
+        assert torch.equal(r, rt[t]), t
+        assert torch.equal(ob, traj[t]), t
+        done_total += int((te | tr).sum())
+        if mode == "Disabled" and bool((te | tr).any()):
+            break                                             # gymnasium leaves stepping a finished env undefined
+    if mode != "Disabled":
+        assert done_total >= 3 * n                            # every env went through several resets
+        assert np.array_equal(env.get_state(), twin.get_state())
+    env.close(); twin.close()
+
+
 def test_million_env_config_sampled_parity(cge, oracle):
     """BASELINE config 3: 1,048,576 envs, discrete, 1,060 fused steps — every env passes its 1,000-step limit (or ends earlier
     on the portfolio bounds) and is re-initialised INSIDE the kernel (the 50-candle reset, crypto_trading_env.py:301-340).
