@@ -17,3 +17,15 @@ for chunk in range(3):
     print(f"steps {chunk*30}..{chunk*30+29}: wave-steps {buf[15]}, total {sum(buf[k] for k in range(7)) * 10.0 / n / 1e3:.1f} us per wave-step")
     for k, nm in enumerate(names):
         print(f"   {nm:48s} {buf[k] * 10.0 / n / 1e3:8.2f} us")
+
+# the step() path (one launch per step: record load, 16-word window fill and flush, LDS-staged rows)
+acts = torch.randint(0, 3, (262144, 9), dtype=torch.int32, device="cuda")
+L.cge_traffic_debug_timing(buf, 1)
+for _ in range(30):
+    env.step(acts)
+torch.cuda.synchronize()
+L.cge_traffic_debug_timing(buf, 1)
+n = max(1, buf[15])
+print(f"step() x 30: wave-steps {buf[15]}, total {sum(buf[k] for k in range(7)) * 10.0 / n / 1e3:.1f} us per wave-step (slot 0 includes the record load and the window fill)")
+for k, nm in enumerate(names):
+    print(f"   {nm:48s} {buf[k] * 10.0 / n / 1e3:8.2f} us")
