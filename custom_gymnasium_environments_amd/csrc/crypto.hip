@@ -184,12 +184,17 @@ struct HistGlobal {
     __device__ __forceinline__ void put(int slot, double c, float4 o) const { closes[(int64_t)slot * n + i] = c; ohlv[(int64_t)slot * n + i] = o; }
 };
 struct HistLds {
-    double *lc;            // this lane's column: lc[slot * 64]
-    float4 *lo;
+    // [50][64] with the env index XOR-swizzled by the slot: a wave reading one slot for its 64 envs (lane = env) and a wave reading
+    // 50 slots of ONE env (lane = candle, the row writer) are both spread over the banks
+    double *lcb;
+    float4 *lob;
+    uint32_t lane;
     HistGlobal g;
-    __device__ __forceinline__ double close(int slot) const { return lc[slot * 64]; }
-    __device__ __forceinline__ float4 rest(int slot) const { return lo[slot * 64]; }
-    __device__ __forceinline__ void put(int slot, double c, float4 o) const { lc[slot * 64] = c; lo[slot * 64] = o; g.put(slot, c, o); }
+    static __device__ __forceinline__ int at(int slot, uint32_t env) { return slot * 64 + (int)(env ^ ((uint32_t)slot & 31u)); }
+    __device__ __forceinline__ double close(int slot) const { return lcb[at(slot, lane)]; }
+    __device__ __forceinline__ float4 rest(int slot) const { return lob[at(slot, lane)]; }
+    __device__ __forceinline__ void put_lds(int slot, double c, float4 o) const { lcb[at(slot, lane)] = c; lob[at(slot, lane)] = o; }
+    __device__ __forceinline__ void put(int slot, double c, float4 o) const { put_lds(slot, c, o); g.put(slot, c, o); }
 };
 
 template <class SP, class SL, class H>
@@ -266,10 +271,14 @@ __device__ __forceinline__ void sell_apply(Env &e, const Cfg &c, double qty, dou
 // LDS-parked windows (dp / dl hold >= WP / WL words: ensure_inline at the top of the step).  MODE 2 (resident rollout): the register
 // windows arrive loaded — issued at the end of the previous step, ahead of that step's observation stores, so that the in-order
 // vmcnt never makes this step wait for them — and the next step's are issued before returning.
-constexpr int M_STEP = 0, M_PARKED = 1, M_RESIDENT = 2;
+constexpr int M_STEP = 0, M_PARKED = 1, M_RESIDENT = 2, M_SPLIT = 3;
+// M_SPLIT (resident rollout, wave A): env_step stops after the P-stream section — trade, volume, regime, the high / low uniforms, P
+// commit and the prefetch of the next P window — and hands these out; the step is completed by finish_step() once the gaussian
+// (drawn by another wave) is there.
+struct SplitOut { double price, volume, u_hi, u_lo; };
 template <int MODE, class H>
 __device__ __forceinline__ bool env_step(Env &e, const Params &p, int64_t i, H &hist, int phase, int32_t a_disc, float a_buy, float a_sell,
-                                         double &reward, RollP &dp, RollL &dl, MtWindow<WP> &wp, MtWindow<WL> &wl) {
+                                         double &reward, RollP &dp, RollL &dl, MtWindow<WP> &wp, MtWindow<WL> &wl, SplitOut *so = nullptr) {
     constexpr bool PARKED = MODE == M_PARKED;
     const Cfg &c = p.cfg;
     uint32_t *__restrict__ blkP = p.mtP + i * MT_STRIDE;
@@ -342,6 +351,11 @@ __device__ __forceinline__ bool env_step(Env &e, const Params &p, int64_t i, H &
         if constexpr (PARKED) dp.skip(2u * (tq + 4u));
         else wp.commit(blkP, e.ppos, e.ppretw, 2u * (tq + 4u));
     }
+    if constexpr (MODE == M_SPLIT) {
+        so->price = price; so->volume = volume; so->u_hi = u_hi; so->u_lo = u_lo;
+        wp.load(blkP, e.ppos);                                     // the next step's P window (its cursor is final)
+        return false;
+    }
     // ---- gaussian (family L): cached half, or up to two polar attempts from the window, else serial
     double g;
     if (e.has_gauss) {
@@ -402,6 +416,62 @@ __device__ __forceinline__ bool env_step(Env &e, const Params &p, int64_t i, H &
     const double pv = e.cash + e.holdings * np_;
     e.step += 1;
     return e.step >= (uint32_t)c.max_steps || pv <= 0.0 || pv >= c.initial_balance * 10.0;   // :382-386
+}
+
+// second half of a split step: price, candle, termination (the tail of env_step above)
+template <class H>
+__device__ __forceinline__ bool finish_step(Env &e, const Params &p, H &hist, int phase, const SplitOut &so, double g) {
+    const Cfg &c = p.cfg;
+    const double np_ = price_update(e, c, so.price, so.volume, g);
+    const double hi = np_ * (1.0 + (1.02 - 1.0) * so.u_hi);       // :353
+    const double lo = np_ * (0.98 + (1.0 - 0.98) * so.u_lo);      // :354
+    hist.put(phase, np_, make_float4((float)so.price, (float)hi, (float)lo, (float)so.volume));
+    e.close = np_;
+    const double pv = e.cash + e.holdings * np_;
+    e.step += 1;
+    return e.step >= (uint32_t)c.max_steps || pv <= 0.0 || pv >= c.initial_balance * 10.0;   // :382-386
+}
+
+// one legacy_gauss() value from the NumPy stream whose state (cursor, cached half) is in `e`: the gaussian block of env_step for a
+// wave that owns nothing but that stream
+__device__ __forceinline__ double draw_gauss(Env &e, uint32_t *__restrict__ blkL) {
+    if (e.has_gauss) {
+        e.has_gauss = 0;
+        const double g = e.gauss;
+        e.gauss = 0.0;
+        return g;
+    }
+    MtWindow<WL> wl;
+    wl.load(blkL, e.lpos);
+    uint32_t lw[WL];
+#pragma unroll
+    for (int j = 0; j < WL; ++j) lw[j] = wl.draw(j, e.lpos, e.lpretw);
+    double x1 = 2.0 * u53(lw[0], lw[1]) - 1.0;
+    double x2 = 2.0 * u53(lw[2], lw[3]) - 1.0;
+    double r2 = x1 * x1 + x2 * x2;
+    uint32_t used = 4;
+    bool ok = !(r2 >= 1.0 || r2 == 0.0);
+    if (!ok) {
+        x1 = 2.0 * u53(lw[4], lw[5]) - 1.0;
+        x2 = 2.0 * u53(lw[6], lw[7]) - 1.0;
+        r2 = x1 * x1 + x2 * x2;
+        used = 8;
+        ok = !(r2 >= 1.0 || r2 == 0.0);
+    }
+    wl.commit(blkL, e.lpos, e.lpretw, used);
+    if (!ok) {
+        MtStream sl(blkL, e.lpos, e.lpretw);
+        do {
+            x1 = 2.0 * sl.random53() - 1.0;
+            x2 = 2.0 * sl.random53() - 1.0;
+            r2 = x1 * x1 + x2 * x2;
+        } while (r2 >= 1.0 || r2 == 0.0);
+        e.lpos = sl.pos; e.lpretw = sl.pretw;
+    }
+    const double f = sqrt(-2.0 * log(r2) / r2);
+    e.gauss = f * x1;
+    e.has_gauss = 1;
+    return f * x2;
 }
 
 // NumPy pairwise sum of 14 / 20 float64 values (loops_utils.h.src): 8 running partials, a balanced
@@ -557,32 +627,62 @@ __device__ __forceinline__ void observe(const Env &e, const Params &p, int64_t i
 // alive: 20 floats of row and 4 candles in registers instead of 60 and 12).
 constexpr int RCH = 4;
 static_assert((HLEN - CT) % RCH == 0, "whole chunks before the two candles that travel with the scalar features");
-template <int C>
-__device__ __forceinline__ void resident_chunks(Indicators &ind, double inv, const HistLds &hist, int oldest, float *row, bool mine) {
-    if constexpr (C < (HLEN - CT) / RCH) {
-        double cl[RCH];
-        float4 oh[RCH];
-        load_candles<C, RCH, RCH>(hist, oldest, cl, oh);
-        float out[RCH * 5];
-        ratios<C * RCH, 0, RCH, RCH * 5, RCH>(ind, inv, cl, oh, out);
-        store_own_row<RCH * 5>(row, C * RCH * 5, out, mine);
-        resident_chunks<C + 1>(ind, inv, hist, oldest, row, mine);
+// mailbox word of an env in the resident rollout: cash_kind (2 bits) | dest << 2 | this lane resets | it steps next (draw its gaussian)
+enum : uint32_t { DEST_NONE = 0u, DEST_OBS = 1u, DEST_FINAL = 2u };
+enum : uint32_t { F_RESET = 1u << 4, F_DRAW_NEXT = 1u << 5 };
+// Rows in the resident rollout.  Wave B (lane = env) streams the 50 closes through the indicators and writes the 11 scalar
+// features, columns 250..260.  Wave C writes the 250 ratio columns ROW BY ROW: lane c < 50 takes candle c of one env, so the row's
+// 1,000 bytes leave as one contiguous run (a 16-byte and a 4-byte store per lane) instead of every lane scattering 16-byte
+// pieces of its own row 1,044 bytes apart — with all arithmetic left in place and only the scattered stores removed the whole
+// kernel took 229 us per 1M-env step instead of 593 (tools/probes/crypto_noobs.py): the store pattern was the step.
+template <int K, int KEND>
+__device__ __forceinline__ void feed_closes(Indicators &ind, const HistLds &hist, int oldest) {
+    if constexpr (K < KEND) {
+        int slot = oldest + K;
+        slot -= slot >= HLEN ? HLEN : 0;
+        ind.template close<K>(hist.close(slot));
+        feed_closes<K + 1, KEND>(ind, hist, oldest);
     }
 }
-__device__ __forceinline__ void observe_resident(const Env &e, const Params &p, const HistLds &hist, int oldest, float *row, bool mine) {
-    const double cur = e.close;
-    const double inv = 1.0 / cur;
+__device__ __forceinline__ void features_resident(const Env &e, const Params &p, const HistLds &hist, int oldest, float *row, bool mine) {
     Indicators ind;
     ind.ef = ind.es = ind.sig = ind.macd = ind.mx = ind.mn = ind.prev = 0.0;
     ind.pg.res = ind.pl.res = ind.pm.res = 0.0;
-    resident_chunks<0>(ind, inv, hist, oldest, row, mine);
-    double cl[RCH];
-    float4 oh[RCH];
-    load_candles<(HLEN - CT) / RCH, CT, RCH>(hist, oldest, cl, oh);
-    float tail[CT * 5 + 11];
-    ratios<HLEN - CT, 0, CT, CT * 5 + 11, RCH>(ind, inv, cl, oh, tail);
-    scalar_features(e, p, ind, cur, tail + CT * 5);
-    store_own_row<CT * 5 + 11>(row, (HLEN - CT) * 5, tail, mine);
+    feed_closes<0, HLEN>(ind, hist, oldest);
+    float ft[11];
+    scalar_features(e, p, ind, e.close, ft);
+    store_own_row<11>(row, HLEN * 5, ft, mine);
+}
+// The (env, candle) pairs of envs [env_lo, env_hi) are dealt to the 64 lanes as one stream (pair q -> env q / 50, candle q % 50), so
+// all lanes work and consecutive lanes write consecutive 20-byte pieces (a row's 1,000 bytes, then the next row's).  Only rows
+// whose mailbox word has all bits of `need` and a destination are written (to obs only if to_obs_only).  flagsv: the workgroup's
+// mailbox words; closes: its current closes; inv: 64 doubles of scratch for 1 / close; base_*: row 0 of the workgroup (or null).
+__device__ __forceinline__ void ratio_rows_resident(const HistLds &hist, int oldest, const uint32_t *flagsv, const double *closes, double *inv_lds,
+                                                    uint32_t need, float *base_obs, float *base_final, bool to_obs_only, int env_lo, int env_hi) {
+    const uint32_t lane = hist.lane;
+    inv_lds[lane] = 1.0 / closes[lane];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const uint32_t q_end = (uint32_t)env_hi * (uint32_t)HLEN;
+#pragma unroll 1
+    for (uint32_t q0 = (uint32_t)env_lo * (uint32_t)HLEN; q0 < q_end; q0 += 64u) {
+        const uint32_t q = q0 + lane < q_end ? q0 + lane : q_end - 1u;
+        const uint32_t env = q / (uint32_t)HLEN, cand = q - env * (uint32_t)HLEN;
+        const uint32_t f = flagsv[env];
+        const uint32_t dest = to_obs_only ? DEST_OBS : (f >> 2) & 3u;
+        float *base = dest == DEST_FINAL ? base_final : base_obs;
+        const bool want = q0 + lane < q_end && (f & need) == need && dest != DEST_NONE && base != nullptr;
+        int slot = oldest + (int)cand;
+        slot -= slot >= HLEN ? HLEN : 0;
+        const double x = hist.lcb[HistLds::at(slot, env)];
+        const float4 o = hist.lob[HistLds::at(slot, env)];
+        const double inv = inv_lds[env];
+        const float v[5] = {(float)((double)o.x * inv), (float)((double)o.y * inv), (float)((double)o.z * inv), (float)(x * inv), (float)((double)o.w * inv)};
+        if (want) {
+            float *dstp = base + (int64_t)env * OBS + 5u * cand;
+            *reinterpret_cast<Piece16 *>(dstp) = Piece16{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+            dstp[4] = v[4];
+        }
+    }
 }
 
 __device__ __forceinline__ void hash_cont(uint64_t key, uint64_t t, float &b, float &s) {
@@ -687,52 +787,65 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
 // window is read from HBM once per launch instead of once per step (1,200 of a step's ~2,900 bytes), and every new candle is
 // also written through to the [50][N] arrays, so nothing has to be copied back.  LDS allows two such windows per CU; with one
 // wave per window (measured: 580 us per 1M-env step against 667 streaming) half of the CU's SIMDs idle while each wave issues
-// ~5,500 mostly float64 instructions per step.  So a workgroup is TWO waves over the same 64 envs and the same window (559 us):
-// wave A steps the market (env_step, generator windows, rewards, resets), wave B turns the window into the 261-column
-// observation row — and B's observation of step t overlaps A's dynamics of step t+1.  Hand-over per step, two barriers:
-//   bar1: B has finished reading window(t-1), A holds step t's new candle in registers;
-//         A then puts the candle and the scalars B needs (cash, holdings, psychology, close, flags) into LDS;
-//   bar2: window(t) is complete: B observes it while A goes on to step t+1.
-// A step in which any env of the wave resets takes two more barriers (B: terminal rows -> final_obs; A: the 50-candle resets into
-// the LDS window; B: the reset rows), so it is not pipelined; it is 6 % of the wave-steps in steady state.
-// A step's only loads from memory are wave A's two generator windows, issued at the end of the previous step.  An episode reset
-// (50 candles, ~700 draws) borrows one of four 96-word draw-window slots of the workgroup (resets are rare: 0.1 % of the
-// env-steps; a fifth simultaneous one waits a round).
-constexpr int RES_SLOTS = 4, RES_SLOT_WORDS = 96;
-struct HistDefer {                                             // wave A's view during env_step: the candle waits in registers for bar1
+// ~5,500 mostly float64 instructions per step.  So a workgroup is FOUR waves over the same 64 envs and the same window:
+//   A steps the market: trade, volume, regime, P-stream draws (env_step<M_SPLIT>), then — after bar1 — price, candle, termination
+//     (finish_step), rewards, resets;
+//   B (lane = env) streams the 50 closes through the indicators and writes the 11 scalar features (features_resident); it owns
+//     the NumPy stream and draws the next step's gaussian (draw_gauss: polar method, software float64 log);
+//   C (two waves, 32 envs each) writes the 250 ratio columns row by row (ratio_rows_resident: lane = candle, 1,000 contiguous
+//     bytes per env) and never loads from memory: nothing ever waits for its stores.
+// B's observation of step t and C's gaussian for step t+1 overlap A's first half of step t+1.  Hand-over per step, two barriers:
+//   bar1: B has finished reading window(t-1), C's gaussian for step t is in LDS, A has done the first half of step t;
+//         A then finishes the step and puts the candle and the scalars B needs (cash, holdings, psychology, close, flags) into LDS;
+//   bar2: window(t) is complete.
+// A step in which any env of the workgroup resets takes two more barriers (B: terminal rows -> final_obs; C hands the NumPy
+// stream's state to A; A: the 50-candle resets into the LDS window, state back to C; B: the reset rows), so it is not pipelined;
+// it is 6 % of the workgroup-steps in steady state.  An episode reset (~700 draws) uses the workgroup's one 96-word draw-window
+// slot (simultaneous resets of a workgroup take turns).
+constexpr int RES_SLOTS = 1, RES_SLOT_WORDS = 96;
+struct HistDefer {                                             // wave A's view during a step: the candle waits in registers for the publish
     double c;
     float4 o;
     int slot;
     HistGlobal g;
     __device__ __forceinline__ void put(int s, double cc, float4 oo) { slot = s; c = cc; o = oo; g.put(s, cc, oo); }
 };
-constexpr size_t RES2_HIST = (size_t)HLEN * 64 * (sizeof(double) + sizeof(float4));
-constexpr size_t RES2_MAIL = 4 * 64 * sizeof(double) + 64 * sizeof(uint32_t) + 16;
-constexpr size_t RES2_LDS = RES2_HIST + RES2_MAIL + (size_t)RES_SLOTS * RES_SLOT_WORDS * 4;
-enum : uint32_t { DEST_NONE = 0u, DEST_OBS = 1u, DEST_FINAL = 2u };
+constexpr size_t RES_HIST = (size_t)HLEN * 64 * (sizeof(double) + sizeof(float4));
+constexpr size_t RES_MAIL = 8 * 64 * sizeof(double) + 2 * 64 * sizeof(uint32_t) + 16;   // cash, holdings, psych, close, g, L cache, 1/close x 2 writers | flags, L cursor | wave flag
+constexpr size_t RES_LDS = RES_HIST + RES_MAIL + (size_t)RES_SLOTS * RES_SLOT_WORDS * 4;
+static_assert(2 * RES_LDS <= 160 * 1024, "two workgroups per CU");
+// The three waves talk through LDS only, so their barrier orders LDS traffic (lgkmcnt) and nothing else: __syncthreads() would also
+// drain vmcnt, i.e. make the row-writing wave wait for its stores every step.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// The reset hand-over is the exception: waves A and B take turns on the env's NumPy generator block in memory, so bar3 / bar4 also
+// wait for the waves' own stores and loads.
+__device__ __forceinline__ void full_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #ifdef CGE_CRYPTO_TIMING
 __device__ unsigned long long g_timing[16384 * 8];
 #define TICK(k) do { const unsigned long long now_ = wall_clock64(); if (lane == 0) { g_timing[blockIdx.x * 8 + k] += now_ - t_last; } t_last = now_; } while (0)
 #else
 #define TICK(k)
 #endif
-__global__ __launch_bounds__(2 * BLOCK) void resident_kernel(Params p) {
+constexpr int RES_WAVES = 4;
+__global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
     extern __shared__ __align__(16) unsigned char res_lds[];
     const uint32_t lane = threadIdx.x & 63u;
-    const bool observer = threadIdx.x >= 64u;                  // wave-uniform
-    double *lc = reinterpret_cast<double *>(res_lds) + lane;
-    float4 *lo = reinterpret_cast<float4 *>(res_lds + (size_t)HLEN * 64 * sizeof(double)) + lane;
-    double *mail = reinterpret_cast<double *>(res_lds + RES2_HIST) + lane;                       // [4][64]: cash, holdings, psych, close
-    uint32_t *mailu = reinterpret_cast<uint32_t *>(res_lds + RES2_HIST + 4 * 64 * sizeof(double)) + lane;   // cash_kind | dest << 2 | reset << 4
-    uint32_t *waveflag = reinterpret_cast<uint32_t *>(res_lds + RES2_HIST + 4 * 64 * sizeof(double) + 64 * sizeof(uint32_t));
-    uint32_t *slots = reinterpret_cast<uint32_t *>(res_lds + RES2_HIST + RES2_MAIL);
+    const uint32_t role = threadIdx.x >> 6;                    // wave-uniform: 0 A (market), 1 B (features, gaussians), 2 and 3 C (rows)
+    double *lcb = reinterpret_cast<double *>(res_lds);
+    float4 *lob = reinterpret_cast<float4 *>(res_lds + (size_t)HLEN * 64 * sizeof(double));
+    double *mail = reinterpret_cast<double *>(res_lds + RES_HIST) + lane;                        // [6][64]: cash, holdings, psych, close, gaussian, L cache
+    uint32_t *mailu = reinterpret_cast<uint32_t *>(res_lds + RES_HIST + 8 * 64 * sizeof(double)) + lane;   // flags; [64 +] L cursor
+    uint32_t *waveflag = reinterpret_cast<uint32_t *>(res_lds + RES_HIST + 8 * 64 * sizeof(double) + 2 * 64 * sizeof(uint32_t));
+    uint32_t *slots = reinterpret_cast<uint32_t *>(res_lds + RES_HIST + RES_MAIL);
+    double &m_gauss = mail[4 * 64], &m_lcache = mail[5 * 64];
+    uint32_t &m_lcur = mailu[64];                              // lpos | pretw flag << 10 | has_gauss << 11
     const int64_t i0 = (int64_t)blockIdx.x * BLOCK;
     const int64_t i = i0 + lane;
     const bool live = i < p.n;
     const int64_t li = live ? i : i0;
-    HistLds hist{lc, lo, HistGlobal{p.closes, p.ohlv, p.n, li}};
-    {   // the window: HBM -> LDS, each wave half of the slots
-        const int s_lo = observer ? HLEN / 2 : 0;
+    HistLds hist{lcb, lob, lane, HistGlobal{p.closes, p.ohlv, p.n, li}};
+    if (role < 2u) {   // the window: HBM -> LDS, waves A and B half of the slots each
+        const int s_lo = role ? HLEN / 2 : 0;
 #pragma unroll 1
         for (int s0 = s_lo; s0 < s_lo + HLEN / 2; s0 += 5) {
             double c[5];
@@ -740,22 +853,51 @@ __global__ __launch_bounds__(2 * BLOCK) void resident_kernel(Params p) {
 #pragma unroll
             for (int j = 0; j < 5; ++j) { c[j] = hist.g.close(s0 + j); o[j] = hist.g.rest(s0 + j); }
 #pragma unroll
-            for (int j = 0; j < 5; ++j) { lc[(s0 + j) * 64] = c[j]; lo[(s0 + j) * 64] = o[j]; }
+            for (int j = 0; j < 5; ++j) hist.put_lds(s0 + j, c[j], o[j]);
         }
     }
+    uint32_t *__restrict__ blkP = p.mtP + li * MT_STRIDE;
+    uint32_t *__restrict__ blkL = p.mtL + li * MT_STRIDE;
     int phase = p.phase;
 #ifdef CGE_CRYPTO_TIMING
     unsigned long long t_last = wall_clock64();
 #endif
-    if (observer) {
-        // ---------------- wave B
-        Env v;                                                 // only the fields the observation reads
-        v.cash = v.holdings = v.psych = v.close = 0.0; v.cash_kind = 0;
+    if (role >= 2u) {
+        const int env_lo = role == 2u ? 0 : 32, env_hi = env_lo + 32;      // two row writers, 32 envs each
+        double *inv_scratch = mail - lane + (role == 2u ? 6 : 7) * 64;
+        // ---------------- waves C: the ratio columns, row by row.  It never loads from memory, so its ~128 row stores per step are
+        // never waited for: they drain while the next steps run (the barriers order LDS traffic only).
+        lds_barrier();                                         // bar0
 #pragma unroll 1
         for (int t = 0; t < p.k_steps; ++t) {
             const int next_phase = phase + 1 == HLEN ? 0 : phase + 1;
-            __syncthreads();                                   // bar1
-            __syncthreads();                                   // bar2
+            lds_barrier();                                     // bar1
+            lds_barrier();                                     // bar2
+            float *base_obs = p.obs ? p.obs + (int64_t)t * p.obs_step_stride + i0 * OBS : nullptr;
+            float *base_final = p.final_obs ? p.final_obs + i0 * OBS : nullptr;
+            ratio_rows_resident(hist, next_phase, mailu - lane, mail - lane + 192, inv_scratch, 0u, base_obs, base_final, false, env_lo, env_hi);
+            if (*waveflag) {
+                full_barrier();                                 // bar3: the pre-reset rows have been read out of the window
+                full_barrier();                                 // bar4: the fresh windows are in LDS
+                ratio_rows_resident(hist, next_phase, mailu - lane, mail - lane + 192, inv_scratch, F_RESET, base_obs, nullptr, true, env_lo, env_hi);   // the reset rows
+            }
+            phase = next_phase;
+        }
+        lds_barrier();                                         // closing barrier
+        return;
+    }
+    if (role == 1u) {
+        // ---------------- wave B: indicators + scalar features of every row; owns the NumPy stream and draws the next step's gaussian
+        Env v;                                                 // the fields the features read; lpos, lpretw, has_gauss, gauss for the stream
+        v.cash = v.holdings = v.psych = v.close = 0.0; v.cash_kind = 0;
+        lds_barrier();                                         // bar0: A has published the stream's state and who steps first
+        v.lpos = m_lcur & 1023u; v.lpretw = (m_lcur & 1024u) ? (uint32_t)MT_N : 0u; v.has_gauss = (m_lcur >> 11) & 1u; v.gauss = m_lcache;
+        if (live && (*mailu & F_DRAW_NEXT)) m_gauss = draw_gauss(v, blkL);
+#pragma unroll 1
+        for (int t = 0; t < p.k_steps; ++t) {
+            const int next_phase = phase + 1 == HLEN ? 0 : phase + 1;
+            lds_barrier();                                     // bar1: the gaussian of step t is in LDS
+            lds_barrier();                                     // bar2
             TICK(4);
             const uint32_t u = *mailu;
             const bool slow = *waveflag != 0u;
@@ -764,40 +906,49 @@ __global__ __launch_bounds__(2 * BLOCK) void resident_kernel(Params p) {
             float *obs_row = p.obs ? p.obs + (int64_t)t * p.obs_step_stride + li * OBS : nullptr;
             float *row = dest == DEST_FINAL ? p.final_obs + li * OBS : obs_row;
             const bool want = dest != DEST_NONE && row != nullptr;
-            if (__ballot(want)) observe_resident(v, p, hist, next_phase, want ? row : obs_row, want);
+            if (__ballot(want)) features_resident(v, p, hist, next_phase, want ? row : obs_row, want);
             TICK(5);
             if (slow) {
-                __syncthreads();                               // bar3: the pre-reset rows are out, A may rewrite the window
-                __syncthreads();                               // bar4: the fresh windows are in LDS
-                const bool again = ((*mailu >> 4) & 1u) != 0u && obs_row != nullptr;
-                v.cash = mail[0]; v.holdings = mail[64]; v.psych = mail[128]; v.close = mail[192]; v.cash_kind = *mailu & 3u;
-                if (__ballot(again)) observe_resident(v, p, hist, next_phase, obs_row, again);
+                m_lcur = v.lpos | (v.lpretw ? 1024u : 0u) | (v.has_gauss << 11); m_lcache = v.gauss;
+                full_barrier();                                 // bar3: the pre-reset rows are out, A may rewrite the window and take the stream
+                full_barrier();                                 // bar4: the fresh windows are in LDS, the stream is back
+                const uint32_t u2 = *mailu;
+                if (u2 & F_RESET) { v.lpos = m_lcur & 1023u; v.lpretw = (m_lcur & 1024u) ? (uint32_t)MT_N : 0u; v.has_gauss = (m_lcur >> 11) & 1u; v.gauss = m_lcache; }
+                const bool again = (u2 & F_RESET) != 0u && obs_row != nullptr;
+                v.cash = mail[0]; v.holdings = mail[64]; v.psych = mail[128]; v.close = mail[192]; v.cash_kind = u2 & 3u;
+                if (__ballot(again)) features_resident(v, p, hist, next_phase, obs_row, again);
             }
+            if (t + 1 < p.k_steps && live && (*mailu & F_DRAW_NEXT)) m_gauss = draw_gauss(v, blkL);   // step t+1's
             phase = next_phase;
         }
-        __syncthreads();                                       // A's closing barrier
+        m_lcur = v.lpos | (v.lpretw ? 1024u : 0u) | (v.has_gauss << 11); m_lcache = v.gauss;
+        lds_barrier();                                         // closing barrier: A stores the record
         return;
     }
-    // ---------------- wave A
+    // ---------------- wave A: the market
     Env e;
     e.load(p.scal, p.n, li);
     RollP dp(nullptr, nullptr, 0, 0);                          // unused in this mode
     RollL dl(nullptr, nullptr, 0, 0);
-    uint32_t *__restrict__ blkP = p.mtP + li * MT_STRIDE;
-    uint32_t *__restrict__ blkL = p.mtL + li * MT_STRIDE;
     MtWindow<WP> wp;
-    MtWindow<WL> wl;
+    MtWindow<WL> wl;                                           // unused (wave C draws the gaussians)
     wp.load(blkP, e.ppos);
-    if (!e.has_gauss) wl.load(blkL, e.lpos);
     const uint64_t key = hash_env_key(p.a_seed, (uint64_t)(p.env0 + li));
     double rsum = 0.0;
     int32_t dcount = 0;
+    {   // the NumPy stream goes to wave C; a lane that starts with a pending NEXT_STEP reset does not step first
+        m_lcur = e.lpos | (e.lpretw ? 1024u : 0u) | (e.has_gauss << 11); m_lcache = e.gauss;
+        const bool steps_first = live && !(p.mode == CGE_AUTORESET_NEXT_STEP && e.needs_reset);
+        *mailu = steps_first ? F_DRAW_NEXT : 0u;
+    }
+    lds_barrier();                                              // bar0 (also: the window is in LDS)
 #pragma unroll 1
     for (int t = 0; t < p.k_steps; ++t) {
         double reward = 0.0;
         bool term = false, reset_now = false, stepped = false;
         const int next_phase = phase + 1 == HLEN ? 0 : phase + 1;
         HistDefer pend{0.0, make_float4(0.f, 0.f, 0.f, 0.f), phase, HistGlobal{p.closes, p.ohlv, p.n, li}};
+        SplitOut so{0.0, 0.0, 0.0, 0.0};
         if (live) {
             if (p.mode == CGE_AUTORESET_NEXT_STEP && e.needs_reset) {
                 reset_now = true;
@@ -811,50 +962,56 @@ __global__ __launch_bounds__(2 * BLOCK) void resident_kernel(Params p) {
                     a = p.actions ? reinterpret_cast<const int32_t *>(p.actions)[(int64_t)t * p.n + i]
                                   : (int32_t)hash_action_from_key(key, (uint64_t)(p.t0 + t), 5u, 0u);
                 }
-                term = env_step<M_RESIDENT>(e, p, li, pend, phase, a, ab, as, reward, dp, dl, wp, wl);
+                (void)env_step<M_SPLIT>(e, p, li, pend, phase, a, ab, as, reward, dp, dl, wp, wl, &so);
                 stepped = true;
-                e.ep_return += reward;
-                if (term) {
-                    e.episodes += 1;
-                    if (p.ep_ret) p.ep_ret[i] = e.ep_return;
-                    if (p.ep_len) p.ep_len[i] = (int32_t)e.step;
-                    if (p.mode == CGE_AUTORESET_SAME_STEP) reset_now = true;
-                    else if (p.mode == CGE_AUTORESET_NEXT_STEP) e.needs_reset = 1;
-                }
             }
         }
         TICK(0);
+        lds_barrier();                                          // bar1: B is done with window(t-1), C's gaussian for this step is in LDS
+        TICK(1);
+        if (stepped) {
+            term = finish_step(e, p, pend, phase, so, m_gauss);
+            e.ep_return += reward;
+            if (term) {
+                e.episodes += 1;
+                if (p.ep_ret) p.ep_ret[i] = e.ep_return;
+                if (p.ep_len) p.ep_len[i] = (int32_t)e.step;
+                if (p.mode == CGE_AUTORESET_SAME_STEP) reset_now = true;
+                else if (p.mode == CGE_AUTORESET_NEXT_STEP) e.needs_reset = 1;
+            }
+            hist.put_lds(pend.slot, pend.c, pend.o);
+        }
         const unsigned long long rm = __ballot(reset_now);
         // rows of this step: a SAME_STEP terminal row goes to final_obs (and the reset row to obs afterwards), a NEXT_STEP
         // reset-only row only exists after the reset
         const uint32_t dest = !live ? DEST_NONE : (term && reset_now) ? (p.final_obs ? DEST_FINAL : DEST_NONE) : reset_now ? DEST_NONE : DEST_OBS;
-        __syncthreads();                                       // bar1: B is done with window(t-1)
-        TICK(1);
-        if (stepped) { lc[pend.slot * 64] = pend.c; lo[pend.slot * 64] = pend.o; }
+        // does this lane step at t+1 (then wave C draws its gaussian now)?  not when the step is a NEXT_STEP reset-only one
+        const bool steps_next = live && !(p.mode == CGE_AUTORESET_NEXT_STEP && e.needs_reset && !reset_now);
         mail[0] = e.cash; mail[64] = e.holdings; mail[128] = e.psych; mail[192] = e.close;
-        *mailu = e.cash_kind | (dest << 2) | ((reset_now ? 1u : 0u) << 4);
+        *mailu = e.cash_kind | (dest << 2) | (reset_now ? F_RESET : 0u) | (steps_next ? F_DRAW_NEXT : 0u);
         if (lane == 0) *waveflag = rm ? 1u : 0u;
-        __syncthreads();                                       // bar2: window(t) is complete
+        lds_barrier();                                          // bar2: window(t) is complete
         TICK(2);
         if (rm) {
-            __syncthreads();                                   // bar3
+            full_barrier();                                      // bar3: B's pre-reset rows are out, C's stream state is in LDS
             const uint32_t rank = (uint32_t)__popcll(rm & ((1ull << lane) - 1ull));
 #pragma unroll 1
             for (uint32_t round = 0; round * RES_SLOTS < (uint32_t)__popcll(rm); ++round) {
                 if (reset_now && rank / RES_SLOTS == round) {
+                    e.lpos = m_lcur & 1023u; e.lpretw = (m_lcur & 1024u) ? (uint32_t)MT_N : 0u; e.has_gauss = (m_lcur >> 11) & 1u; e.gauss = m_lcache;
                     uint32_t *row = slots + (rank % RES_SLOTS) * RES_SLOT_WORDS;
                     LdsDrawsCall<64> sp(row, blkP, e.ppos, e.ppretw);
                     LdsDrawsCall<32> sl(row + 64, blkL, e.lpos, e.lpretw);
                     reset_body(e, p, hist, next_phase, sp, sl);
                     sp.flush(); sl.flush();
                     e.ppos = sp.pos; e.ppretw = sp.pretw; e.lpos = sl.pos; e.lpretw = sl.pretw;
-                    wp.load(blkP, e.ppos);                     // the prefetched windows belonged to the finished episode's cursors
-                    if (!e.has_gauss) wl.load(blkL, e.lpos);
+                    wp.load(blkP, e.ppos);                     // the prefetched window belonged to the finished episode's cursor
+                    m_lcur = e.lpos | (e.lpretw ? 1024u : 0u) | (e.has_gauss << 11); m_lcache = e.gauss;
                     mail[0] = e.cash; mail[64] = e.holdings; mail[128] = e.psych; mail[192] = e.close;
-                    *mailu = e.cash_kind | (1u << 4);
+                    *mailu = e.cash_kind | F_RESET | F_DRAW_NEXT;
                 }
             }
-            __syncthreads();                                   // bar4
+            full_barrier();                                      // bar4
         }
         if (live) {
             rsum += reward;
@@ -868,8 +1025,9 @@ __global__ __launch_bounds__(2 * BLOCK) void resident_kernel(Params p) {
 #endif
         phase = next_phase;
     }
-    __syncthreads();                                           // B's last observation is out
+    lds_barrier();                                              // closing barrier: B's last rows are out, C's stream state is in LDS
     if (live) {
+        e.lpos = m_lcur & 1023u; e.lpretw = (m_lcur & 1024u) ? (uint32_t)MT_N : 0u; e.has_gauss = (m_lcur >> 11) & 1u; e.gauss = m_lcache;
         e.store(p.scal, p.n, i);
         if (p.reward_sum) p.reward_sum[i] = rsum;
         if (p.done_count) p.done_count[i] = dcount;
@@ -1081,10 +1239,10 @@ int cge_crypto_rollout(cge_crypto *h, int32_t k_steps, const void *actions, uint
     static const bool resident = [] { const char *v = getenv("CGE_CRYPTO_RESIDENT"); return !v || atoi(v) != 0; }();
     if (resident && k_steps >= 2) {
         if (!h->resident_ready) {
-            CGE_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(crypto::resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)crypto::RES2_LDS));
+            CGE_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(crypto::resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)crypto::RES_LDS));
             h->resident_ready = true;
         }
-        hipLaunchKernelGGL(crypto::resident_kernel, dim3(h->blocks()), dim3(2 * crypto::BLOCK), crypto::RES2_LDS, as_stream(stream), p);
+        hipLaunchKernelGGL(crypto::resident_kernel, dim3(h->blocks()), dim3(crypto::RES_WAVES * crypto::BLOCK), crypto::RES_LDS, as_stream(stream), p);
     } else {
         hipLaunchKernelGGL(crypto::step_kernel<true>, dim3(h->blocks()), dim3(crypto::BLOCK), 0, as_stream(stream), p);
     }
