@@ -844,16 +844,16 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
     const bool live = i < p.n;
     const int64_t li = live ? i : i0;
     HistLds hist{lcb, lob, lane, HistGlobal{p.closes, p.ohlv, p.n, li}};
-    if (role < 2u) {   // the window: HBM -> LDS, waves A and B half of the slots each
-        const int s_lo = role ? HLEN / 2 : 0;
+    if (role >= 1u) {   // the window: HBM -> LDS by waves B and C (17 + 17 + 16 slots) while wave A already steps the market
+        const int s_lo = role == 1u ? 0 : role == 2u ? 17 : 34, s_hi = role == 1u ? 17 : role == 2u ? 34 : HLEN;
 #pragma unroll 1
-        for (int s0 = s_lo; s0 < s_lo + HLEN / 2; s0 += 5) {
-            double c[5];
-            float4 o[5];
+        for (int s0 = s_lo; s0 < s_hi; s0 += 6) {
+            double c[6];
+            float4 o[6];
 #pragma unroll
-            for (int j = 0; j < 5; ++j) { c[j] = hist.g.close(s0 + j); o[j] = hist.g.rest(s0 + j); }
+            for (int j = 0; j < 6; ++j) { const int sl = s0 + j < s_hi ? s0 + j : s_hi - 1; c[j] = hist.g.close(sl); o[j] = hist.g.rest(sl); }
 #pragma unroll
-            for (int j = 0; j < 5; ++j) hist.put_lds(s0 + j, c[j], o[j]);
+            for (int j = 0; j < 6; ++j) { const int sl = s0 + j < s_hi ? s0 + j : s_hi - 1; hist.put_lds(sl, c[j], o[j]); }
         }
     }
     uint32_t *__restrict__ blkP = p.mtP + li * MT_STRIDE;
@@ -867,7 +867,6 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
         double *inv_scratch = mail - lane + (role == 2u ? 6 : 7) * 64;
         // ---------------- waves C: the ratio columns, row by row.  It never loads from memory, so its ~128 row stores per step are
         // never waited for: they drain while the next steps run (the barriers order LDS traffic only).
-        lds_barrier();                                         // bar0
 #pragma unroll 1
         for (int t = 0; t < p.k_steps; ++t) {
             const int next_phase = phase + 1 == HLEN ? 0 : phase + 1;
@@ -888,11 +887,10 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
     }
     if (role == 1u) {
         // ---------------- wave B: indicators + scalar features of every row; owns the NumPy stream and draws the next step's gaussian
-        Env v;                                                 // the fields the features read; lpos, lpretw, has_gauss, gauss for the stream
-        v.cash = v.holdings = v.psych = v.close = 0.0; v.cash_kind = 0;
-        lds_barrier();                                         // bar0: A has published the stream's state and who steps first
-        v.lpos = m_lcur & 1023u; v.lpretw = (m_lcur & 1024u) ? (uint32_t)MT_N : 0u; v.has_gauss = (m_lcur >> 11) & 1u; v.gauss = m_lcache;
-        if (live && (*mailu & F_DRAW_NEXT)) m_gauss = draw_gauss(v, blkL);
+        Env v;                                                 // the record: the stream's state (lpos, lpretw, has_gauss, gauss) is this wave's from here on;
+        v.load(p.scal, p.n, li);                               // cash, holdings, psych, close, cash_kind are refreshed from the mailbox every step
+        // a lane that starts with a pending NEXT_STEP reset does not step first: no gaussian for it
+        if (live && !(p.mode == CGE_AUTORESET_NEXT_STEP && v.needs_reset)) m_gauss = draw_gauss(v, blkL);
 #pragma unroll 1
         for (int t = 0; t < p.k_steps; ++t) {
             const int next_phase = phase + 1 == HLEN ? 0 : phase + 1;
@@ -936,12 +934,6 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
     const uint64_t key = hash_env_key(p.a_seed, (uint64_t)(p.env0 + li));
     double rsum = 0.0;
     int32_t dcount = 0;
-    {   // the NumPy stream goes to wave C; a lane that starts with a pending NEXT_STEP reset does not step first
-        m_lcur = e.lpos | (e.lpretw ? 1024u : 0u) | (e.has_gauss << 11); m_lcache = e.gauss;
-        const bool steps_first = live && !(p.mode == CGE_AUTORESET_NEXT_STEP && e.needs_reset);
-        *mailu = steps_first ? F_DRAW_NEXT : 0u;
-    }
-    lds_barrier();                                              // bar0 (also: the window is in LDS)
 #pragma unroll 1
     for (int t = 0; t < p.k_steps; ++t) {
         double reward = 0.0;
@@ -1018,6 +1010,7 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
             dcount += term ? 1 : 0;
             if (p.reward) p.reward[(int64_t)t * p.n + i] = (float)reward;
             if (p.terminated) p.terminated[(int64_t)t * p.n + i] = term ? 1 : 0;
+            if (p.truncated) p.truncated[(int64_t)t * p.n + i] = 0;                    // step() through this kernel (k = 1)
         }
         TICK(3);
 #ifdef CGE_CRYPTO_TIMING
@@ -1115,6 +1108,21 @@ struct cge_crypto : HandleBase {
         (void)hipFree(scal); (void)hipFree(closes); (void)hipFree(ohlv); (void)hipFree(mtP); (void)hipFree(mtL);
     }
 };
+
+// CGE_CRYPTO_RESIDENT: 2 (default) the resident kernel serves rollouts and step(); 1 rollouts only; 0 the streaming kernels
+static int resident_mode() {
+    static const int m = [] { const char *v = getenv("CGE_CRYPTO_RESIDENT"); return v ? atoi(v) : 2; }();
+    return m;
+}
+static hipError_t launch_resident(cge_crypto *h, const crypto::Params &p, hipStream_t s) {
+    if (!h->resident_ready) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(crypto::resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)crypto::RES_LDS);
+        if (e != hipSuccess) return e;
+        h->resident_ready = true;
+    }
+    hipLaunchKernelGGL(crypto::resident_kernel, dim3(h->blocks()), dim3(crypto::RES_WAVES * crypto::BLOCK), crypto::RES_LDS, s, p);
+    return hipGetLastError();
+}
 
 extern "C" {
 
@@ -1218,7 +1226,9 @@ int cge_crypto_step(cge_crypto *h, const void *actions, float *obs_out, float *r
     crypto::Params p = h->params();
     p.actions = actions; p.obs = obs_out; p.reward = reward_out; p.terminated = terminated_out; p.truncated = truncated_out;
     p.final_obs = final_obs_out; p.k_steps = 1;
-    hipLaunchKernelGGL(crypto::step_kernel<false>, dim3(h->blocks()), dim3(crypto::BLOCK), 0, as_stream(stream), p);
+    // the four-wave resident kernel also serves a single step: its waves share the row, feature and market work of the 64 envs
+    if (resident_mode() >= 2) CGE_TRY(h, launch_resident(h, p, as_stream(stream)));
+    else hipLaunchKernelGGL(crypto::step_kernel<false>, dim3(h->blocks()), dim3(crypto::BLOCK), 0, as_stream(stream), p);
     CGE_TRY(h, hipGetLastError());
     h->phase = (h->phase + 1) % crypto::HLEN;
     return CGE_OK;
@@ -1235,17 +1245,8 @@ int cge_crypto_rollout(cge_crypto *h, int32_t k_steps, const void *actions, uint
     crypto::Params p = h->params();
     p.k_steps = k_steps; p.actions = actions; p.a_seed = action_seed; p.t0 = t0; p.obs = obs_out; p.obs_step_stride = obs_step_stride;
     p.reward = reward_traj_out; p.terminated = terminated_traj_out; p.reward_sum = reward_sum_out; p.done_count = done_count_out;
-    // k >= 2: the resident kernel (the window is read once per launch); CGE_CRYPTO_RESIDENT=0 keeps the streaming kernel
-    static const bool resident = [] { const char *v = getenv("CGE_CRYPTO_RESIDENT"); return !v || atoi(v) != 0; }();
-    if (resident && k_steps >= 2) {
-        if (!h->resident_ready) {
-            CGE_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(crypto::resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)crypto::RES_LDS));
-            h->resident_ready = true;
-        }
-        hipLaunchKernelGGL(crypto::resident_kernel, dim3(h->blocks()), dim3(crypto::RES_WAVES * crypto::BLOCK), crypto::RES_LDS, as_stream(stream), p);
-    } else {
-        hipLaunchKernelGGL(crypto::step_kernel<true>, dim3(h->blocks()), dim3(crypto::BLOCK), 0, as_stream(stream), p);
-    }
+    if (resident_mode() >= 1 && k_steps >= 2) CGE_TRY(h, launch_resident(h, p, as_stream(stream)));
+    else hipLaunchKernelGGL(crypto::step_kernel<true>, dim3(h->blocks()), dim3(crypto::BLOCK), 0, as_stream(stream), p);
     CGE_TRY(h, hipGetLastError());
     h->phase = (h->phase + k_steps) % crypto::HLEN;
     return CGE_OK;

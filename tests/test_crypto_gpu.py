@@ -166,7 +166,7 @@ def test_rollout_matches_oracle(cge, oracle):
 @pytest.mark.parametrize("kind,mode", [("discrete", "SameStep"), ("discrete", "NextStep"), ("continuous", "SameStep"),
                                        ("continuous", "NextStep"), ("discrete", "Disabled")])
 def test_resident_rollout_equals_step_by_step_through_resets(cge, kind, mode):
-    """The fused rollout's resident kernel (two waves per 64 envs around an LDS candle window, csrc/crypto.hip) against the
+    """The fused rollout's resident kernel (four waves per 64 envs around an LDS candle window, csrc/crypto.hip) against the
     step() kernel on a twin, value for value: a 13-step time limit puts several in-kernel episode resets (the non-pipelined
     four-barrier step), NEXT_STEP's reset-only steps and ragged last workgroups into 60 fused steps."""
     n, k = 64 * 3 + 5, 60
