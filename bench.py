@@ -54,7 +54,7 @@ ENVS = {
     # rollout: the 50-candle window (1,200 B) is resident in LDS for a launch (read once: resident_ro); per step only the new candle
     # (24 B, written through) and the generator words (144 B) stream
     "crypto":  dict(algo=2346, obs=1044, state=64, resident=64, resident_ro=1200, stream=168, n_act=5, act_shape=(),   dtype="f64",
-                    step_kernel="cge::crypto::step_kernel<false>", roll_kernel="cge::crypto::resident_kernel", ref_py="1.64e3-1.68e3 steps/s/process"),
+                    step_kernel="cge::crypto::resident_kernel<true>", roll_kernel="cge::crypto::resident_kernel<false>", ref_py="1.64e3-1.68e3 steps/s/process"),
     "traffic": dict(algo=1134, obs=520, state=240, resident=240, stream=60, n_act=3, act_shape=(9,), dtype="int32",
                     step_kernel="cge::traffic::step_kernel<false>", roll_kernel="cge::traffic::step_kernel<true>", ref_py="1.75e3-1.90e3 steps/s/process"),
     "parking": dict(algo=662,  obs=52, state=288, resident=288, stream=24, n_act=8, act_shape=(),   dtype="f64",

@@ -827,7 +827,10 @@ __device__ unsigned long long g_timing[16384 * 8];
 #define TICK(k)
 #endif
 constexpr int RES_WAVES = 4;
+// ONE_STEP: the step() entry (k = 1); a separate instantiation mainly so that profiles tell the two paths apart
+template <bool ONE_STEP>
 __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
+    if (ONE_STEP) p.k_steps = 1;
     extern __shared__ __align__(16) unsigned char res_lds[];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t role = threadIdx.x >> 6;                    // wave-uniform: 0 A (market), 1 B (features, gaussians), 2 and 3 C (rows)
@@ -1114,13 +1117,15 @@ static int resident_mode() {
     static const int m = [] { const char *v = getenv("CGE_CRYPTO_RESIDENT"); return v ? atoi(v) : 2; }();
     return m;
 }
-static hipError_t launch_resident(cge_crypto *h, const crypto::Params &p, hipStream_t s) {
+static hipError_t launch_resident(cge_crypto *h, const crypto::Params &p, hipStream_t s, bool one_step) {
     if (!h->resident_ready) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(crypto::resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)crypto::RES_LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(crypto::resident_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)crypto::RES_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(crypto::resident_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)crypto::RES_LDS);
         if (e != hipSuccess) return e;
         h->resident_ready = true;
     }
-    hipLaunchKernelGGL(crypto::resident_kernel, dim3(h->blocks()), dim3(crypto::RES_WAVES * crypto::BLOCK), crypto::RES_LDS, s, p);
+    if (one_step) hipLaunchKernelGGL(crypto::resident_kernel<true>, dim3(h->blocks()), dim3(crypto::RES_WAVES * crypto::BLOCK), crypto::RES_LDS, s, p);
+    else hipLaunchKernelGGL(crypto::resident_kernel<false>, dim3(h->blocks()), dim3(crypto::RES_WAVES * crypto::BLOCK), crypto::RES_LDS, s, p);
     return hipGetLastError();
 }
 
@@ -1227,7 +1232,7 @@ int cge_crypto_step(cge_crypto *h, const void *actions, float *obs_out, float *r
     p.actions = actions; p.obs = obs_out; p.reward = reward_out; p.terminated = terminated_out; p.truncated = truncated_out;
     p.final_obs = final_obs_out; p.k_steps = 1;
     // the four-wave resident kernel also serves a single step: its waves share the row, feature and market work of the 64 envs
-    if (resident_mode() >= 2) CGE_TRY(h, launch_resident(h, p, as_stream(stream)));
+    if (resident_mode() >= 2) CGE_TRY(h, launch_resident(h, p, as_stream(stream), true));
     else hipLaunchKernelGGL(crypto::step_kernel<false>, dim3(h->blocks()), dim3(crypto::BLOCK), 0, as_stream(stream), p);
     CGE_TRY(h, hipGetLastError());
     h->phase = (h->phase + 1) % crypto::HLEN;
@@ -1245,7 +1250,7 @@ int cge_crypto_rollout(cge_crypto *h, int32_t k_steps, const void *actions, uint
     crypto::Params p = h->params();
     p.k_steps = k_steps; p.actions = actions; p.a_seed = action_seed; p.t0 = t0; p.obs = obs_out; p.obs_step_stride = obs_step_stride;
     p.reward = reward_traj_out; p.terminated = terminated_traj_out; p.reward_sum = reward_sum_out; p.done_count = done_count_out;
-    if (resident_mode() >= 1 && k_steps >= 2) CGE_TRY(h, launch_resident(h, p, as_stream(stream)));
+    if (resident_mode() >= 1 && k_steps >= 2) CGE_TRY(h, launch_resident(h, p, as_stream(stream), false));
     else hipLaunchKernelGGL(crypto::step_kernel<true>, dim3(h->blocks()), dim3(crypto::BLOCK), 0, as_stream(stream), p);
     CGE_TRY(h, hipGetLastError());
     h->phase = (h->phase + k_steps) % crypto::HLEN;
