@@ -623,10 +623,6 @@ __device__ __forceinline__ void observe(const Env &e, const Params &p, int64_t i
     store_own_row<CT * 5 + 11>(row, NFULL * CH * 5, tail, mine);
 }
 
-// The resident rollout's observation: the candles come from the wave's LDS copy, four at a time (no prefetch buffers to keep
-// alive: 20 floats of row and 4 candles in registers instead of 60 and 12).
-constexpr int RCH = 4;
-static_assert((HLEN - CT) % RCH == 0, "whole chunks before the two candles that travel with the scalar features");
 // mailbox word of an env in the resident rollout: cash_kind (2 bits) | dest << 2 | this lane resets | it steps next (draw its gaussian)
 enum : uint32_t { DEST_NONE = 0u, DEST_OBS = 1u, DEST_FINAL = 2u };
 enum : uint32_t { F_RESET = 1u << 4, F_DRAW_NEXT = 1u << 5 };
@@ -814,7 +810,7 @@ constexpr size_t RES_HIST = (size_t)HLEN * 64 * (sizeof(double) + sizeof(float4)
 constexpr size_t RES_MAIL = 8 * 64 * sizeof(double) + 2 * 64 * sizeof(uint32_t) + 16;   // cash, holdings, psych, close, g, L cache, 1/close x 2 writers | flags, L cursor | wave flag
 constexpr size_t RES_LDS = RES_HIST + RES_MAIL + (size_t)RES_SLOTS * RES_SLOT_WORDS * 4;
 static_assert(2 * RES_LDS <= 160 * 1024, "two workgroups per CU");
-// The three waves talk through LDS only, so their barrier orders LDS traffic (lgkmcnt) and nothing else: __syncthreads() would also
+// The waves talk through LDS only, so their barrier orders LDS traffic (lgkmcnt) and nothing else: __syncthreads() would also
 // drain vmcnt, i.e. make the row-writing wave wait for its stores every step.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // The reset hand-over is the exception: waves A and B take turns on the env's NumPy generator block in memory, so bar3 / bar4 also
@@ -932,7 +928,7 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
     RollP dp(nullptr, nullptr, 0, 0);                          // unused in this mode
     RollL dl(nullptr, nullptr, 0, 0);
     MtWindow<WP> wp;
-    MtWindow<WL> wl;                                           // unused (wave C draws the gaussians)
+    MtWindow<WL> wl;                                           // unused (wave B draws the gaussians)
     wp.load(blkP, e.ppos);
     const uint64_t key = hash_env_key(p.a_seed, (uint64_t)(p.env0 + li));
     double rsum = 0.0;
