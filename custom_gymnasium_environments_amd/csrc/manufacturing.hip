@@ -476,23 +476,24 @@ __device__ __forceinline__ double big_type_sum(const Env &e, const Tab &tb, bool
 
 // obs[50..55]: np.mean of quality_score per product type over products_in_system (:220-228), NumPy pairwise order.
 // Wave-uniform walk over the union of the lanes' live slot ranges; per lane 6 x (8 accumulators + result) in LDS.
+constexpr int WALK = 16;            // slots per round trip of the type_means walk
 __device__ __forceinline__ void type_means(Env &e, const Tab &tb, bool live, double *acc_lane, double (&mean)[6]) {
     const uint32_t smin = wave_min(live ? e.lo : (uint32_t)CAP), smax = wave_max(live ? e.nprod : 0u);
     uint64_t jc = 0;
     uint32_t first_alive = e.nprod;
-    // 8 slots per round trip: the loads are unconditional (every slot row exists) and issued before the first use
+    // 16 slots per round trip (8: 40 dependent trips per step once ~300 products have been started): the loads are unconditional (every slot row exists) and issued before the first use
 #pragma unroll 1
-    for (uint32_t s0 = smin; s0 < smax; s0 += 8u) {
-        uint32_t mm[8];
-        double qq[8];
+    for (uint32_t s0 = smin; s0 < smax; s0 += (uint32_t)WALK) {
+        uint32_t mm[WALK];
+        double qq[WALK];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < WALK; ++u) {
             const uint32_t sl = s0 + u < (uint32_t)CAP ? s0 + u : (uint32_t)CAP - 1u;
             mm[u] = tb.pm[(int64_t)sl * tb.n];
             qq[u] = tb.pq[(int64_t)sl * tb.n];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < WALK; ++u) {
             const uint32_t s = s0 + u, m = mm[u];
             const double q = qq[u];
             if (live && s >= e.lo && s < e.nprod && (m & M_ALIVE)) {
