@@ -48,31 +48,23 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 
 # words and tables that live in HBM even inside a fused launch) + 2 x the state that is NOT register-resident, plus the resident
 # record once per launch (2 x resident / kc); it reads no actions (device-side hash).
 ENVS = {
-    "snake":   dict(algo=145,  obs=100, state=48, resident=48, stream=0, n_act=4, act_shape=(),   dtype="i8",
-                    step_kernel="cge::snake::step_kernel<10, 256, 1, 1>", roll_kernel="cge::snake::rollout_kernel<10, 256, 1, 1, true, false>",
+    # the 16-byte hot record is all a launch reads and writes of the state (snakes of <= 25 cells); the digit ring adds < 1 B / env-step
+    "snake":   dict(algo=145,  obs=100, state=16, resident=16, stream=0, n_act=4, act_shape=(),   dtype="i8",
                     ref_py="3.4e5-4.2e5 steps/s/process"),
     # rollout: the 50-candle window (1,200 B) is resident in LDS for a launch (read once: resident_ro); per step only the new candle
     # (24 B, written through) and the generator words (144 B) stream
-    "crypto":  dict(algo=2346, obs=1044, state=64, resident=64, resident_ro=1200, stream=168, n_act=5, act_shape=(),   dtype="f64",
-                    step_kernel="cge::crypto::resident_kernel<true>", roll_kernel="cge::crypto::resident_kernel<false>", ref_py="1.64e3-1.68e3 steps/s/process"),
-    "traffic": dict(algo=1134, obs=520, state=240, resident=240, stream=60, n_act=3, act_shape=(9,), dtype="int32",
-                    step_kernel="cge::traffic::step_kernel<false>", roll_kernel="cge::traffic::step_kernel<true>", ref_py="1.75e3-1.90e3 steps/s/process"),
-    "parking": dict(algo=662,  obs=52, state=288, resident=288, stream=24, n_act=8, act_shape=(),   dtype="f64",
-                    step_kernel="cge::parking::step_kernel<false>", roll_kernel="cge::parking::step_kernel<true>", ref_py="2.66e4 steps/s/process"),
-    "climate": dict(algo=218,  obs=36, state=80, resident=80, stream=0, n_act=None, act_shape=None, dtype="f64",
-                    step_kernel="cge::climate::step_kernel<false>", roll_kernel="cge::climate::step_kernel<true>", ref_py="1.27e4 steps/s/process"),
+    "crypto":  dict(algo=2346, obs=1044, state=64, resident=64, resident_ro=1200, stream=168, n_act=5, act_shape=(),   dtype="f64", ref_py="1.64e3-1.68e3 steps/s/process"),
+    "traffic": dict(algo=1134, obs=520, state=240, resident=240, stream=60, n_act=3, act_shape=(9,), dtype="int32", ref_py="1.75e3-1.90e3 steps/s/process"),
+    "parking": dict(algo=662,  obs=52, state=288, resident=288, stream=24, n_act=8, act_shape=(),   dtype="f64", ref_py="2.66e4 steps/s/process"),
+    "climate": dict(algo=218,  obs=36, state=80, resident=80, stream=0, n_act=None, act_shape=None, dtype="f64", ref_py="1.27e4 steps/s/process"),
     # fleet's rollout is K (step, dense) launch pairs: the record goes through HBM every step
-    "fleet":   dict(algo=642,  obs=304, state=160, resident=0, stream=0, n_act=8, act_shape=(3,), dtype="f64",
-                    step_kernel="cge::fleet::step_kernel + cge::fleet::dense_kernel",
-                    roll_kernel="cge::fleet::step_kernel + cge::fleet::dense_kernel", launches_per_step=True, ref_py="2.01e4 steps/s/process"),
+    "fleet":   dict(algo=642,  obs=304, state=160, resident=0, stream=0, n_act=8, act_shape=(3,), dtype="f64", launches_per_step=True, ref_py="2.01e4 steps/s/process"),
     # 972 obs + 2 x 768 state + action/reward/flags + ~70 MT19937 words read and written per step (2 x 280); only the 96-byte
     # MISC group stays in registers across fused steps, the doctor / nurse / bed / equipment groups are re-loaded per step
-    "hospital": dict(algo=3078, obs=972, state=768, resident=96, stream=560, n_act=35, act_shape=(), dtype="f64",
-                     step_kernel="cge::hosp::step_kernel<false>", roll_kernel="cge::hosp::step_kernel<true>", ref_py="not in BASELINE.md"),
+    "hospital": dict(algo=3078, obs=972, state=768, resident=96, stream=560, n_act=35, act_shape=(), dtype="f64", ref_py="not in BASELINE.md"),
     # 292 obs + 2 x 336 state + action/reward/flags; plus 10 bytes (quality f64 + meta u16) per product in the system, which the
     # per-type np.mean of the observation has to read every step: added from the measured mean occupancy (algo_per_product)
-    "manufacturing": dict(algo=974, algo_per_product=10, obs=292, state=336, resident=336, stream=0, n_act=25, act_shape=(), dtype="f64",
-                          step_kernel="cge::mfg::step_kernel<false>", roll_kernel="cge::mfg::step_kernel<true>", ref_py="not in BASELINE.md"),
+    "manufacturing": dict(algo=974, algo_per_product=10, obs=292, state=336, resident=336, stream=0, n_act=25, act_shape=(), dtype="f64", ref_py="not in BASELINE.md"),
 }
 WORKLOADS = {
     "snake_1m": dict(env="snake", n=1 << 20, desc="SnakeEnv 10x10, 1,048,576 parallel envs per GPU, random actions, fused auto-reset"),
@@ -287,6 +279,9 @@ class _DryEnv:
     def invalid_action_count(self):
         return 0
 
+    def last_kernel(self):
+        return "dry-run"
+
     def close(self):
         pass
 
@@ -378,9 +373,12 @@ def main():
     budget = args.traj_gib * (1 << 30) / (1 if len(names) == 1 else 4)
     kc = {nm: max(1, min(K, int(budget // (n * ENVS[nm]["obs"])))) for nm in names}
     launched = {}                                        # kernel name -> env-steps launched (for --manifest)
+    ran = {}                                             # (env type, path) -> the kernel the library says it launched last
 
     def count(nm, path, steps):
-        kern = ENVS[nm]["roll_kernel" if path == "rollout" else "step_kernel"]
+        # the library reports the kernel it dispatched (cge_<env>_last_kernel): nothing here guesses a template instance
+        kern = envs[nm].last_kernel()
+        ran[(nm, path)] = kern
         launched[kern] = launched.get(kern, 0) + n * steps
 
     def run_rollout(k_total, t0):
@@ -390,8 +388,8 @@ def main():
                 while done < k_total:
                     k = min(kc[nm], k_total - done)
                     envs[nm].rollout(k, action_seed=123, t0=t0 + done, trajectory=True, per_step=True)
+                    count(nm, "rollout", k)
                     done += k
-                count(nm, "rollout", k_total)
 
     def run_steps(actions, lo, hi):
         for t in range(lo, hi):
@@ -466,7 +464,7 @@ def main():
             b = {"path": path, "value": total_envs * K / wall, "unit": "env-steps/s", "ms_per_step": wall * 1e3 / K}
             rl = {}
             for nm in names:
-                kern = ENVS[nm]["roll_kernel" if path == "rollout" else "step_kernel"]
+                kern = ran[(nm, path)]                   # set by the timed region's own launches (the last thing each leg ran)
                 # fleet's rollout is K (step, dense) launch pairs, not one fused launch: price it per pair
                 fused = path == "rollout" and not ENVS[nm].get("launches_per_step")
                 launches = -(-K // kc[nm]) if fused else K

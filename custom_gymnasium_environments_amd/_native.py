@@ -78,6 +78,7 @@ SIGNATURES = {
     "cge_snake_device_bytes": (_sz, [_vp]),
     "cge_snake_episode_stats": (C.c_int, [_vp, _vp, _vp]),
     "cge_snake_last_error": (C.c_char_p, [_vp]),
+    "cge_snake_last_kernel": (C.c_char_p, [_vp]),
     "cge_crypto_default_config": (None, [C.POINTER(CryptoConfig)]),
     "cge_crypto_create": (C.c_int, [C.POINTER(CryptoConfig), _i64, C.c_int, _i64, C.POINTER(_vp)]),
     "cge_crypto_destroy": (C.c_int, [_vp]),
@@ -92,6 +93,7 @@ SIGNATURES = {
     "cge_crypto_device_bytes": (_sz, [_vp]),
     "cge_crypto_episode_stats": (C.c_int, [_vp, _vp, _vp]),
     "cge_crypto_last_error": (C.c_char_p, [_vp]),
+    "cge_crypto_last_kernel": (C.c_char_p, [_vp]),
     "cge_traffic_default_config": (None, [C.POINTER(TrafficConfig)]),
     "cge_traffic_create": (C.c_int, [C.POINTER(TrafficConfig), _i64, C.c_int, _i64, C.POINTER(_vp)]),
     "cge_traffic_destroy": (C.c_int, [_vp]),
@@ -107,6 +109,7 @@ SIGNATURES = {
     "cge_traffic_device_bytes": (_sz, [_vp]),
     "cge_traffic_episode_stats": (C.c_int, [_vp, _vp, _vp]),
     "cge_traffic_last_error": (C.c_char_p, [_vp]),
+    "cge_traffic_last_kernel": (C.c_char_p, [_vp]),
     "cge_parking_create": (C.c_int, [C.POINTER(ParkingConfig), _i64, C.c_int, _i64, C.POINTER(_vp)]),
     "cge_parking_destroy": (C.c_int, [_vp]),
     "cge_parking_seed": (C.c_int, [_vp, _vp, _u64, _vp]),
@@ -121,6 +124,7 @@ SIGNATURES = {
     "cge_parking_device_bytes": (_sz, [_vp]),
     "cge_parking_episode_stats": (C.c_int, [_vp, _vp, _vp]),
     "cge_parking_last_error": (C.c_char_p, [_vp]),
+    "cge_parking_last_kernel": (C.c_char_p, [_vp]),
     "cge_climate_create": (C.c_int, [C.POINTER(ClimateConfig), _i64, C.c_int, _i64, C.POINTER(_vp)]),
     "cge_climate_destroy": (C.c_int, [_vp]),
     "cge_climate_seed": (C.c_int, [_vp, _vp, _u64, _vp]),
@@ -134,6 +138,7 @@ SIGNATURES = {
     "cge_climate_device_bytes": (_sz, [_vp]),
     "cge_climate_episode_stats": (C.c_int, [_vp, _vp, _vp]),
     "cge_climate_last_error": (C.c_char_p, [_vp]),
+    "cge_climate_last_kernel": (C.c_char_p, [_vp]),
     "cge_fleet_create": (C.c_int, [C.POINTER(FleetConfig), _i64, C.c_int, _i64, C.POINTER(_vp)]),
     "cge_fleet_destroy": (C.c_int, [_vp]),
     "cge_fleet_seed": (C.c_int, [_vp, _vp, _u64, _vp]),
@@ -147,6 +152,7 @@ SIGNATURES = {
     "cge_fleet_device_bytes": (_sz, [_vp]),
     "cge_fleet_episode_stats": (C.c_int, [_vp, _vp, _vp]),
     "cge_fleet_last_error": (C.c_char_p, [_vp]),
+    "cge_fleet_last_kernel": (C.c_char_p, [_vp]),
     "cge_manufacturing_create": (C.c_int, [C.POINTER(ManufacturingConfig), _i64, C.c_int, _i64, C.POINTER(_vp)]),
     "cge_manufacturing_destroy": (C.c_int, [_vp]),
     "cge_manufacturing_seed": (C.c_int, [_vp, _vp, _u64, _vp]),
@@ -160,6 +166,7 @@ SIGNATURES = {
     "cge_manufacturing_device_bytes": (_sz, [_vp]),
     "cge_manufacturing_episode_stats": (C.c_int, [_vp, _vp, _vp]),
     "cge_manufacturing_last_error": (C.c_char_p, [_vp]),
+    "cge_manufacturing_last_kernel": (C.c_char_p, [_vp]),
     "cge_hospital_create": (C.c_int, [C.POINTER(HospitalConfig), _i64, C.c_int, _i64, C.POINTER(_vp)]),
     "cge_hospital_destroy": (C.c_int, [_vp]),
     "cge_hospital_seed": (C.c_int, [_vp, _vp, _u64, _vp]),
@@ -173,6 +180,7 @@ SIGNATURES = {
     "cge_hospital_device_bytes": (_sz, [_vp]),
     "cge_hospital_episode_stats": (C.c_int, [_vp, _vp, _vp]),
     "cge_hospital_last_error": (C.c_char_p, [_vp]),
+    "cge_hospital_last_kernel": (C.c_char_p, [_vp]),
 }
 
 _lib = None

@@ -18,6 +18,7 @@ struct HandleBase {
     int64_t n = 0;
     int64_t env0 = 0;
     std::string last_error;
+    std::string last_kernel;       // the kernel(s) the last step() / rollout() call launched, as rocprofv3 prints them (<env>_last_kernel)
     size_t device_bytes = 0;
     double *ep_ret = nullptr;      // episode-statistics outputs registered by <env>_episode_stats (caller-owned device buffers)
     int32_t *ep_len = nullptr;

@@ -349,6 +349,7 @@ int cge_climate_step(cge_climate *h, const float *ac_temp, const int8_t *lights,
     p.ac = ac_temp; p.lights = lights; p.obs = obs_out; p.reward = reward_out; p.terminated = terminated_out; p.truncated = truncated_out;
     p.final_obs = final_obs_out; p.k_steps = 1;
     hipLaunchKernelGGL(climate::step_kernel<false>, dim3(h->blocks()), dim3(climate::BLOCK), 0, as_stream(stream), p);
+    h->last_kernel = "cge::climate::step_kernel<false>";
     CGE_TRY(h, hipGetLastError());
     return CGE_OK;
 }
@@ -365,6 +366,7 @@ int cge_climate_rollout(cge_climate *h, int32_t k_steps, const float *ac_temp, c
     p.k_steps = k_steps; p.ac = ac_temp; p.lights = lights; p.a_seed = action_seed; p.t0 = t0; p.obs = obs_out; p.obs_step_stride = obs_step_stride;
     p.reward = reward_traj_out; p.terminated = terminated_traj_out; p.reward_sum = reward_sum_out; p.done_count = done_count_out;
     hipLaunchKernelGGL(climate::step_kernel<true>, dim3(h->blocks()), dim3(climate::BLOCK), 0, as_stream(stream), p);
+    h->last_kernel = "cge::climate::step_kernel<true>";
     CGE_TRY(h, hipGetLastError());
     return CGE_OK;
 }
@@ -388,5 +390,7 @@ int cge_climate_episode_stats(cge_climate *h, double *return_out, int32_t *lengt
 }
 
 const char *cge_climate_last_error(const cge_climate *h) { return h ? h->last_error.c_str() : "null handle"; }
+
+const char *cge_climate_last_kernel(const cge_climate *h) { return h ? h->last_kernel.c_str() : ""; }
 
 }  // extern "C"

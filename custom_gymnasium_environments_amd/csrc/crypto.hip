@@ -1122,6 +1122,7 @@ static hipError_t launch_resident(cge_crypto *h, const crypto::Params &p, hipStr
     }
     if (one_step) hipLaunchKernelGGL(crypto::resident_kernel<true>, dim3(h->blocks()), dim3(crypto::RES_WAVES * crypto::BLOCK), crypto::RES_LDS, s, p);
     else hipLaunchKernelGGL(crypto::resident_kernel<false>, dim3(h->blocks()), dim3(crypto::RES_WAVES * crypto::BLOCK), crypto::RES_LDS, s, p);
+    h->last_kernel = one_step ? "cge::crypto::resident_kernel<true>" : "cge::crypto::resident_kernel<false>";
     return hipGetLastError();
 }
 
@@ -1229,7 +1230,7 @@ int cge_crypto_step(cge_crypto *h, const void *actions, float *obs_out, float *r
     p.final_obs = final_obs_out; p.k_steps = 1;
     // the four-wave resident kernel also serves a single step: its waves share the row, feature and market work of the 64 envs
     if (resident_mode() >= 2) CGE_TRY(h, launch_resident(h, p, as_stream(stream), true));
-    else hipLaunchKernelGGL(crypto::step_kernel<false>, dim3(h->blocks()), dim3(crypto::BLOCK), 0, as_stream(stream), p);
+    else { hipLaunchKernelGGL(crypto::step_kernel<false>, dim3(h->blocks()), dim3(crypto::BLOCK), 0, as_stream(stream), p); h->last_kernel = "cge::crypto::step_kernel<false>"; }
     CGE_TRY(h, hipGetLastError());
     h->phase = (h->phase + 1) % crypto::HLEN;
     return CGE_OK;
@@ -1247,7 +1248,7 @@ int cge_crypto_rollout(cge_crypto *h, int32_t k_steps, const void *actions, uint
     p.k_steps = k_steps; p.actions = actions; p.a_seed = action_seed; p.t0 = t0; p.obs = obs_out; p.obs_step_stride = obs_step_stride;
     p.reward = reward_traj_out; p.terminated = terminated_traj_out; p.reward_sum = reward_sum_out; p.done_count = done_count_out;
     if (resident_mode() >= 1 && k_steps >= 2) CGE_TRY(h, launch_resident(h, p, as_stream(stream), false));
-    else hipLaunchKernelGGL(crypto::step_kernel<true>, dim3(h->blocks()), dim3(crypto::BLOCK), 0, as_stream(stream), p);
+    else { hipLaunchKernelGGL(crypto::step_kernel<true>, dim3(h->blocks()), dim3(crypto::BLOCK), 0, as_stream(stream), p); h->last_kernel = "cge::crypto::step_kernel<true>"; }
     CGE_TRY(h, hipGetLastError());
     h->phase = (h->phase + k_steps) % crypto::HLEN;
     return CGE_OK;
@@ -1369,5 +1370,7 @@ int cge_crypto_episode_stats(cge_crypto *h, double *return_out, int32_t *length_
 }
 
 const char *cge_crypto_last_error(const cge_crypto *h) { return h ? h->last_error.c_str() : "null handle"; }
+
+const char *cge_crypto_last_kernel(const cge_crypto *h) { return h ? h->last_kernel.c_str() : ""; }
 
 }  // extern "C"

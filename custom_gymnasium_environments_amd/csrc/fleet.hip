@@ -703,6 +703,7 @@ struct cge_fleet : HandleBase {
             hipLaunchKernelGGL(fleet::dense_kernel, dim3(db < 1024u ? db : 1024u), dim3(fleet::BLOCK), 0, s, p, 0);
             parity ^= 1;
         }
+        last_kernel = "cge::fleet::step_kernel + cge::fleet::dense_kernel";
         return hipGetLastError();
     }
     hipError_t launch_all(fleet::Params &p, int what, hipStream_t s) {
@@ -853,5 +854,7 @@ int cge_fleet_episode_stats(cge_fleet *h, double *return_out, int32_t *length_ou
 }
 
 const char *cge_fleet_last_error(const cge_fleet *h) { return h ? h->last_error.c_str() : "null handle"; }
+
+const char *cge_fleet_last_kernel(const cge_fleet *h) { return h ? h->last_kernel.c_str() : ""; }
 
 }  // extern "C"

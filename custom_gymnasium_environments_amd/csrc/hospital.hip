@@ -1044,6 +1044,7 @@ int cge_hospital_step(cge_hospital *h, const int32_t *actions, float *obs_out, f
     p.actions = actions; p.obs = obs_out; p.reward = reward_out; p.terminated = terminated_out; p.truncated = truncated_out;
     p.final_obs = final_obs_out; p.k_steps = 1;
     hipLaunchKernelGGL(hosp::step_kernel<false>, dim3(h->blocks()), dim3(hosp::BLOCK), 0, as_stream(stream), p);
+    h->last_kernel = "cge::hosp::step_kernel<false>";
     CGE_TRY(h, hipGetLastError());
     return CGE_OK;
 }
@@ -1060,6 +1061,7 @@ int cge_hospital_rollout(cge_hospital *h, int32_t k_steps, const int32_t *action
     p.k_steps = k_steps; p.actions = actions; p.a_seed = action_seed; p.t0 = t0; p.obs = obs_out; p.obs_step_stride = obs_step_stride;
     p.reward = reward_traj_out; p.terminated = terminated_traj_out; p.reward_sum = reward_sum_out; p.done_count = done_count_out;
     hipLaunchKernelGGL(hosp::step_kernel<true>, dim3(h->blocks()), dim3(hosp::BLOCK), 0, as_stream(stream), p);
+    h->last_kernel = "cge::hosp::step_kernel<true>";
     CGE_TRY(h, hipGetLastError());
     return CGE_OK;
 }
@@ -1083,5 +1085,7 @@ int cge_hospital_episode_stats(cge_hospital *h, double *return_out, int32_t *len
 }
 
 const char *cge_hospital_last_error(const cge_hospital *h) { return h ? h->last_error.c_str() : "null handle"; }
+
+const char *cge_hospital_last_kernel(const cge_hospital *h) { return h ? h->last_kernel.c_str() : ""; }
 
 }  // extern "C"

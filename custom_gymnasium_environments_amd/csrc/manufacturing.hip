@@ -844,6 +844,7 @@ int cge_manufacturing_step(cge_manufacturing *h, const int32_t *actions, float *
     p.actions = actions; p.obs = obs_out; p.reward = reward_out; p.terminated = terminated_out; p.truncated = truncated_out;
     p.final_obs = final_obs_out; p.k_steps = 1;
     hipLaunchKernelGGL(mfg::step_kernel<false>, dim3(h->blocks()), dim3(mfg::BLOCK), 0, as_stream(stream), p);
+    h->last_kernel = "cge::mfg::step_kernel<false>";
     CGE_TRY(h, hipGetLastError());
     return CGE_OK;
 }
@@ -860,6 +861,7 @@ int cge_manufacturing_rollout(cge_manufacturing *h, int32_t k_steps, const int32
     p.k_steps = k_steps; p.actions = actions; p.a_seed = action_seed; p.t0 = t0; p.obs = obs_out; p.obs_step_stride = obs_step_stride;
     p.reward = reward_traj_out; p.terminated = terminated_traj_out; p.reward_sum = reward_sum_out; p.done_count = done_count_out;
     hipLaunchKernelGGL(mfg::step_kernel<true>, dim3(h->blocks()), dim3(mfg::BLOCK), 0, as_stream(stream), p);
+    h->last_kernel = "cge::mfg::step_kernel<true>";
     CGE_TRY(h, hipGetLastError());
     return CGE_OK;
 }
@@ -883,5 +885,7 @@ int cge_manufacturing_episode_stats(cge_manufacturing *h, double *return_out, in
 }
 
 const char *cge_manufacturing_last_error(const cge_manufacturing *h) { return h ? h->last_error.c_str() : "null handle"; }
+
+const char *cge_manufacturing_last_kernel(const cge_manufacturing *h) { return h ? h->last_kernel.c_str() : ""; }
 
 }  // extern "C"

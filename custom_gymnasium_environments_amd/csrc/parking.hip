@@ -525,6 +525,7 @@ int cge_parking_step(cge_parking *h, const int32_t *actions, float *obs_out, flo
     p.actions = actions; p.obs = obs_out; p.reward = reward_out; p.terminated = terminated_out; p.truncated = truncated_out;
     p.final_obs = final_obs_out; p.k_steps = 1;
     hipLaunchKernelGGL(parking::step_kernel<false>, dim3(h->blocks()), dim3(parking::BLOCK), 0, as_stream(stream), p);
+    h->last_kernel = "cge::parking::step_kernel<false>";
     CGE_TRY(h, hipGetLastError());
     return CGE_OK;
 }
@@ -541,6 +542,7 @@ int cge_parking_rollout(cge_parking *h, int32_t k_steps, const int32_t *actions,
     p.k_steps = k_steps; p.actions = actions; p.a_seed = action_seed; p.t0 = t0; p.obs = obs_out; p.obs_step_stride = obs_step_stride;
     p.reward = reward_traj_out; p.terminated = terminated_traj_out; p.reward_sum = reward_sum_out; p.done_count = done_count_out;
     hipLaunchKernelGGL(parking::step_kernel<true>, dim3(h->blocks()), dim3(parking::BLOCK), 0, as_stream(stream), p);
+    h->last_kernel = "cge::parking::step_kernel<true>";
     CGE_TRY(h, hipGetLastError());
     return CGE_OK;
 }
@@ -576,5 +578,7 @@ int cge_parking_episode_stats(cge_parking *h, double *return_out, int32_t *lengt
 }
 
 const char *cge_parking_last_error(const cge_parking *h) { return h ? h->last_error.c_str() : "null handle"; }
+
+const char *cge_parking_last_kernel(const cge_parking *h) { return h ? h->last_kernel.c_str() : ""; }
 
 }  // extern "C"

@@ -13,8 +13,10 @@
 // env is all a step() reads and writes for snakes up to 29 cells — older moves live in two cold columns, and the occupancy
 // bits are not stored: they are rebuilt in registers by the head-to-tail walk when the record is loaded.
 // The whole record lives in VGPRs during a step (static-index mask/select chains, cge_device.hpp).
-// Food placement (the only RNG use) fetches a window of the env's MT19937 block in ONE round trip,
-// issued before the observation is staged so its latency hides behind that work.
+// Food placement (the only RNG use) never opens the env's 2560-byte MT19937 block on the common path: every env owns a RING of
+// 64 pre-drawn digits (the top KBITS bits of the next generator words, tempered) in two uint4 columns next to the state, with
+// the number of digits left in the hot record; a placement reads two dwords of it, and the ring is refilled wave-cooperatively
+// (64 lanes twist 64 consecutive words of ONE env) when it runs dry — once per ~256 env-steps per env (DigitQ below).
 // The (N,G,G) int8 observation is built in LDS (one row per lane, dword stride G*G/4 — odd for
 // G=10, so conflict-free) and streamed out as 16-byte-per-lane stores.
 #include <cstdlib>
@@ -35,17 +37,17 @@ constexpr int bitlen(int n) {
 }
 
 enum : uint32_t { F_NEEDS_RESET = 1u, F_BOARD_FULL = 2u, F_FOOD_VALID = 4u };
-constexpr int FOOD_WINDOW = 8;   // default MT words fetched per round trip by _place_food (mean use: 3.2 for G=10)
 
 template <int G>
 struct Lay {
     static constexpr int CELLS = G * G;
     static constexpr int OCCW = (CELLS + 31) / 32;
     static constexpr int SRW = (2 * (CELLS - 1) + 31) / 32;   // move history: 2 bits per body segment behind the head
-    // G=10 (the benchmark grid): a 16-byte HOT record holds every scalar and the 28 most recent moves; older moves spill into two
-    // cold columns that only snakes longer than 29 / 93 cells ever touch.  Occupancy is not stored at all there (see Env).
+    // G=10 (the benchmark grid): a 16-byte HOT record holds every scalar and the 24 most recent moves; older moves spill into two
+    // cold columns that only snakes longer than 25 / 89 cells ever touch.  Occupancy is not stored at all there (see Env).
     static constexpr bool TIGHT = (G == 10);
-    static constexpr int HOT_DIRS = 28, COLD0_DIRS = 64;
+    static constexpr int HOT_SH = 15;                          // bit of hot word 2 at which the move history starts
+    static constexpr int HOT_DIRS = (2 * 32 - HOT_SH) / 2, COLD0_DIRS = 64;   // 24 moves in the hot record
     static constexpr int NW = TIGHT ? 12 : OCCW + SRW + 4;
     static constexpr int COLS = (NW + 3) / 4;
     static constexpr int OBS_DW = CELLS / 4;
@@ -71,7 +73,7 @@ struct Env {
     using L = Lay<G>;
     uint32_t occ[L::OCCW];
     uint32_t sr[L::SRW];
-    uint32_t head, tail, len, food, dir, steps, score, flags, episodes, mt_pos, mt_pretw;
+    uint32_t head, tail, len, food, dir, steps, score, flags, episodes, mt_pos, mt_pretw, dq_left;
 
     __device__ __forceinline__ void load(const uint4 *__restrict__ state, int64_t n, int64_t i) {
         uint32_t raw[L::COLS * 4];
@@ -108,8 +110,10 @@ struct Env {
     }
     // G=10 hot record  w0: head:7 | len:7 @7 | food:7 @14 | dir:2 @21 | flags:3 @23 | score[5:0] @26
     //                  w1: steps:12 | mt_pos:10 @12 | mt_pretw!=0 @22 | score[6] @23 | episodes[7:0] @24
-    //                  w2: episodes[15:8] | sr bits 0..23 @8      w3: sr bits 24..55
-    //       cold words 4..11: sr bits 56..  (read / written only when len-1 > 28, words 8.. only when len-1 > 92)
+    //                  w2: episodes[15:8] | dq_left:7 @8 | sr bits 0..16 @15      w3: sr bits 17..48
+    //       cold words 4..11: sr bits 49..  (read / written only when len-1 > 24, words 8.. only when len-1 > 88)
+    // mt_pos (0..624) is the first generator word that has NOT been turned into a digit yet; the dq_left digits in the env's
+    // ring are those of words [mt_pos - dq_left, mt_pos), so the CPython cursor of the stream is mt_pos - dq_left.
     __host__ __device__ __forceinline__ void unpack(const uint32_t *raw) {
         if constexpr (L::TIGHT) {
             const uint32_t w0 = raw[0], w1 = raw[1], w2 = raw[2];
@@ -117,9 +121,9 @@ struct Env {
             score = (w0 >> 26) | (((w1 >> 23) & 1u) << 6);
             steps = w1 & 0xFFFu; mt_pos = (w1 >> 12) & 1023u; mt_pretw = (w1 & (1u << 22)) ? (uint32_t)MT_N : 0u;
             episodes = (w1 >> 24) | ((w2 & 0xFFu) << 8);
-            sr[0] = (w2 >> 8) | (raw[3] << 24);
+            dq_left = (w2 >> 8) & 127u;
 #pragma unroll
-            for (int k = 1; k < L::SRW; ++k) sr[k] = (raw[2 + k] >> 8) | (raw[3 + k] << 24);
+            for (int k = 0; k < L::SRW; ++k) sr[k] = (raw[2 + k] >> L::HOT_SH) | (raw[3 + k] << (32 - L::HOT_SH));
             mask_history();
             rebuild_occupancy();
         } else {
@@ -131,7 +135,7 @@ struct Env {
             head = m0 & 1023u; tail = (m0 >> 10) & 1023u; food = (m0 >> 20) & 1023u; dir = m0 >> 30;
             steps = m1 & 0xffffu; score = (m1 >> 16) & 1023u; flags = m1 >> 26;
             episodes = raw[L::OCCW + L::SRW + 2];
-            mt_pos = m3 & 1023u; mt_pretw = (m3 & 1024u) ? (uint32_t)MT_N : 0u; len = m3 >> 11;
+            mt_pos = m3 & 1023u; mt_pretw = (m3 & 1024u) ? (uint32_t)MT_N : 0u; len = (m3 >> 11) & 1023u; dq_left = (m3 >> 24) & 127u;
         }
     }
     __host__ __device__ __forceinline__ void pack(uint32_t *raw) const {
@@ -139,10 +143,10 @@ struct Env {
             const uint32_t ep = episodes < L::MAX_EPISODES ? episodes : L::MAX_EPISODES;
             raw[0] = head | (len << 7) | (food << 14) | (dir << 21) | (flags << 23) | ((score & 63u) << 26);
             raw[1] = steps | (mt_pos << 12) | (mt_pretw ? (1u << 22) : 0u) | (((score >> 6) & 1u) << 23) | ((ep & 0xFFu) << 24);
-            raw[2] = (ep >> 8) | (sr[0] << 8);
+            raw[2] = (ep >> 8) | (dq_left << 8) | (sr[0] << L::HOT_SH);
 #pragma unroll
-            for (int k = 1; k < L::SRW; ++k) raw[2 + k] = (sr[k - 1] >> 24) | (sr[k] << 8);
-            raw[2 + L::SRW] = sr[L::SRW - 1] >> 24;
+            for (int k = 1; k < L::SRW; ++k) raw[2 + k] = (sr[k - 1] >> (32 - L::HOT_SH)) | (sr[k] << L::HOT_SH);
+            raw[2 + L::SRW] = sr[L::SRW - 1] >> (32 - L::HOT_SH);
 #pragma unroll
             for (int k = 3 + L::SRW; k < 12; ++k) raw[k] = 0;
         } else {
@@ -153,7 +157,7 @@ struct Env {
             raw[L::OCCW + L::SRW] = head | (tail << 10) | (food << 20) | (dir << 30);
             raw[L::OCCW + L::SRW + 1] = steps | (score << 16) | (flags << 26);
             raw[L::OCCW + L::SRW + 2] = episodes;
-            raw[L::OCCW + L::SRW + 3] = mt_pos | (mt_pretw ? 1024u : 0u) | (len << 11);
+            raw[L::OCCW + L::SRW + 3] = mt_pos | (mt_pretw ? 1024u : 0u) | (len << 11) | (dq_left << 24);
 #pragma unroll
             for (int k = L::NW; k < L::COLS * 4; ++k) raw[k] = 0;
         }
@@ -208,40 +212,6 @@ struct Env {
             return false;
         }
         return true;
-    }
-
-    // snake_env.py:121-129 — `random.randint(0,G-1)` twice (row first, then column), each
-    // _randbelow(G): r = next_u32 >> (32-k), redrawn while r >= G; the pair is redrawn while it lies
-    // on the snake.  `win` was loaded at the current cursor; a reload happens only if 8 words were
-    // not enough (0.6 % of placements for G=10).
-    template <int FW>
-    __device__ __forceinline__ void place_food(uint32_t *__restrict__ blk, MtWindow<FW> &win) {
-        uint32_t phase = 0, row = 0;
-        for (;;) {
-            uint32_t used = 0;
-            bool done = false;
-#pragma unroll
-            for (int j = 0; j < FW; ++j) {
-                if (!done) {
-                    const uint32_t r = win.draw(j, mt_pos, mt_pretw) >> (32 - L::KBITS);
-                    used = j + 1;
-                    if (r < (uint32_t)G) {
-                        if (phase == 0) {
-                            row = r;
-                            phase = 1;
-                        } else {
-                            phase = 0;
-                            const uint32_t cell = row * G + r;
-                            if (!occupied(cell)) { food = cell; done = true; }
-                        }
-                    }
-                }
-            }
-            win.commit(blk, mt_pos, mt_pretw, used);
-            if (done) break;
-            win.load(blk, mt_pos);
-        }
-        flags |= F_FOOD_VALID;
     }
 
     // snake_env.py:49-65 without the trailing _place_food()
@@ -321,6 +291,7 @@ struct Env {
 
 struct Params {
     uint4 *state;
+    uint4 *dq;            // digit rings (DigitQ), COLS columns of uint4
     uint32_t *mt;
     int64_t n, env0;
     const int32_t *actions;
@@ -330,6 +301,7 @@ struct Params {
     uint8_t *terminated, *truncated;
     int8_t *final_obs;
     int32_t mode, max_steps, k_steps;
+    uint32_t dq_topup;    // rollout: rings with fewer digits than this are topped up when the launch starts (host: by k_steps)
     uint64_t a_seed;
     int64_t t0, obs_step_stride;
     float *reward_sum;
@@ -341,191 +313,163 @@ struct Params {
 
 __device__ __forceinline__ uint32_t shfl_u32(uint32_t v, uint32_t src) { return (uint32_t)__shfl((int)v, (int)src, 64); }
 
-// Wave-cooperative _place_food (snake_env.py:121-129).  Under random play ~7 % of the lanes need a new food cell in a
-// step, so virtually every wave has one — and a per-lane placement loop (8 window words: load, twist, temper, reject,
-// occupancy test, commit) made all 64 lanes pay ~650 VALU for the few that needed it.  Here the lanes that need food are
-// served 8 at a time by groups of 8 lanes: lane j of group g draws word j of owner g's MT19937 window, the (row, col)
-// pairing with rejection is resolved with ballots inside the group, the consumed words are committed by the lanes that
-// produced them and one packed word goes back to the owner.  Must be called by all 64 lanes of the wave.
+// ------------------------------------------------------------------ the env's digit ring (DigitQ)
+// _place_food (snake_env.py:121-129) only ever looks at the top KBITS bits of a generator word (`getrandbits(k)` inside
+// `random.randint`), ~0.25 words per env-step under random play.  Opening the env's 2560-byte MT19937 block for that — three
+// scattered lines read, one written back, per placement — was a quarter of step()'s HBM traffic (round 2: 33 of 176 bytes per
+// env-step), and inside a fused rollout the block loads queued behind the CU's backlog of observation stores.  So the digits
+// are drawn ahead of time and kept NEXT TO THE STATE:
+//   * ring: SLOTS = 64 digits of DB bits (4 for G <= 15, else 8) per env in COLS uint4 columns, struct-of-arrays like the state
+//     (column c of env i at dq[c*N + i]); the digit of generator word w sits in slot w mod 64.
+//   * cursor: Env::mt_pos = first word that has not been turned into a digit yet (0..624), Env::dq_left = digits not consumed
+//     yet — those of words [mt_pos - dq_left, mt_pos), so the ring's head slot is (mt_pos - dq_left) mod 64 and the stream's
+//     CPython cursor is mt_pos - dq_left.  Both live in the hot record: a placement costs no dependent "load the cursor" trip.
+//   * refill (dq_refill): wave-cooperative and per env — lane l serves slot l: it loads the three state words its word needs
+//     (64 CONSECUTIVE words per load instruction: coalesced, unlike a lane walking its own block), twists the word in place
+//     (the block is advanced exactly as CPython's batch regeneration would, one word at a time), tempers it and ORs the digit
+//     into the ring.  A refill tops the ring up to 64 digits but never crosses word 623: every parked digit belongs to the
+//     generation of mt_pos, which keeps cge_snake_get_state's canonical (CPython) form a plain "twist the rest" away; the
+//     generation wraps when the ring is empty at word 624.
+//   * use: step() loads the ring columns of just the lanes that place food (~8 %), the fused rollout parks every lane's ring in
+//     LDS for the launch and tops up the lanes that are likely to run dry (threshold by k_steps) before the first observation
+//     store is in flight; both write a ring back only if it was refilled.  There is ONE rollout kernel for every k_steps
+//     (round 2 had a per-launch queue for k >= 24 and per-step window loads below: the driver's 20-step launch ran the slow one).
 template <int G>
-__device__ __forceinline__ void wave_place_food(Env<G> &e, uint32_t *blk, bool need) {
-    using L = Lay<G>;
-    const uint32_t lane = threadIdx.x & 63u, g = lane >> 3, j = lane & 7u;
-    const uint32_t plo = (uint32_t)reinterpret_cast<uintptr_t>(blk), phi = (uint32_t)(reinterpret_cast<uintptr_t>(blk) >> 32);
-    uint32_t carry = 0;                                        // owner side: bit 0 = a row is pending, bits 1.. = that row
-    bool pending_me = need;
-    unsigned long long pending = __ballot(pending_me);
-#pragma unroll 1
-    while (pending) {
-        unsigned long long m = pending;
-        uint32_t owner = 64u;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {                          // the q-th pending lane owns group q in this pass
-            const uint32_t o = m ? (uint32_t)__ffsll((long long)m) - 1u : 64u;
-            m = m ? (m & (m - 1ull)) : 0ull;
-            owner = g == (uint32_t)q ? o : owner;
-        }
-        const bool active = owner < 64u;
-        const uint32_t src = active ? owner : lane;
-        const uint32_t *oblk = reinterpret_cast<const uint32_t *>(((uint64_t)shfl_u32(phi, src) << 32) | (uint64_t)shfl_u32(plo, src));
-        const uint32_t pos = shfl_u32(e.mt_pos, src), pretw = shfl_u32(e.mt_pretw, src), ocarry = shfl_u32(carry, src);
-        uint32_t occ[L::OCCW];
-#pragma unroll
-        for (int w = 0; w < L::OCCW; ++w) occ[w] = shfl_u32(e.occ[w], src);
-        uint32_t k = pos + j;
-        const bool ready = k < pretw;
-        k -= k >= (uint32_t)MT_N ? MT_N : 0;
-        const uint32_t k1 = k + 1 == (uint32_t)MT_N ? 0 : k + 1;
-        const uint32_t km = k + MT_M >= (uint32_t)MT_N ? k + MT_M - MT_N : k + MT_M;
-        uint32_t a = 0, b = 0, c = 0;
-        if (active) { a = oblk[k]; b = oblk[k1]; c = oblk[km]; }
-        const uint32_t y = ready ? a : mt_twist(a, b, c);
-        const uint32_t r = mt_temper(y) >> (32 - L::KBITS);
-        const bool valid = active && r < (uint32_t)G;
-        const uint32_t vm = (uint32_t)(__ballot(valid) >> (8u * g)) & 0xFFu;
-        const uint32_t below = vm & ((1u << j) - 1u);
-        const uint32_t idx = (uint32_t)__popc(below) + (ocarry & 1u);            // index among the valid draws, a carried row counts
-        const uint32_t prevj = below ? 31u - (uint32_t)__clz((int)below) : 0u;
-        const uint32_t rprev = shfl_u32(r, g * 8u + prevj);
-        const uint32_t row = below ? rprev : (ocarry >> 1);
-        const uint32_t cell = row * (uint32_t)G + r;
-        const bool cand = valid && (idx & 1u) && !((sel(occ, cell >> 5) >> (cell & 31u)) & 1u);
-        const uint32_t cm = (uint32_t)(__ballot(cand) >> (8u * g)) & 0xFFu;
-        const uint32_t jdone = cm ? (uint32_t)__ffs((int)cm) - 1u : 7u;
-        const uint32_t used = cm ? jdone + 1u : 8u;
-        if (active && j < used && pos + j >= pretw) mt_store(const_cast<uint32_t *>(oblk), k, y);   // persist the consumed words
-        const uint32_t wcell = shfl_u32(cell, g * 8u + jdone);
-        // not placed with these 8 words: an unpaired row (odd number of valid draws) carries into the next window
-        const uint32_t nv = (uint32_t)__popc(vm) + (ocarry & 1u);
-        const uint32_t lastv = vm ? 31u - (uint32_t)__clz((int)vm) : 0u;
-        const uint32_t rlast = shfl_u32(r, g * 8u + lastv);
-        const uint32_t ncarry = (nv & 1u) ? (1u | ((vm ? rlast : (ocarry >> 1)) << 1)) : 0u;
-        const uint32_t packed = wcell | (used << 10) | ((cm ? 1u : 0u) << 14) | (ncarry << 15);
-        // owners pick up their group's result
-        const uint32_t og = (uint32_t)__popcll(pending & ((1ull << lane) - 1ull));
-        const uint32_t res = shfl_u32(packed, (og < 8u ? og : 0u) * 8u);
-        if (pending_me && og < 8u) {
-            uint32_t np = e.mt_pos + ((res >> 10) & 15u);
-            if (np >= (uint32_t)MT_N) { np -= MT_N; e.mt_pretw = 0; }
-            e.mt_pos = np;
-            if ((res >> 14) & 1u) { e.food = res & 1023u; pending_me = false; }
-            else carry = res >> 15;
-        }
-        pending = __ballot(pending_me);
-    }
-    if (need) e.flags |= F_FOOD_VALID;
-}
-
-// ------------------------------------------------------------------ per-launch digit queue (fused rollout)
-// _place_food only ever looks at the top KBITS bits of a generator word (`getrandbits(k)`), and a 200-step launch consumes ~50
-// words per env.  The fused rollout therefore draws them up front: when a launch starts, every wave twists the next QN words
-// of each of its 64 envs cooperatively (64 lanes load 64 CONSECUTIVE state words of one env: coalesced, unlike a lane walking
-// its own 2560-byte block), tempers them and parks just the digits in LDS — 48 bytes per env for 10x10.  Inside the step loop a
-// placement is then pure VALU + LDS.  Why it matters: in the K-step loop the only global LOADS were these generator words, and on
-// gfx950 they queued behind the CU's backlog of observation STORES (loads and stores share the vector memory pipe): 22 us per
-// 1M-env step without any placement, 38 us with the per-step window loads (profiles/README.md, round 2).  The words a launch
-// consumed are committed (twisted in place, cursor advanced) once, after the last step; a wave whose queue runs low mid-launch
-// commits and refills — wave-convergent, rare (mean consumption 0.25 words per env-step).
-template <int G>
-struct QLay {
-    static constexpr int DB = Lay<G>::KBITS <= 4 ? 4 : 8;     // stored bits per digit
+struct DigitQ {
+    static constexpr int DB = Lay<G>::KBITS <= 4 ? 4 : 8;      // stored bits per digit
     static constexpr int PER = 32 / DB;                        // digits per dword = digits examined per placement round
-    static constexpr int QN = 96;                              // digits per fill (< 227: no window word depends on another)
-    static constexpr int QDW = QN / PER;
-    static constexpr int QROW = (QDW + 1) | 1;                 // odd dword stride, one pad word behind the last digit
-    static constexpr int MIN_STEPS = 24;                       // shorter launches keep the per-step window loads
+    static constexpr int SLOTS = 64;
+    static constexpr int QDW = SLOTS / PER;                    // dwords per ring (8 or 16)
+    static constexpr int COLS = QDW / 4;                       // uint4 columns per env
+    static constexpr int QROW = QDW + 1;                       // LDS row stride in dwords (odd: the 64 rows start in different banks)
+    static constexpr uint32_t DMASK = (1u << DB) - 1u;
+    static constexpr uint32_t ALL_COLS = (1u << COLS) - 1u;
 };
 
+// per-lane view of the ring while a kernel runs: the lane's row of the wave's LDS rows, which columns of it are loaded, whether
+// it has to go back to HBM
 template <int G>
-__device__ __forceinline__ void queue_fill(const Env<G> &e, const uint32_t *blk, uint32_t *wave_q, uint32_t &qcur, uint32_t &qlen) {
-    using L = Lay<G>;
-    using Q = QLay<G>;
-    constexpr int NQ = (Q::QN + 63) / 64, RG = 2;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t plo = (uint32_t)reinterpret_cast<uintptr_t>(blk), phi = (uint32_t)(reinterpret_cast<uintptr_t>(blk) >> 32);
-#pragma unroll 1
-    for (int r0 = 0; r0 < 64; r0 += RG) {
-        uint32_t a[RG][NQ], b[RG][NQ], c[RG][NQ];
+struct DqCtx {
+    uint32_t *wave_q;      // LDS: QROW dwords per lane of this wave
+    uint32_t *blk;         // this lane's generator block
+    uint4 *dq;             // global ring columns
+    int64_t n, i;          // batch size, this lane's env (a valid env for every lane, see the callers)
+    uint32_t loaded;       // bit c: column c of this lane's row is in LDS
+    bool dirty;
+
+    __device__ __forceinline__ uint32_t *my_row() const { return wave_q + (threadIdx.x & 63u) * DigitQ<G>::QROW; }
+    __device__ __forceinline__ void load_cols(uint32_t cols) {                  // cols: bit mask of columns to fetch (per lane)
+        using Q = DigitQ<G>;
+        uint32_t *row = my_row();
 #pragma unroll
-        for (int g = 0; g < RG; ++g) {                         // all loads of RG envs first: one round trip, not RG * NQ
-            const uint32_t *ob = lane_ptr(plo, phi, r0 + g);
-            const uint32_t pos = lane_u32(e.mt_pos, r0 + g) & 1023u;           // 10-bit field; a valid cursor is < 624, so k stays inside the 640-word block
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                uint32_t k = pos + 64u * q + lane;              // < 624 + 128: one wrap
-                k -= k >= (uint32_t)MT_N ? MT_N : 0;
-                const uint32_t k1 = k + 1 == (uint32_t)MT_N ? 0 : k + 1;
-                const uint32_t km = k + MT_M >= (uint32_t)MT_N ? k + MT_M - MT_N : k + MT_M;
-                a[g][q] = ob[k]; b[g][q] = ob[k1]; c[g][q] = ob[km];
+        for (int c = 0; c < Q::COLS; ++c) {
+            if (cols & ~loaded & (1u << c)) {
+                const uint4 v = dq[(int64_t)c * n + i];
+                row[4 * c] = v.x; row[4 * c + 1] = v.y; row[4 * c + 2] = v.z; row[4 * c + 3] = v.w;
             }
+        }
+        loaded |= cols;
+    }
+    __device__ __forceinline__ void write_back() {
+        using Q = DigitQ<G>;
+        if (!dirty) return;
+        const uint32_t *row = my_row();
+#pragma unroll
+        for (int c = 0; c < Q::COLS; ++c) dq[(int64_t)c * n + i] = make_uint4(row[4 * c], row[4 * c + 1], row[4 * c + 2], row[4 * c + 3]);
+        dirty = false;
+    }
+};
+
+// Top the rings of the lanes in `want` (a ballot) up to 64 digits, two envs per memory round trip.  Must be called by all 64
+// lanes of the wave.  Every load of a round precedes its stores (program order); lanes whose slot is not being filled re-read
+// the first word of the run.
+template <int G>
+__device__ __forceinline__ void dq_refill(Env<G> &e, DqCtx<G> &q, unsigned long long want) {
+    using L = Lay<G>;
+    using Q = DigitQ<G>;
+    constexpr int RG = 2;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t plo = (uint32_t)reinterpret_cast<uintptr_t>(q.blk), phi = (uint32_t)(reinterpret_cast<uintptr_t>(q.blk) >> 32);
+#pragma unroll 1
+    while (want) {
+        int r[RG];
+        bool has[RG];
+        uint32_t pos[RG], pretw[RG], left[RG], fill[RG], k[RG], a[RG], b[RG], c[RG];
+        uint32_t *ob[RG];
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+            has[g] = want != 0ull;
+            r[g] = has[g] ? (int)__builtin_ctzll(want) : r[0];
+            want = has[g] ? (want & (want - 1ull)) : 0ull;
+            uint32_t p = lane_u32(e.mt_pos, r[g]) & 1023u, lf = lane_u32(e.dq_left, r[g]) & 127u, pt = lane_u32(e.mt_pretw, r[g]);
+            p = p < (uint32_t)MT_N ? p : (uint32_t)MT_N;       // a valid cursor is <= 624: keeps every index inside the 640-word block
+            lf = lf < (uint32_t)Q::SLOTS ? lf : (uint32_t)Q::SLOTS;
+            if (p == (uint32_t)MT_N && lf == 0u) { p = 0u; pt = 0u; }          // the generation wraps on an empty ring
+            const uint32_t room = (uint32_t)Q::SLOTS - lf, rest = (uint32_t)MT_N - p;
+            pos[g] = p; pretw[g] = pt; left[g] = lf; fill[g] = room < rest ? room : rest;
+            const uint32_t j = (lane - p) & 63u;               // slot `lane` holds word p + j
+            const uint32_t kk = j < fill[g] ? p + j : (p < (uint32_t)MT_N ? p : 0u);
+            const uint32_t km = kk + MT_M >= (uint32_t)MT_N ? kk + MT_M - MT_N : kk + MT_M;
+            k[g] = kk;
+            ob[g] = lane_ptr(plo, phi, r[g]);
+            a[g] = ob[g][kk]; b[g] = ob[g][kk + 1]; c[g] = ob[g][km];          // kk + 1 <= 624: word 624 mirrors word 0 (cge_device.hpp)
         }
 #pragma unroll
         for (int g = 0; g < RG; ++g) {
-            const uint32_t pos = lane_u32(e.mt_pos, r0 + g), pretw = lane_u32(e.mt_pretw, r0 + g);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const uint32_t j = 64u * q + lane;
-                const uint32_t y = pos + j < pretw ? a[g][q] : mt_twist(a[g][q], b[g][q], c[g][q]);
-                uint32_t x = (mt_temper(y) >> (32 - L::KBITS)) << (Q::DB * (j % Q::PER));
-                x |= shfl_u32(x, lane ^ 1u);                    // OR over each aligned group of PER lanes -> one dword of digits
-                x |= shfl_u32(x, lane ^ 2u);
-                if (Q::PER == 8) x |= shfl_u32(x, lane ^ 4u);
-                if (j % Q::PER == 0 && j < (uint32_t)Q::QN) wave_q[(r0 + g) * Q::QROW + j / Q::PER] = x;
+            if (!has[g]) continue;                             // wave-uniform
+            const bool active = ((lane - pos[g]) & 63u) < fill[g];
+            const bool ready = k[g] < pretw[g];                // an imported CPython state: this generation's words are already twisted
+            const uint32_t y = ready ? a[g] : mt_twist(a[g], b[g], c[g]);
+            if (active && !ready) mt_store(ob[g], k[g], y);
+            const uint32_t sh = (lane % Q::PER) * Q::DB;
+            uint32_t x = active ? (mt_temper(y) >> (32 - L::KBITS)) << sh : 0u;
+            uint32_t m = active ? Q::DMASK << sh : 0u;
+            x |= shfl_u32(x, lane ^ 1u); m |= shfl_u32(m, lane ^ 1u);           // OR over each aligned group of PER lanes -> one ring dword
+            x |= shfl_u32(x, lane ^ 2u); m |= shfl_u32(m, lane ^ 2u);
+            if (Q::PER == 8) { x |= shfl_u32(x, lane ^ 4u); m |= shfl_u32(m, lane ^ 4u); }
+            uint32_t *row = q.wave_q + r[g] * Q::QROW;
+            if (lane % Q::PER == 0u && m) row[lane / Q::PER] = (row[lane / Q::PER] & ~m) | x;
+            if (lane == (uint32_t)r[g]) {
+                e.mt_pos = pos[g] + fill[g];
+                e.mt_pretw = pretw[g];
+                e.dq_left = left[g] + fill[g];
+                q.dirty = true;
+                q.loaded = Q::ALL_COLS;                        // every slot that means anything is in the row now
             }
         }
     }
-    qcur = 0;
-    qlen = Q::QN;
 }
 
-// twist-in-place the words each env consumed since its fill and advance the cursors
+// a ring can take more digits: it is not full, and it is not sitting at the end of a generation with digits of it still unused
 template <int G>
-__device__ __forceinline__ void queue_commit(Env<G> &e, uint32_t *blk, uint32_t &qcur, uint32_t &qlen) {
-    using Q = QLay<G>;
-    constexpr int NQ = (Q::QN + 63) / 64;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t plo = (uint32_t)reinterpret_cast<uintptr_t>(blk), phi = (uint32_t)(reinterpret_cast<uintptr_t>(blk) >> 32);
-#pragma unroll 1
-    for (int r = 0; r < 64; ++r) {
-        const uint32_t used = lane_u32(qcur, r);
-        if (used == 0) continue;                               // wave-uniform
-        uint32_t *ob = lane_ptr(plo, phi, r);
-        const uint32_t pos = lane_u32(e.mt_pos, r) & 1023u, pretw = lane_u32(e.mt_pretw, r);
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            if (64u * q >= used) break;                        // wave-uniform
-            const uint32_t j = 64u * q + lane;
-            uint32_t k = pos + j;
-            k -= k >= (uint32_t)MT_N ? MT_N : 0;
-            const uint32_t k1 = k + 1 == (uint32_t)MT_N ? 0 : k + 1;
-            const uint32_t km = k + MT_M >= (uint32_t)MT_N ? k + MT_M - MT_N : k + MT_M;
-            const uint32_t y = mt_twist(ob[k], ob[k1], ob[km]);   // every load of the round precedes its stores (program order)
-            if (j < used && pos + j >= pretw) mt_store(ob, k, y);
-        }
-    }
-    uint32_t np = e.mt_pos + qcur;
-    if (np >= (uint32_t)MT_N) { np -= MT_N; e.mt_pretw = 0; }
-    e.mt_pos = np;
-    qcur = 0;
-    qlen = 0;
+__device__ __forceinline__ bool dq_can_fill(const Env<G> &e) {
+    return e.dq_left < (uint32_t)DigitQ<G>::SLOTS && !(e.mt_pos >= (uint32_t)MT_N && e.dq_left > 0u);
 }
 
-// _place_food (snake_env.py:121-129) out of the lane's digit queue; must be called by all 64 lanes of the wave
-template <int G>
-__device__ __forceinline__ void queue_place_food(Env<G> &e, uint32_t *blk, uint32_t *wave_q, uint32_t &qcur, uint32_t &qlen, bool need) {
+// _place_food (snake_env.py:121-129) out of the lane's digit ring: `random.randint(0,G-1)` twice (row first, then column), each
+// _randbelow(G): r = getrandbits(k), redrawn while r >= G; the pair is redrawn while it lies on the snake.  Must be called by all
+// 64 lanes of the wave.  FETCH: the ring columns a round needs are loaded on demand (step() / reset()); the rollout has them all.
+template <int G, bool FETCH>
+__device__ __forceinline__ void dq_place_food(Env<G> &e, DqCtx<G> &q, bool need) {
     using L = Lay<G>;
-    using Q = QLay<G>;
-    const uint32_t *myq = wave_q + (threadIdx.x & 63u) * Q::QROW;
+    using Q = DigitQ<G>;
+    const uint32_t *myq = q.my_row();
     bool pending = need;
     uint32_t phase = 0, row = 0;
 #pragma unroll 1
     while (__ballot(pending)) {
-        if (__ballot(pending && qcur + (uint32_t)Q::PER > qlen)) {   // some lane could run dry in this round: commit and refill (rare)
-            queue_commit<G>(e, blk, qcur, qlen);
-            queue_fill<G>(e, blk, wave_q, qcur, qlen);
+        if (FETCH) {
+            const uint32_t head = (e.mt_pos - e.dq_left) & 63u, d0 = head / Q::PER, d1 = (d0 + 1u) & (uint32_t)(Q::QDW - 1);
+            const uint32_t cols = pending && e.dq_left ? (1u << (d0 >> 2)) | (1u << (d1 >> 2)) : 0u;
+            if (__ballot((cols & ~q.loaded) != 0u)) q.load_cols(cols);
         }
-        const uint32_t idx = qcur / Q::PER < (uint32_t)Q::QDW ? qcur / Q::PER : (uint32_t)Q::QDW - 1u, off = (qcur % Q::PER) * Q::DB;   // (idle lanes may sit at the end)
-        const uint32_t bits = (uint32_t)((((uint64_t)myq[idx + 1] << 32) | (uint64_t)myq[idx]) >> off);
+        const unsigned long long dry = __ballot(pending && e.dq_left < (uint32_t)Q::PER && dq_can_fill<G>(e));
+        if (dry) dq_refill<G>(e, q, dry);                      // wave-convergent; once per ~256 env-steps per env
+        const uint32_t head = (e.mt_pos - e.dq_left) & 63u;
+        const uint32_t idx = head / Q::PER, off = (head % Q::PER) * Q::DB;
+        uint32_t bits = (uint32_t)((((uint64_t)myq[(idx + 1u) & (uint32_t)(Q::QDW - 1)] << 32) | (uint64_t)myq[idx]) >> off);
+        const uint32_t avail = e.dq_left < (uint32_t)Q::PER ? e.dq_left : (uint32_t)Q::PER;
+        if (avail < (uint32_t)Q::PER) bits |= 0xFFFFFFFFu << (avail * Q::DB);   // slots past the ring's end read as digits >= G: skipped
         uint32_t used = 0;
         bool done = !pending;
         if constexpr (L::TIGHT) {                              // 10x10: bit-parallel scan of the 8 digits (snake_place.hpp)
@@ -536,7 +480,7 @@ __device__ __forceinline__ void queue_place_food(Env<G> &e, uint32_t *blk, uint3
 #pragma unroll
             for (int j = 0; j < Q::PER; ++j) {
                 if (!done) {
-                    const uint32_t r = (bits >> (Q::DB * j)) & ((1u << Q::DB) - 1u);
+                    const uint32_t r = (bits >> (Q::DB * j)) & Q::DMASK;
                     used = j + 1;
                     if (r < (uint32_t)G) {
                         if (phase == 0) {
@@ -552,7 +496,7 @@ __device__ __forceinline__ void queue_place_food(Env<G> &e, uint32_t *blk, uint3
             }
         }
         if (pending) {
-            qcur += used;
+            e.dq_left -= used < avail ? used : avail;
             if (done) { pending = false; e.flags |= F_FOOD_VALID; }
         }
     }
@@ -611,7 +555,7 @@ __device__ __forceinline__ uint32_t transition(Env<G> &e, const Params &p, int64
     }
     if (need_food) need_food = e.can_place_food();
     if (obs_row) e.write_obs_body(obs_row);
-    // the caller runs wave_place_food with the whole wave, then (T_DEFERRED, rare) finish_deferred + a second round, then write_obs_food
+    // the caller runs dq_place_food with the whole wave, then (T_DEFERRED, rare) finish_deferred + a second round, then write_obs_food
     return (need_food ? T_NEED_FOOD : 0u) | (was_reset ? T_WAS_RESET : 0u) | (deferred ? T_DEFERRED : 0u);
 }
 
@@ -628,7 +572,9 @@ __device__ __forceinline__ bool finish_deferred(Env<G> &e, const Params &p, int6
 template <int G, int BLOCK, int MINW, int MODE>
 __global__ __launch_bounds__(BLOCK, MINW) void step_kernel(Params p) {
     using L = Lay<G>;
+    using Q = DigitQ<G>;
     __shared__ uint4 tile4[BLOCK * L::OBS_DW / 4];
+    __shared__ uint32_t qmem[BLOCK * Q::QROW];
     uint32_t *tile = reinterpret_cast<uint32_t *>(tile4);
     const int64_t first = (int64_t)blockIdx.x * BLOCK;
     const int64_t i = first + threadIdx.x;
@@ -645,14 +591,17 @@ __global__ __launch_bounds__(BLOCK, MINW) void step_kernel(Params p) {
         const int32_t a = p.actions[i];
         tf = transition<G, MODE>(e, p, i, (uint32_t)a, (uint32_t)a <= 3u, row, r, term, short_wave);
     }
-    wave_place_food<G>(e, p.mt + li * MT_STRIDE, tf & T_NEED_FOOD);
+    // only the lanes that place food (~8 %) touch their digit ring: two dwords of it, fetched on demand (dq_place_food<.., true>)
+    DqCtx<G> q{qmem + (threadIdx.x & ~63u) * Q::QROW, p.mt + li * MT_STRIDE, p.dq, p.n, li, 0u, false};
+    dq_place_food<G, true>(e, q, tf & T_NEED_FOOD);
     if (__ballot(tf & T_DEFERRED)) {                           // rare, wave-uniform
         const bool again = (tf & T_DEFERRED) && finish_deferred<G>(e, p, i, row);
-        wave_place_food<G>(e, p.mt + li * MT_STRIDE, again);
+        dq_place_food<G, true>(e, q, again);
     }
     if (live_lane) {
         e.write_obs_food(row);
         e.store(p.state, p.n, i);
+        q.write_back();
         p.reward[i] = r;
         p.terminated[i] = term ? 1 : 0;
         if (p.truncated) p.truncated[i] = 0;   // reference never truncates (snake_env.py:119)
@@ -686,13 +635,13 @@ __device__ __forceinline__ void store_wave_rows(const uint32_t *rows, int8_t *ds
 // six full 1-KiB store instructions and a 256-byte tail) and goes straight on to the next transition while the stores drain.
 // History: round 1 gave the stores to a dedicated writer wave behind two LDS-only barriers per step, because on gfx950 loads
 // and stores retire through one in-order counter and a compute wave's next food-placement LOADS had to wait for its own obs
-// STORES.  The per-launch digit queue (QLay) removed every global load from the step loop, and with it the reason for the
-// writer: measured on 1M envs with every step's obs written to a [K, N, 100] trajectory, writer-wave kernel 28.5-38 us per
-// step (74 % of wave time parked at the barriers), this kernel see DESIGN.md section 6.
-template <int G, int BLOCK, int MINW, int MODE, bool USE_Q, bool ACTIONS>
+// STORES.  Pre-drawn digits (round 2: a per-launch queue; now the env's persistent ring, DigitQ) removed the global loads from
+// the step loop, and with them the reason for the writer: measured on 1M envs with every step's obs written to a [K, N, 100]
+// trajectory, writer-wave kernel 28.5-38 us per step (74 % of wave time parked at the barriers), this kernel see DESIGN.md 6.
+template <int G, int BLOCK, int MINW, int MODE, bool ACTIONS>
 __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
     using L = Lay<G>;
-    using Q = QLay<G>;
+    using Q = DigitQ<G>;
     __shared__ uint4 tile4[BLOCK * L::OBS_DW / 4];
     __shared__ uint32_t qmem[BLOCK * Q::QROW];
     uint32_t *tile = reinterpret_cast<uint32_t *>(tile4);
@@ -702,12 +651,13 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
     const int64_t wlive = p.n - wfirst < 64 ? p.n - wfirst : 64;
     const int64_t i = first + threadIdx.x;
     const bool live_lane = i < p.n;
-    Env<G> e;
+    const int64_t li = live_lane ? i : wfirst;                 // dead lanes of the last wave mirror a valid env: the cooperative
+    Env<G> e;                                                  // refill reads every lane's cursor (and never serves a dead lane)
     uint64_t key = 0;
     float rsum = 0.0f;
     int32_t dcount = 0;
-    e.load(p.state, p.n, live_lane ? i : wfirst);              // dead lanes of the last wave mirror a valid env: the cooperative
-    if (live_lane) key = hash_env_key(p.a_seed, (uint64_t)(p.env0 + i));   // queue code reads every lane's cursor
+    e.load(p.state, p.n, li);
+    if (live_lane) key = hash_env_key(p.a_seed, (uint64_t)(p.env0 + i));
     // The lane's obs row lives in LDS for the whole rollout and is kept up to date INCREMENTALLY: a move sets the new head
     // byte and clears the vacated tail byte, a new food sets one byte; only an episode reset rewrites the row, and that is
     // done by the wave together (25 lanes clear the row of each resetting env) — rebuilding 25 dwords per lane per step
@@ -718,20 +668,20 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
     uint32_t *wave_rows = tile + (threadIdx.x & ~63u) * L::OBS_DW;
     if (row && live_lane) { e.write_obs_body(row); e.write_obs_food(row); }
     // ACTIONS (compile time): explicit [k, n] actions, fetched one step ahead so the load's latency hides behind the previous step.
-    // The hash-action instance has NO global load anywhere in its step loop — on purpose: gfx950 counts loads and stores in one
-    // in-order counter, and a load that is merely POSSIBLE on some path makes the compiler put `s_waitcnt vmcnt(0)` at the join,
-    // which also drains the wave's observation stores.  With `p.actions` tested at run time that wait sat in every step of the
-    // hash path (round 2, found in the ISA): the wave waited for its previous tile to reach HBM before every transition.
+    // The hash-action instance has NO global load in its step loop on the common path — on purpose: gfx950 counts loads and
+    // stores in one in-order counter, and a load that is merely POSSIBLE on some path makes the compiler put `s_waitcnt vmcnt(0)`
+    // at the join, which also drains the wave's observation stores (round 2, found in the ISA).  The ring refill below is the one
+    // exception: wave-uniform, behind a scalar branch that is taken once per ~4 wave-steps in long launches and (with the top-up
+    // before the loop) practically never in short ones.
     uint32_t a_next = (ACTIONS && live_lane && p.k_steps > 0) ? (uint32_t)p.actions[i] : 0u;
-    uint32_t *blk = p.mt + (live_lane ? i : wfirst) * MT_STRIDE;
-    // generator words for the whole launch, drawn before the first observation store is in flight (see QLay)
-    uint32_t *wave_q = qmem + (threadIdx.x & ~63u) * Q::QROW;
-    uint32_t qcur = 0, qlen = 0;
-    if (USE_Q) queue_fill<G>(e, blk, wave_q, qcur, qlen);
-    auto place = [&](bool need) {
-        if (USE_Q) queue_place_food<G>(e, blk, wave_q, qcur, qlen, need);
-        else wave_place_food<G>(e, blk, need);
-    };
+    // the digit rings of the wave's envs, parked in LDS for the launch; rings that could run dry during it are topped up now,
+    // before the first observation store is in flight
+    DqCtx<G> q{qmem + (threadIdx.x & ~63u) * Q::QROW, p.mt + li * MT_STRIDE, p.dq, p.n, li, 0u, false};
+    q.load_cols(Q::ALL_COLS);
+    {
+        const unsigned long long low = __ballot(live_lane && e.dq_left < p.dq_topup && dq_can_fill<G>(e));
+        if (low) dq_refill<G>(e, q, low);
+    }
     for (int t = 0; t < p.k_steps; ++t) {
         float r = 0.0f;
         bool term = false, need_food = false, was_reset = false;
@@ -754,7 +704,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
         bool want = need_food;
 #pragma unroll 1
         for (int round = 0; round < 2; ++round) {
-            place(want);
+            dq_place_food<G, false>(e, q, want);
             if (round == 1 || __ballot(tf & T_DEFERRED) == 0ull) break;
             want = (tf & T_DEFERRED) && finish_deferred<G>(e, p, i, nullptr);
             if (tf & T_DEFERRED) { was_reset = true; need_food = want; }
@@ -765,7 +715,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
                 const uint32_t rl = (uint32_t)__ffsll((long long)rm) - 1u;
                 rm &= rm - 1ull;
                 if (lane < (uint32_t)L::OBS_DW) wave_rows[rl * L::OBS_DW + lane] = 0u;
-                if (L::OBS_DW > 64) for (uint32_t q = lane + 64u; q < (uint32_t)L::OBS_DW; q += 64u) wave_rows[rl * L::OBS_DW + q] = 0u;
+                if (L::OBS_DW > 64) for (uint32_t q2 = lane + 64u; q2 < (uint32_t)L::OBS_DW; q2 += 64u) wave_rows[rl * L::OBS_DW + q2] = 0u;
             }
             if (live_lane) {
                 if (was_reset) rowb[e.head] = 1;
@@ -783,9 +733,9 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
             if (p.terminated) p.terminated[(int64_t)t * p.n + i] = term ? 1 : 0;
         }
     }
-    if (USE_Q) queue_commit<G>(e, blk, qcur, qlen);
     if (live_lane) {
         e.store(p.state, p.n, i);
+        q.write_back();
         if (p.reward_sum) p.reward_sum[i] = rsum;
         if (p.done_count) p.done_count[i] = dcount;
     }
@@ -794,28 +744,28 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
 template <int G>
 __global__ __launch_bounds__(Lay<G>::BLOCK) void reset_kernel(Params p) {
     using L = Lay<G>;
+    using Q = DigitQ<G>;
     __shared__ uint4 tile4[L::BLOCK * L::OBS_DW / 4];
+    __shared__ uint32_t qmem[L::BLOCK * Q::QROW];
     uint32_t *tile = reinterpret_cast<uint32_t *>(tile4);
     const int64_t first = (int64_t)blockIdx.x * L::BLOCK;
     const int64_t i = first + threadIdx.x;
-    if (i < p.n) {
-        Env<G> e;
-        e.load(p.state, p.n, i);
-        uint32_t *row = p.obs ? tile + threadIdx.x * L::OBS_DW : nullptr;
-        uint32_t *blk = p.mt + i * MT_STRIDE;
-        const bool doit = !p.mask || p.mask[i];
-        bool need_food = false;
-        if (doit) {
-            e.reset_body();
-            need_food = e.can_place_food();
-        }
-        MtWindow<FOOD_WINDOW> win;
-        if (need_food) win.load(blk, e.mt_pos);
-        if (row) e.write_obs_body(row);
-        if (need_food) e.place_food(blk, win);
-        if (row) e.write_obs_food(row);
-        if (doit) e.store(p.state, p.n, i);
+    const bool live_lane = i < p.n;
+    const int64_t li = live_lane ? i : first;                  // dead lanes mirror a valid env (they take part in the cooperative refill)
+    Env<G> e;
+    e.load(p.state, p.n, li);
+    uint32_t *row = p.obs ? tile + threadIdx.x * L::OBS_DW : nullptr;
+    const bool doit = live_lane && (!p.mask || p.mask[i]);
+    bool need_food = false;
+    if (doit) {
+        e.reset_body();
+        need_food = e.can_place_food();
     }
+    if (row) e.write_obs_body(row);
+    DqCtx<G> q{qmem + (threadIdx.x & ~63u) * Q::QROW, p.mt + li * MT_STRIDE, p.dq, p.n, li, 0u, false};
+    dq_place_food<G, true>(e, q, need_food);
+    if (row) e.write_obs_food(row);
+    if (doit) { e.store(p.state, p.n, i); q.write_back(); }
     if (p.obs) {
         lds_barrier();
         const int64_t live = p.n - first < L::BLOCK ? p.n - first : L::BLOCK;
@@ -832,6 +782,7 @@ __global__ __launch_bounds__(256) void rewind_kernel(uint4 *__restrict__ state, 
     e.load(state, n, i);
     e.mt_pos = 0;
     e.mt_pretw = 0;
+    e.dq_left = 0;                                             // digits drawn from the old stream are dropped with it
     e.store(state, n, i);
 }
 
@@ -889,22 +840,24 @@ __global__ __launch_bounds__(256) void render_kernel(const uint4 *__restrict__ s
 struct Ops {
     int cells, cols, block, nw, max_steps_limit;
     void (*rewind)(uint4 *, int64_t, hipStream_t);
-    void (*step)(const Params &, hipStream_t);
-    void (*rollout)(const Params &, hipStream_t);
+    int dq_cols;
+    void (*step)(const Params &, hipStream_t, std::string *);
+    void (*rollout)(const Params &, hipStream_t, std::string *);
     void (*reset)(const Params &, hipStream_t);
     void (*info)(const uint4 *, int64_t, int, int32_t *, hipStream_t);
     void (*render)(const uint4 *, int64_t, uint32_t *, hipStream_t);
-    void (*decode)(const uint32_t *raw, int32_t *hdr, uint16_t *body, uint32_t *mt_pos, uint32_t *mt_pretw);
+    void (*decode)(const uint32_t *raw, int32_t *hdr, uint16_t *body, uint32_t *mt_pos, uint32_t *mt_pretw, uint32_t *dq_left);
     bool (*encode)(const int32_t *hdr, const uint16_t *body, uint32_t *raw);
 };
 
 template <int G>
-void decode_env(const uint32_t *raw, int32_t *hdr, uint16_t *body, uint32_t *mt_pos, uint32_t *mt_pretw) {
+void decode_env(const uint32_t *raw, int32_t *hdr, uint16_t *body, uint32_t *mt_pos, uint32_t *mt_pretw, uint32_t *dq_left) {
     using L = Lay<G>;
     Env<G> e;
     e.unpack(raw);
     *mt_pos = e.mt_pos;
     *mt_pretw = e.mt_pretw;
+    *dq_left = e.dq_left;
     const int len = (int)e.length();
     const bool fv = e.flags & F_FOOD_VALID;
     hdr[0] = len; hdr[1] = (int32_t)e.dir;
@@ -955,30 +908,27 @@ bool encode_env(const int32_t *hdr, const uint16_t *body, uint32_t *raw) {
     return true;
 }
 
-// the autoreset mode and the placement scheme are compile-time properties of the kernels (no mode tests in the step loop)
+// the autoreset mode and the action source are compile-time properties of the kernels (no mode tests in the step loop).
+// `name` receives the launched kernel as rocprofv3 prints it (cge_snake_last_kernel: bench.py keys its roofline block on it).
 template <int G, int BLOCK, int MINW, int MODE>
-void launch_mode(const Params &p, bool rollout, hipStream_t s) {
+void launch_mode(const Params &p, bool rollout, hipStream_t s, std::string *name) {
     const dim3 grid((unsigned)((p.n + BLOCK - 1) / BLOCK)), block(BLOCK);
-    if (!rollout) hipLaunchKernelGGL((step_kernel<G, BLOCK, MINW, MODE>), grid, block, 0, s, p);
-    else if (p.k_steps >= QLay<G>::MIN_STEPS) {
-        if (p.actions) hipLaunchKernelGGL((rollout_kernel<G, BLOCK, MINW, MODE, true, true>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((rollout_kernel<G, BLOCK, MINW, MODE, true, false>), grid, block, 0, s, p);
+    char buf[96];
+    if (!rollout) {
+        hipLaunchKernelGGL((step_kernel<G, BLOCK, MINW, MODE>), grid, block, 0, s, p);
+        snprintf(buf, sizeof buf, "cge::snake::step_kernel<%d, %d, %d, %d>", G, BLOCK, MINW, MODE);
     } else {
-        if (p.actions) hipLaunchKernelGGL((rollout_kernel<G, BLOCK, MINW, MODE, false, true>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((rollout_kernel<G, BLOCK, MINW, MODE, false, false>), grid, block, 0, s, p);
+        if (p.actions) hipLaunchKernelGGL((rollout_kernel<G, BLOCK, MINW, MODE, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((rollout_kernel<G, BLOCK, MINW, MODE, false>), grid, block, 0, s, p);
+        snprintf(buf, sizeof buf, "cge::snake::rollout_kernel<%d, %d, %d, %d, %s>", G, BLOCK, MINW, MODE, p.actions ? "true" : "false");
     }
+    if (name) *name = buf;
 }
 template <int G, int BLOCK, int MINW>
-void launch_any(const Params &p, bool rollout, hipStream_t s) {
-    if (p.mode == CGE_AUTORESET_SAME_STEP) launch_mode<G, BLOCK, MINW, CGE_AUTORESET_SAME_STEP>(p, rollout, s);
-    else if (p.mode == CGE_AUTORESET_NEXT_STEP) launch_mode<G, BLOCK, MINW, CGE_AUTORESET_NEXT_STEP>(p, rollout, s);
-    else launch_mode<G, BLOCK, MINW, CGE_AUTORESET_DISABLED>(p, rollout, s);
-}
-template <int G, int BLOCK, int MINW>
-void set_variant(Ops &o) {
-    o.block = BLOCK;
-    o.step = [](const Params &p, hipStream_t s) { launch_any<G, BLOCK, MINW>(p, false, s); };
-    o.rollout = [](const Params &p, hipStream_t s) { launch_any<G, BLOCK, MINW>(p, true, s); };
+void launch_any(const Params &p, bool rollout, hipStream_t s, std::string *name) {
+    if (p.mode == CGE_AUTORESET_SAME_STEP) launch_mode<G, BLOCK, MINW, CGE_AUTORESET_SAME_STEP>(p, rollout, s, name);
+    else if (p.mode == CGE_AUTORESET_NEXT_STEP) launch_mode<G, BLOCK, MINW, CGE_AUTORESET_NEXT_STEP>(p, rollout, s, name);
+    else launch_mode<G, BLOCK, MINW, CGE_AUTORESET_DISABLED>(p, rollout, s, name);
 }
 
 template <int G>
@@ -986,10 +936,12 @@ Ops make_ops() {
     using L = Lay<G>;
     Ops o;
     o.cells = L::CELLS; o.cols = L::COLS; o.block = L::BLOCK; o.nw = L::NW; o.max_steps_limit = L::MAX_STEPS_LIMIT;
+    o.dq_cols = DigitQ<G>::COLS;
     o.rewind = [](uint4 *st, int64_t n, hipStream_t s) {
         hipLaunchKernelGGL(rewind_kernel<G>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st, n);
     };
-    set_variant<G, L::BLOCK, 1>(o);
+    o.step = [](const Params &p, hipStream_t s, std::string *name) { launch_any<G, L::BLOCK, 1>(p, false, s, name); };
+    o.rollout = [](const Params &p, hipStream_t s, std::string *name) { launch_any<G, L::BLOCK, 1>(p, true, s, name); };
     o.reset = [](const Params &p, hipStream_t s) {
         hipLaunchKernelGGL(reset_kernel<G>, dim3((unsigned)((p.n + L::BLOCK - 1) / L::BLOCK)), dim3(L::BLOCK), 0, s, p);
     };
@@ -1009,14 +961,7 @@ static bool ops_for(int grid, Ops &o) {
     switch (grid) {
         case 6: o = make_ops<6>(); return true;
         case 8: o = make_ops<8>(); return true;
-        case 10: {
-            o = make_ops<10>();
-            // tuning variants of the benchmark grid, selectable for A/B runs (default = best measured)
-            const char *v = getenv("CGE_SNAKE_VARIANT");
-            const int k = v ? atoi(v) : 0;
-            if (k == 1) set_variant<10, 64, 1>(o);
-            return true;
-        }
+        case 10: o = make_ops<10>(); return true;
         case 12: o = make_ops<12>(); return true;
         case 16: o = make_ops<16>(); return true;
         case 20: o = make_ops<20>(); return true;
@@ -1033,12 +978,13 @@ struct cge_snake : HandleBase {
     cge_snake_config cfg{};
     snake::Ops ops{};
     uint4 *state = nullptr;
+    uint4 *dq = nullptr;           // digit rings (snake::DigitQ)
     uint32_t *mt = nullptr;
     unsigned long long *err = nullptr;
 
     snake::Params params() const {
         snake::Params p{};
-        p.state = state; p.mt = mt; p.n = n; p.env0 = env0;
+        p.state = state; p.dq = dq; p.mt = mt; p.n = n; p.env0 = env0;
         p.mode = cfg.autoreset_mode; p.max_steps = cfg.max_steps; p.err_count = err;
         p.ep_ret = ep_ret; p.ep_len = ep_len;
         return p;
@@ -1071,17 +1017,20 @@ int cge_snake_create(const cge_snake_config *cfg, int64_t n_envs, int device, in
     DeviceGuard g(device);
     const size_t state_bytes = (size_t)ops.cols * n_envs * sizeof(uint4);
     const size_t mt_bytes = (size_t)n_envs * MT_STRIDE * sizeof(uint32_t);
+    const size_t dq_bytes = (size_t)ops.dq_cols * n_envs * sizeof(uint4);
     hipError_t e;
     if ((e = hipMalloc(&h->state, state_bytes)) != hipSuccess || (e = hipMalloc(&h->mt, mt_bytes)) != hipSuccess ||
-        (e = hipMalloc(&h->err, sizeof(unsigned long long))) != hipSuccess ||
-        (e = hipMemset(h->state, 0, state_bytes)) != hipSuccess || (e = hipMemset(h->err, 0, sizeof(unsigned long long))) != hipSuccess) {
+        (e = hipMalloc(&h->dq, dq_bytes)) != hipSuccess || (e = hipMalloc(&h->err, sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMemset(h->state, 0, state_bytes)) != hipSuccess || (e = hipMemset(h->dq, 0, dq_bytes)) != hipSuccess ||
+        (e = hipMemset(h->err, 0, sizeof(unsigned long long))) != hipSuccess) {
         if (h->state) (void)hipFree(h->state);
         if (h->mt) (void)hipFree(h->mt);
+        if (h->dq) (void)hipFree(h->dq);
         if (h->err) (void)hipFree(h->err);
         delete h;
         return CGE_ERR_HIP;
     }
-    h->device_bytes = state_bytes + mt_bytes + sizeof(unsigned long long);
+    h->device_bytes = state_bytes + mt_bytes + dq_bytes + sizeof(unsigned long long);
     // default streams: random.seed(env_index0 + i); default state: reset() so a handle is always steppable
     e = launch_mt_seed(h->mt, MT_STRIDE, n_envs, nullptr, 0, env_index0, 0, nullptr);
     if (e == hipSuccess) {
@@ -1091,7 +1040,7 @@ int cge_snake_create(const cge_snake_config *cfg, int64_t n_envs, int device, in
     }
     if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e != hipSuccess) {
-        (void)hipFree(h->state); (void)hipFree(h->mt); (void)hipFree(h->err);
+        (void)hipFree(h->state); (void)hipFree(h->mt); (void)hipFree(h->dq); (void)hipFree(h->err);
         delete h;
         return CGE_ERR_HIP;
     }
@@ -1105,6 +1054,7 @@ int cge_snake_destroy(cge_snake *h) {
     (void)hipDeviceSynchronize();
     (void)hipFree(h->state);
     (void)hipFree(h->mt);
+    (void)hipFree(h->dq);
     (void)hipFree(h->err);
     delete h;
     return CGE_OK;
@@ -1139,7 +1089,7 @@ int cge_snake_step(cge_snake *h, const int32_t *actions, int8_t *obs_out, float 
     snake::Params p = h->params();
     p.actions = actions; p.obs = obs_out; p.reward = reward_out;
     p.terminated = terminated_out; p.truncated = truncated_out; p.final_obs = final_obs_out;
-    h->ops.step(p, as_stream(stream));
+    h->ops.step(p, as_stream(stream), &h->last_kernel);
     CGE_TRY(h, hipGetLastError());
     return CGE_OK;
 }
@@ -1158,7 +1108,12 @@ int cge_snake_rollout(cge_snake *h, int32_t k_steps, const int32_t *actions, uin
     p.obs = obs_out; p.obs_step_stride = obs_step_stride;
     p.reward = reward_traj_out; p.terminated = terminated_traj_out;
     p.reward_sum = reward_sum_out; p.done_count = done_count_out;
-    h->ops.rollout(p, as_stream(stream));
+    // rings that could run dry during the launch are topped up before its first step: a placement takes 3.2 digits on average
+    // and a launch of k steps ~0.25 k of them per env, with a long tail — 12 + k covers all but ~1e-3 of the envs of a 20-step
+    // launch; from 52 steps on every ring starts full
+    const int32_t top = 12 + k_steps;
+    p.dq_topup = (uint32_t)(top < 16 ? 16 : top > 64 ? 64 : top);
+    h->ops.rollout(p, as_stream(stream), &h->last_kernel);
     CGE_TRY(h, hipGetLastError());
     return CGE_OK;
 }
@@ -1209,13 +1164,16 @@ int cge_snake_get_state(cge_snake *h, void *host_buf, void *stream) {
         int32_t *hdr = (int32_t *)p;
         uint32_t *omt = (uint32_t *)(p + 32);
         uint16_t *body = (uint16_t *)(p + 32 + MT_N * 4);
-        uint32_t pos = 0, pretw = 0;
-        h->ops.decode(raw.data(), hdr, body, &pos, &pretw);
-        // incremental-twist stream -> CPython layout (words >= idx generated but unconsumed)
+        uint32_t pos = 0, pretw = 0, left = 0;
+        h->ops.decode(raw.data(), hdr, body, &pos, &pretw, &left);
+        // incremental-twist stream -> CPython layout (words >= idx generated but unconsumed).  Words [pos - left, pos) are twisted
+        // already and wait in the env's digit ring (snake::DigitQ): the CPython cursor is pos - left, and since a ring never
+        // holds digits of two generations, twisting the words from pos on completes the generation.
         const uint32_t *w = &mt[(size_t)i * MT_STRIDE];
         memcpy(omt, w, MT_N * 4);
+        if (left > pos) return h->fail(CGE_ERR_INVALID_ARG, "cge_snake_get_state: corrupted digit-ring cursor");
         if (pretw >= (uint32_t)MT_N) {
-            hdr[7] = (int32_t)pos;
+            hdr[7] = (int32_t)(pos - left);
         } else if (pos == 0) {
             hdr[7] = MT_N;
         } else {
@@ -1225,7 +1183,7 @@ int cge_snake_get_state(cge_snake *h, void *host_buf, void *stream) {
                 const uint32_t t = (omt[k] & 0x80000000u) | (omt[k1] & 0x7fffffffu);
                 omt[k] = omt[km] ^ (t >> 1) ^ ((t & 1u) ? 0x9908b0dfu : 0u);
             }
-            hdr[7] = (int32_t)pos;
+            hdr[7] = (int32_t)(pos - left);
         }
     }
     return CGE_OK;
@@ -1284,5 +1242,7 @@ int cge_snake_episode_stats(cge_snake *h, double *return_out, int32_t *length_ou
 }
 
 const char *cge_snake_last_error(const cge_snake *h) { return h ? h->last_error.c_str() : "null handle"; }
+
+const char *cge_snake_last_kernel(const cge_snake *h) { return h ? h->last_kernel.c_str() : ""; }
 
 }  // extern "C"

@@ -573,6 +573,7 @@ int cge_traffic_step(cge_traffic *h, const int32_t *actions, float *obs_out, flo
     p.actions = actions; p.obs = obs_out; p.reward = reward_out; p.terminated = terminated_out; p.truncated = truncated_out;
     p.final_obs = final_obs_out; p.k_steps = 1;
     hipLaunchKernelGGL(traffic::step_kernel<false>, dim3(h->blocks()), dim3(traffic::BLOCK), 0, as_stream(stream), p);
+    h->last_kernel = "cge::traffic::step_kernel<false>";
     CGE_TRY(h, hipGetLastError());
     return CGE_OK;
 }
@@ -589,6 +590,7 @@ int cge_traffic_rollout(cge_traffic *h, int32_t k_steps, const int32_t *actions,
     p.k_steps = k_steps; p.actions = actions; p.a_seed = action_seed; p.t0 = t0; p.obs = obs_out; p.obs_step_stride = obs_step_stride;
     p.reward = reward_traj_out; p.terminated = terminated_traj_out; p.reward_sum = reward_sum_out; p.done_count = done_count_out;
     hipLaunchKernelGGL(traffic::step_kernel<true>, dim3(h->blocks()), dim3(traffic::BLOCK), 0, as_stream(stream), p);
+    h->last_kernel = "cge::traffic::step_kernel<true>";
     CGE_TRY(h, hipGetLastError());
     return CGE_OK;
 }
@@ -698,5 +700,7 @@ int cge_traffic_episode_stats(cge_traffic *h, double *return_out, int32_t *lengt
 }
 
 const char *cge_traffic_last_error(const cge_traffic *h) { return h ? h->last_error.c_str() : "null handle"; }
+
+const char *cge_traffic_last_kernel(const cge_traffic *h) { return h ? h->last_kernel.c_str() : ""; }
 
 }  // extern "C"

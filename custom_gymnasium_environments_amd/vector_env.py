@@ -121,6 +121,11 @@ class DeviceVectorEnv(VectorEnvBase):
     def device_bytes(self):
         return int(self._fn("device_bytes")(self._h))
 
+    def last_kernel(self):
+        """Name(s) of the kernel(s) the last step() / rollout() launched, as rocprofv3 prints them ("" before the first call)."""
+        raw = self._fn("last_kernel")(self._h)
+        return raw.decode() if raw else ""
+
     # ------------------------------------------------------------------ episode statistics
     def record_episode_statistics(self, enable=True):
         """What gymnasium.wrappers.vector.RecordEpisodeStatistics adds around a vector env, computed by the step kernel itself:

@@ -138,6 +138,9 @@ int64_t cge_snake_error_count(cge_snake *h, void *stream);
 size_t cge_snake_device_bytes(const cge_snake *h);
 int cge_snake_episode_stats(cge_snake *h, double *return_out, int32_t *length_out);
 const char *cge_snake_last_error(const cge_snake *h);
+/* the kernel(s) the last step() / rollout() call on this handle launched, by the name rocprofv3 --kernel-trace prints
+ * ("" before the first call): lets a measurement attribute its time and PMC bytes to what actually ran. */
+const char *cge_snake_last_kernel(const cge_snake *h);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Crypto  (crypto_trading_env/crypto_trading_env.py: CryptoTradingEnv)                        */
@@ -208,6 +211,7 @@ int cge_crypto_set_state(cge_crypto *h, const void *host_buf, void *stream);
 size_t cge_crypto_device_bytes(const cge_crypto *h);
 int cge_crypto_episode_stats(cge_crypto *h, double *return_out, int32_t *length_out);
 const char *cge_crypto_last_error(const cge_crypto *h);
+const char *cge_crypto_last_kernel(const cge_crypto *h);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Traffic  (traffic_management_env/environment.py: TrafficManagementEnv, utils.py, config.py)  */
@@ -270,6 +274,7 @@ int cge_traffic_set_state(cge_traffic *h, const void *host_buf, void *stream);
 size_t cge_traffic_device_bytes(const cge_traffic *h);
 int cge_traffic_episode_stats(cge_traffic *h, double *return_out, int32_t *length_out);
 const char *cge_traffic_last_error(const cge_traffic *h);
+const char *cge_traffic_last_kernel(const cge_traffic *h);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Smart parking  (smart_parking_env/core/parking_env.py: SmartParkingEnv + customer/parking_lot/pricing) */
@@ -322,6 +327,7 @@ int cge_parking_snapshot_set(cge_parking *h, const void *host_buf, void *stream)
 size_t cge_parking_device_bytes(const cge_parking *h);
 int cge_parking_episode_stats(cge_parking *h, double *return_out, int32_t *length_out);
 const char *cge_parking_last_error(const cge_parking *h);
+const char *cge_parking_last_kernel(const cge_parking *h);
 
 /* ------------------------------------------------------------------------------------------ */
 /* SmartClimate  (smartclimate_rl-main/smartclimate/env.py: SmartClimateEnv, utils.py)          */
@@ -371,6 +377,7 @@ int cge_climate_snapshot_set(cge_climate *h, const void *host_buf, void *stream)
 size_t cge_climate_device_bytes(const cge_climate *h);
 int cge_climate_episode_stats(cge_climate *h, double *return_out, int32_t *length_out);
 const char *cge_climate_last_error(const cge_climate *h);
+const char *cge_climate_last_kernel(const cge_climate *h);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Fleet  (fleet_management_env/fleet_env.py: FleetManagementEnv)                               */
@@ -413,6 +420,7 @@ int cge_fleet_snapshot_set(cge_fleet *h, const void *host_buf, void *stream);
 size_t cge_fleet_device_bytes(const cge_fleet *h);
 int cge_fleet_episode_stats(cge_fleet *h, double *return_out, int32_t *length_out);
 const char *cge_fleet_last_error(const cge_fleet *h);
+const char *cge_fleet_last_kernel(const cge_fleet *h);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Manufacturing  (smart_manufacturing_env/manufacturing_env.py: SmartManufacturingEnv)         */
@@ -456,6 +464,7 @@ int cge_manufacturing_snapshot_set(cge_manufacturing *h, const void *host_buf, v
 size_t cge_manufacturing_device_bytes(const cge_manufacturing *h);
 int cge_manufacturing_episode_stats(cge_manufacturing *h, double *return_out, int32_t *length_out);
 const char *cge_manufacturing_last_error(const cge_manufacturing *h);
+const char *cge_manufacturing_last_kernel(const cge_manufacturing *h);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Hospital  (hospital_management_env/hospital_env.py: HospitalManagementEnv)                   */
@@ -500,6 +509,7 @@ int cge_hospital_snapshot_set(cge_hospital *h, const void *host_buf, void *strea
 size_t cge_hospital_device_bytes(const cge_hospital *h);
 int cge_hospital_episode_stats(cge_hospital *h, double *return_out, int32_t *length_out);
 const char *cge_hospital_last_error(const cge_hospital *h);
+const char *cge_hospital_last_kernel(const cge_hospital *h);
 
 #ifdef __cplusplus
 }
