@@ -60,7 +60,9 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 // {magic, n_envs, env tag, extra} followed by the handle's device arrays in their device layout.  Only valid for a handle
 // created with the same n_envs and config.  H provides blobs() -> vector<pair<void*, size_t>>, snap_tag, snap_extra().
 struct SnapHeader { uint64_t magic; int64_t n; uint32_t tag, extra; uint64_t reserved; };
-constexpr uint64_t SNAP_MAGIC = 0x3150414e53454743ull;   // "CGESNAP1"
+// "CGESNAP3": 1 = round 1; 2 = round 2 (MT blocks grew mirror words 624..639, ep_return fields in the records) — blobs of an older
+// layout are refused instead of being read with the wrong meaning
+constexpr uint64_t SNAP_MAGIC = 0x3350414e53454743ull;
 template <class H>
 size_t snapshot_bytes(const H *h) {
     size_t t = sizeof(SnapHeader);

@@ -350,25 +350,37 @@ struct DigitQ {
 // it has to go back to HBM
 template <int G>
 struct DqCtx {
-    uint32_t *wave_q;      // LDS: QROW dwords per lane of this wave
+    uint32_t *wave_q;      // LDS: `stride` dwords per lane of this wave, the first QDW of them the ring
+    uint32_t stride;       // >= QDW, odd where it can be (QROW in a dedicated array; the step kernel borrows its obs tile rows: OBS_DW)
     uint32_t *blk;         // this lane's generator block
     uint4 *dq;             // global ring columns
     int64_t n, i;          // batch size, this lane's env (a valid env for every lane, see the callers)
     uint32_t loaded;       // bit c: column c of this lane's row is in LDS
     bool dirty;
 
-    __device__ __forceinline__ uint32_t *my_row() const { return wave_q + (threadIdx.x & 63u) * DigitQ<G>::QROW; }
-    __device__ __forceinline__ void load_cols(uint32_t cols) {                  // cols: bit mask of columns to fetch (per lane)
+    __device__ __forceinline__ uint32_t *my_row() const { return wave_q + (threadIdx.x & 63u) * stride; }
+    __device__ __forceinline__ void load_all() {                                // every column of this lane's ring (fused rollout, launch start)
         using Q = DigitQ<G>;
         uint32_t *row = my_row();
+        uint4 v[Q::COLS];
 #pragma unroll
-        for (int c = 0; c < Q::COLS; ++c) {
-            if (cols & ~loaded & (1u << c)) {
-                const uint4 v = dq[(int64_t)c * n + i];
-                row[4 * c] = v.x; row[4 * c + 1] = v.y; row[4 * c + 2] = v.z; row[4 * c + 3] = v.w;
-            }
+        for (int c = 0; c < Q::COLS; ++c) v[c] = dq[(int64_t)c * n + i];
+#pragma unroll
+        for (int c = 0; c < Q::COLS; ++c) { row[4 * c] = v[c].x; row[4 * c + 1] = v[c].y; row[4 * c + 2] = v[c].z; row[4 * c + 3] = v[c].w; }
+        loaded = Q::ALL_COLS;
+    }
+    // the (at most two) columns a placement round reads, c0 and c1, for the lanes with `want`: both loads are issued inside ONE
+    // predicated region, so a wave whose lanes need different columns still pays one memory round trip (a load per `if` would
+    // be closed by its own s_waitcnt); c1 == c0 re-reads the same 16 bytes
+    __device__ __forceinline__ void load_pair(bool want, uint32_t c0, uint32_t c1) {
+        using Q = DigitQ<G>;
+        if (want && ((~loaded >> c0) & 1u || (~loaded >> c1) & 1u)) {
+            uint32_t *row = my_row();
+            const uint4 v0 = dq[(int64_t)c0 * n + i], v1 = dq[(int64_t)c1 * n + i];
+            row[4 * c0] = v0.x; row[4 * c0 + 1] = v0.y; row[4 * c0 + 2] = v0.z; row[4 * c0 + 3] = v0.w;
+            row[4 * c1] = v1.x; row[4 * c1 + 1] = v1.y; row[4 * c1 + 2] = v1.z; row[4 * c1 + 3] = v1.w;
+            loaded |= (1u << c0) | (1u << c1);
         }
-        loaded |= cols;
     }
     __device__ __forceinline__ void write_back() {
         using Q = DigitQ<G>;
@@ -427,7 +439,7 @@ __device__ __forceinline__ void dq_refill(Env<G> &e, DqCtx<G> &q, unsigned long 
             x |= shfl_u32(x, lane ^ 1u); m |= shfl_u32(m, lane ^ 1u);           // OR over each aligned group of PER lanes -> one ring dword
             x |= shfl_u32(x, lane ^ 2u); m |= shfl_u32(m, lane ^ 2u);
             if (Q::PER == 8) { x |= shfl_u32(x, lane ^ 4u); m |= shfl_u32(m, lane ^ 4u); }
-            uint32_t *row = q.wave_q + r[g] * Q::QROW;
+            uint32_t *row = q.wave_q + (uint32_t)r[g] * q.stride;
             if (lane % Q::PER == 0u && m) row[lane / Q::PER] = (row[lane / Q::PER] & ~m) | x;
             if (lane == (uint32_t)r[g]) {
                 e.mt_pos = pos[g] + fill[g];
@@ -460,8 +472,7 @@ __device__ __forceinline__ void dq_place_food(Env<G> &e, DqCtx<G> &q, bool need)
     while (__ballot(pending)) {
         if (FETCH) {
             const uint32_t head = (e.mt_pos - e.dq_left) & 63u, d0 = head / Q::PER, d1 = (d0 + 1u) & (uint32_t)(Q::QDW - 1);
-            const uint32_t cols = pending && e.dq_left ? (1u << (d0 >> 2)) | (1u << (d1 >> 2)) : 0u;
-            if (__ballot((cols & ~q.loaded) != 0u)) q.load_cols(cols);
+            q.load_pair(pending && e.dq_left != 0u, d0 >> 2, d1 >> 2);
         }
         const unsigned long long dry = __ballot(pending && e.dq_left < (uint32_t)Q::PER && dq_can_fill<G>(e));
         if (dry) dq_refill<G>(e, q, dry);                      // wave-convergent; once per ~256 env-steps per env
@@ -569,48 +580,6 @@ __device__ __forceinline__ bool finish_deferred(Env<G> &e, const Params &p, int6
     return e.can_place_food();
 }
 
-template <int G, int BLOCK, int MINW, int MODE>
-__global__ __launch_bounds__(BLOCK, MINW) void step_kernel(Params p) {
-    using L = Lay<G>;
-    using Q = DigitQ<G>;
-    __shared__ uint4 tile4[BLOCK * L::OBS_DW / 4];
-    __shared__ uint32_t qmem[BLOCK * Q::QROW];
-    uint32_t *tile = reinterpret_cast<uint32_t *>(tile4);
-    const int64_t first = (int64_t)blockIdx.x * BLOCK;
-    const int64_t i = first + threadIdx.x;
-    const bool live_lane = i < p.n;
-    const int64_t li = live_lane ? i : first;
-    Env<G> e;
-    e.load(p.state, p.n, li);
-    float r = 0.0f;
-    bool term = false;
-    uint32_t tf = 0;
-    uint32_t *row = tile + threadIdx.x * L::OBS_DW;
-    const bool short_wave = __ballot(e.len > 15u) == 0ull;     // every history of this wave fits one word (see Env::move)
-    if (live_lane) {
-        const int32_t a = p.actions[i];
-        tf = transition<G, MODE>(e, p, i, (uint32_t)a, (uint32_t)a <= 3u, row, r, term, short_wave);
-    }
-    // only the lanes that place food (~8 %) touch their digit ring: two dwords of it, fetched on demand (dq_place_food<.., true>)
-    DqCtx<G> q{qmem + (threadIdx.x & ~63u) * Q::QROW, p.mt + li * MT_STRIDE, p.dq, p.n, li, 0u, false};
-    dq_place_food<G, true>(e, q, tf & T_NEED_FOOD);
-    if (__ballot(tf & T_DEFERRED)) {                           // rare, wave-uniform
-        const bool again = (tf & T_DEFERRED) && finish_deferred<G>(e, p, i, row);
-        dq_place_food<G, true>(e, q, again);
-    }
-    if (live_lane) {
-        e.write_obs_food(row);
-        e.store(p.state, p.n, i);
-        q.write_back();
-        p.reward[i] = r;
-        p.terminated[i] = term ? 1 : 0;
-        if (p.truncated) p.truncated[i] = 0;   // reference never truncates (snake_env.py:119)
-    }
-    lds_barrier();
-    const int64_t live = p.n - first < BLOCK ? p.n - first : BLOCK;
-    store_tile<BLOCK, BLOCK * L::CELLS>(tile, p.obs + first * L::CELLS, (uint32_t)(live * L::CELLS));
-}
-
 // One wave streams its own 64 obs rows (FULL contiguous bytes) from LDS to HBM: (ds_read_b128, global_store_dwordx4) pairs at
 // constant offsets, two pairs in flight at a time — the fully unrolled copy kept 28 VGPRs of tile data live across the step and
 // cost a wave per SIMD of occupancy.  Partial last wave / unaligned destination: the generic store_tile paths.
@@ -627,6 +596,55 @@ __device__ __forceinline__ void store_wave_rows(const uint32_t *rows, int8_t *ds
         return;
     }
     store_tile<64, 0>(rows, dst, bytes_valid, lane);
+}
+
+template <int G, int BLOCK, int MINW, int MODE>
+__global__ __launch_bounds__(BLOCK, MINW) void step_kernel(Params p) {
+    using L = Lay<G>;
+    using Q = DigitQ<G>;
+    static_assert(L::OBS_DW >= Q::QDW, "a ring row fits a lane's obs row");
+    __shared__ uint4 tile4[BLOCK * L::OBS_DW / 4];
+    uint32_t *tile = reinterpret_cast<uint32_t *>(tile4);
+    const int64_t first = (int64_t)blockIdx.x * BLOCK;
+    const int64_t i = first + threadIdx.x;
+    const bool live_lane = i < p.n;
+    const int64_t li = live_lane ? i : first;
+    Env<G> e;
+    e.load(p.state, p.n, li);
+    float r = 0.0f;
+    bool term = false;
+    uint32_t tf = 0;
+    uint32_t *row = tile + threadIdx.x * L::OBS_DW;
+    const bool short_wave = __ballot(e.len > 15u) == 0ull;     // every history of this wave fits one word (see Env::move)
+    if (live_lane) {
+        const int32_t a = p.actions[i];
+        tf = transition<G, MODE>(e, p, i, (uint32_t)a, (uint32_t)a <= 3u, nullptr, r, term, short_wave);
+    }
+    // Only the lanes that place food (~8 %) touch their digit ring: two dwords of it, fetched on demand (dq_place_food<.., true>).
+    // The ring rows borrow the lanes' own obs tile rows (the observation is staged after the placement): a separate 9 KB array
+    // took the kernel from 6 to 4 workgroups per CU.  Measured on one box and dropped (round 3, gpurun_out/r3_ab_step1.txt):
+    // prefetching every lane's ring next to the hot record (no dependent round trip, +32 B per env-step) 35.0 vs 34.8-35.1 us;
+    // every wave streaming its own 64 rows without the workgroup barrier 35.0-35.5 us — the kernel runs at the box's copy
+    // bandwidth on the 157 B per env-step it moves, the second round trip is hidden by the other 23 waves of the CU.
+    DqCtx<G> q{tile + (threadIdx.x & ~63u) * L::OBS_DW, (uint32_t)L::OBS_DW, p.mt + li * MT_STRIDE, p.dq, p.n, li, 0u, false};
+    dq_place_food<G, true>(e, q, tf & T_NEED_FOOD);
+    bool again = false;
+    if (__ballot(tf & T_DEFERRED)) {                           // rare, wave-uniform: see transition()
+        again = (tf & T_DEFERRED) && finish_deferred<G>(e, p, i, nullptr);
+        dq_place_food<G, true>(e, q, again);
+    }
+    if (live_lane) q.write_back();                             // before the row is reused for the observation
+    e.write_obs_body(row);
+    if (live_lane) {
+        e.write_obs_food(row);
+        e.store(p.state, p.n, i);
+        p.reward[i] = r;
+        p.terminated[i] = term ? 1 : 0;
+        if (p.truncated) p.truncated[i] = 0;   // reference never truncates (snake_env.py:119)
+    }
+    lds_barrier();
+    const int64_t live = p.n - first < BLOCK ? p.n - first : BLOCK;
+    store_tile<BLOCK, BLOCK * L::CELLS>(tile, p.obs + first * L::CELLS, (uint32_t)(live * L::CELLS));
 }
 
 // k fused steps per launch: state stays in VGPRs, only the obs rows (+ optional per-step reward / flag / explicit actions) touch
@@ -676,8 +694,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
     uint32_t a_next = (ACTIONS && live_lane && p.k_steps > 0) ? (uint32_t)p.actions[i] : 0u;
     // the digit rings of the wave's envs, parked in LDS for the launch; rings that could run dry during it are topped up now,
     // before the first observation store is in flight
-    DqCtx<G> q{qmem + (threadIdx.x & ~63u) * Q::QROW, p.mt + li * MT_STRIDE, p.dq, p.n, li, 0u, false};
-    q.load_cols(Q::ALL_COLS);
+    DqCtx<G> q{qmem + (threadIdx.x & ~63u) * Q::QROW, (uint32_t)Q::QROW, p.mt + li * MT_STRIDE, p.dq, p.n, li, 0u, false};
+    q.load_all();
     {
         const unsigned long long low = __ballot(live_lane && e.dq_left < p.dq_topup && dq_can_fill<G>(e));
         if (low) dq_refill<G>(e, q, low);
@@ -762,7 +780,7 @@ __global__ __launch_bounds__(Lay<G>::BLOCK) void reset_kernel(Params p) {
         need_food = e.can_place_food();
     }
     if (row) e.write_obs_body(row);
-    DqCtx<G> q{qmem + (threadIdx.x & ~63u) * Q::QROW, p.mt + li * MT_STRIDE, p.dq, p.n, li, 0u, false};
+    DqCtx<G> q{qmem + (threadIdx.x & ~63u) * Q::QROW, (uint32_t)Q::QROW, p.mt + li * MT_STRIDE, p.dq, p.n, li, 0u, false};
     dq_place_food<G, true>(e, q, need_food);
     if (row) e.write_obs_food(row);
     if (doit) { e.store(p.state, p.n, i); q.write_back(); }

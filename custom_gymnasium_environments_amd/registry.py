@@ -65,7 +65,8 @@ class NumpyVectorEnv:
     device slab (the env's output tensors are carved out of it), so a step is one kernel launch, one asynchronous device-to-host
     copy of the slab into pinned memory and one event wait; actions go up through a pinned staging buffer.  Two pinned slabs
     alternate, so the arrays step t returned stay valid while step t+1 runs (gymnasium hands out fresh arrays every step; the
-    arrays of step t-2 are overwritten — copy them if you keep them longer)."""
+    arrays of step t-2 are overwritten — copy them if you keep them longer).  `infos["episode"]["r"/"l"]` are per-step copies
+    here; on the torch path (numpy=False) they are the env's persistent statistics buffers, which later steps update in place."""
 
     def __init__(self, env, time_limit_truncates=False):
         if not getattr(env, "_reuse", False):
@@ -77,8 +78,9 @@ class NumpyVectorEnv:
         self.metadata, self.render_mode, self.spec = env.metadata, getattr(env, "render_mode", None), getattr(env, "spec", None)
         self.closed = False
         self._truncates = bool(time_limit_truncates) and getattr(env, "max_episode_steps", None) is not None
+        self._next_step = getattr(getattr(env, "autoreset_mode", None), "name", "") == "NEXT_STEP"
+        self._prev_done = np.zeros(self.num_envs, np.bool_)
         self._dev = env.device
-        self._stream = torch.cuda.current_stream(self._dev)
         self._layout = None
         self._host = None
         self._flip = 0
@@ -107,7 +109,9 @@ class NumpyVectorEnv:
         host = self._host[self._flip]
         self._flip ^= 1
         host.copy_(self._slab, non_blocking=True)              # the one device-to-host copy of this step
-        self._event.record(self._stream)
+        # the env launched its kernel on the stream that is current NOW (DeviceVectorEnv._stream), and so did the copy: the event
+        # belongs on that stream, not on whichever one was current when the adapter was built
+        self._event.record(torch.cuda.current_stream(self._dev))
         self._event.synchronize()
         out = {}
         hnp = host.numpy()
@@ -180,6 +184,7 @@ class NumpyVectorEnv:
     def reset(self, *, seed=None, options=None):
         obs, infos = self.env.reset(seed=seed, options=options)
         self._elapsed[...] = 0                                 # reset() is rare: plain synchronous copies, the step slab is untouched
+        self._prev_done[...] = False
         return obs.cpu().numpy(), {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in infos.items()}
 
     def step(self, actions):
@@ -187,9 +192,19 @@ class NumpyVectorEnv:
         host, infos_np = self._collect({"obs": obs, "reward": rew, "terminated": term, "truncated": trunc}, infos)
         terminated, truncated = host["terminated"], host["truncated"]
         if self._truncates:                                    # what gymnasium.wrappers.TimeLimit(max_episode_steps) adds on top of the env
-            self._elapsed += 1
+            if self._next_step:
+                # NextStep: the step() after an episode's end only resets that env (its action is ignored, the env takes no
+                # step).  gymnasium's vector TimeLimit restarts its counter on that call and does not count it.
+                self._elapsed[self._prev_done] = 0
+                self._elapsed[~self._prev_done] += 1
+            else:
+                self._elapsed += 1
             truncated = truncated | (self._elapsed >= self.env.max_episode_steps)
-            self._elapsed[terminated | truncated] = 0
+            done = terminated | truncated
+            if self._next_step:
+                self._prev_done = done
+            else:
+                self._elapsed[done] = 0
         return host["obs"], host["reward"], terminated, truncated, infos_np
 
     def call(self, name, *args, **kwargs):

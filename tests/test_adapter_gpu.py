@@ -91,3 +91,25 @@ def test_time_limit_truncates_flag_mirrors_gymnasiums_timelimit_wrapper():
         saw += int(trunc.sum())
     assert saw > 0
     env.close()
+
+
+def test_time_limit_truncates_in_next_step_mode_counts_env_steps_only():
+    """in NextStep mode (the default) the call after an episode's end is a reset-only step; gymnasium's TimeLimit does
+    not count it.  Over several episodes `truncated` must fire exactly on the env's own limit step, never a step early, and a
+    reset-only step must report no flag at all."""
+    import custom_gymnasium_environments_amd as cge
+    n, limit = 16, 30
+    env = cge.make_vec("snake_env_classic-v0", n, numpy=True, autoreset_mode="NextStep", time_limit_truncates=True, max_steps=limit)
+    env.unwrapped.max_episode_steps = limit
+    env.reset(seed=2)
+    prev_done = np.zeros(n, bool)
+    episodes_by_limit = 0
+    for t in range(6 * (limit + 1)):                             # up/right/down/left cycle: circles in place, every episode runs into the limit
+        _, rew, term, trunc, _ = env.step(np.full(n, t % 4))
+        steps = env.unwrapped.info("steps").cpu().numpy()
+        assert not (term | trunc)[prev_done].any(), t            # reset-only step: nothing ends on it
+        assert np.array_equal(trunc, term & (steps == limit)), t  # truncation == the env's own limit step, on that step
+        episodes_by_limit += int(trunc.sum())
+        prev_done = term | trunc
+    assert episodes_by_limit >= 4 * n
+    env.close()
