@@ -359,15 +359,17 @@ struct DqCtx {
     bool dirty;
 
     __device__ __forceinline__ uint32_t *my_row() const { return wave_q + (threadIdx.x & 63u) * stride; }
-    __device__ __forceinline__ void load_all() {                                // every column of this lane's ring (fused rollout, launch start)
-        using Q = DigitQ<G>;
+    // every column of this lane's ring (fused rollout, launch start), in two halves so that the caller can put its own loads
+    // (the env record) into the same round trip
+    __device__ __forceinline__ void issue_all(uint4 (&v)[DigitQ<G>::COLS]) const {
+#pragma unroll
+        for (int c = 0; c < DigitQ<G>::COLS; ++c) v[c] = dq[(int64_t)c * n + i];
+    }
+    __device__ __forceinline__ void park_all(const uint4 (&v)[DigitQ<G>::COLS]) {
         uint32_t *row = my_row();
-        uint4 v[Q::COLS];
 #pragma unroll
-        for (int c = 0; c < Q::COLS; ++c) v[c] = dq[(int64_t)c * n + i];
-#pragma unroll
-        for (int c = 0; c < Q::COLS; ++c) { row[4 * c] = v[c].x; row[4 * c + 1] = v[c].y; row[4 * c + 2] = v[c].z; row[4 * c + 3] = v[c].w; }
-        loaded = Q::ALL_COLS;
+        for (int c = 0; c < DigitQ<G>::COLS; ++c) { row[4 * c] = v[c].x; row[4 * c + 1] = v[c].y; row[4 * c + 2] = v[c].z; row[4 * c + 3] = v[c].w; }
+        loaded = DigitQ<G>::ALL_COLS;
     }
     // the (at most two) columns a placement round reads, c0 and c1, for the lanes with `want`: both loads are issued inside ONE
     // predicated region, so a wave whose lanes need different columns still pays one memory round trip (a load per `if` would
@@ -392,14 +394,13 @@ struct DqCtx {
     }
 };
 
-// Top the rings of the lanes in `want` (a ballot) up to 64 digits, two envs per memory round trip.  Must be called by all 64
+// Top the rings of the lanes in `want` (a ballot) up to 64 digits, RG envs per memory round trip.  Must be called by all 64
 // lanes of the wave.  Every load of a round precedes its stores (program order); lanes whose slot is not being filled re-read
 // the first word of the run.
-template <int G>
+template <int G, int RG = 2>
 __device__ __forceinline__ void dq_refill(Env<G> &e, DqCtx<G> &q, unsigned long long want) {
     using L = Lay<G>;
     using Q = DigitQ<G>;
-    constexpr int RG = 2;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t plo = (uint32_t)reinterpret_cast<uintptr_t>(q.blk), phi = (uint32_t)(reinterpret_cast<uintptr_t>(q.blk) >> 32);
 #pragma unroll 1
@@ -660,6 +661,10 @@ template <int G, int BLOCK, int MINW, int MODE, bool ACTIONS>
 __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
     using L = Lay<G>;
     using Q = DigitQ<G>;
+#ifndef CGE_SNAKE_TOPUP_RG
+#define CGE_SNAKE_TOPUP_RG 8
+#endif
+    constexpr int TOPUP_RG = CGE_SNAKE_TOPUP_RG;
     __shared__ uint4 tile4[BLOCK * L::OBS_DW / 4];
     __shared__ uint32_t qmem[BLOCK * Q::QROW];
     uint32_t *tile = reinterpret_cast<uint32_t *>(tile4);
@@ -674,7 +679,12 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
     uint64_t key = 0;
     float rsum = 0.0f;
     int32_t dcount = 0;
+    // the digit rings of the wave's envs are parked in LDS for the launch; their loads share the env record's round trip
+    DqCtx<G> q{qmem + (threadIdx.x & ~63u) * Q::QROW, (uint32_t)Q::QROW, p.mt + li * MT_STRIDE, p.dq, p.n, li, 0u, false};
+    uint4 ring[Q::COLS];
+    q.issue_all(ring);
     e.load(p.state, p.n, li);
+    q.park_all(ring);
     if (live_lane) key = hash_env_key(p.a_seed, (uint64_t)(p.env0 + i));
     // The lane's obs row lives in LDS for the whole rollout and is kept up to date INCREMENTALLY: a move sets the new head
     // byte and clears the vacated tail byte, a new food sets one byte; only an episode reset rewrites the row, and that is
@@ -692,13 +702,10 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
     // exception: wave-uniform, behind a scalar branch that is taken once per ~4 wave-steps in long launches and (with the top-up
     // before the loop) practically never in short ones.
     uint32_t a_next = (ACTIONS && live_lane && p.k_steps > 0) ? (uint32_t)p.actions[i] : 0u;
-    // the digit rings of the wave's envs, parked in LDS for the launch; rings that could run dry during it are topped up now,
-    // before the first observation store is in flight
-    DqCtx<G> q{qmem + (threadIdx.x & ~63u) * Q::QROW, (uint32_t)Q::QROW, p.mt + li * MT_STRIDE, p.dq, p.n, li, 0u, false};
-    q.load_all();
+    // rings that could run dry during the launch are topped up now, before the first observation store is in flight
     {
         const unsigned long long low = __ballot(live_lane && e.dq_left < p.dq_topup && dq_can_fill<G>(e));
-        if (low) dq_refill<G>(e, q, low);
+        if (low) dq_refill<G, TOPUP_RG>(e, q, low);            // several envs per round trip: nothing else is live yet
     }
     for (int t = 0; t < p.k_steps; ++t) {
         float r = 0.0f;
@@ -1126,11 +1133,12 @@ int cge_snake_rollout(cge_snake *h, int32_t k_steps, const int32_t *actions, uin
     p.obs = obs_out; p.obs_step_stride = obs_step_stride;
     p.reward = reward_traj_out; p.terminated = terminated_traj_out;
     p.reward_sum = reward_sum_out; p.done_count = done_count_out;
-    // rings that could run dry during the launch are topped up before its first step: a placement takes 3.2 digits on average
-    // and a launch of k steps ~0.25 k of them per env, with a long tail — 12 + k covers all but ~1e-3 of the envs of a 20-step
-    // launch; from 52 steps on every ring starts full
-    const int32_t top = 12 + k_steps;
-    p.dq_topup = (uint32_t)(top < 16 ? 16 : top > 64 ? 64 : top);
+    // Rings that hold less than one placement round are topped up before the launch's first step; everything else is left to
+    // the in-loop refill (wave-convergent, ~0.25 / 64 per env-step).  Measured on 1M envs, us per step at k = 20 / 40 / 100 / 200
+    // (gpurun_out/r3_ab_topup.txt, one box): threshold 8-16: 26.5-27.8 / 25.2-26.3 / 24.7-25.4 / 23.4-24.8; 32: 28.5-29.3 / 26.9-27.7 /
+    // 25.1-25.9 / 23.4-25.7; 64 (every ring full at the start): 31.5 / 29.2 / 25.9 / 22.8-24.8 — topping every ring up at every
+    // launch costs a block visit per env per launch for a handful of digits each.
+    p.dq_topup = 12u;
     h->ops.rollout(p, as_stream(stream), &h->last_kernel);
     CGE_TRY(h, hipGetLastError());
     return CGE_OK;

@@ -88,6 +88,7 @@ def _declare(L):
     L.orc_snake_render_rgb.argtypes = [vp, vp]
 
     L.orc_crypto_create.argtypes = [i64, i32, i32]; L.orc_crypto_create.restype = vp
+    L.orc_crypto_set_config.argtypes = [vp, vp]
     L.orc_crypto_destroy.argtypes = [vp]
     L.orc_crypto_seed.argtypes = [vp, vp]
     L.orc_crypto_reset.argtypes = [vp, vp, vp]
@@ -304,7 +305,11 @@ class CryptoOracle(_EpisodeStats):
     """Batch of independent CryptoTradingEnv restatements (oracle/orc_crypto.c)."""
     _name = "crypto"
 
-    def __init__(self, n, action_type="discrete", mode=SAME_STEP, max_steps=None):
+    # TradingConfig fields (crypto_trading_env.py:28-38) in the order orc_crypto_set_config takes them, with the reference defaults
+    CONFIG_FIELDS = (("initial_balance", 10000.0), ("trading_fee_rate", 0.001), ("slippage_rate", 0.0005), ("min_price", 100.0),
+                     ("max_price", 100000.0), ("volatility_base", 0.02), ("market_psychology_factor", 0.1))
+
+    def __init__(self, n, action_type="discrete", mode=SAME_STEP, max_steps=None, config=None):
         self.n, self.mode = int(n), int(mode)
         self.continuous = action_type == "continuous"
         self.h = lib().orc_crypto_create(self.n, int(self.continuous), self.mode)
@@ -312,6 +317,12 @@ class CryptoOracle(_EpisodeStats):
             raise ValueError("orc_crypto_create failed")
         if max_steps is not None:
             lib().orc_crypto_set_max_steps(self.h, int(max_steps))
+        if config:
+            unknown = set(config) - {k for k, _ in self.CONFIG_FIELDS}
+            if unknown:
+                raise ValueError(f"unknown TradingConfig field(s) {sorted(unknown)}")
+            cfg = np.array([float(config.get(k, d)) for k, d in self.CONFIG_FIELDS], np.float64)
+            lib().orc_crypto_set_config(self.h, _p(cfg))
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -284,6 +284,15 @@ orc_crypto *orc_crypto_create(int64_t n, int continuous, int mode) {
 }
 void orc_crypto_destroy(orc_crypto *h) { if (h) { free(h->e); eps_free(&h->eps); free(h); } }
 
+/* CryptoTradingEnv(config=TradingConfig(...)) (:28-38, :252): cfg = {initial_balance, trading_fee_rate, slippage_rate, min_price,
+ * max_price, volatility_base, market_psychology_factor}; call right after create (history_length stays 50).  __init__ sets
+ * self.cash = config.initial_balance (:260). */
+void orc_crypto_set_config(orc_crypto *h, const double *cfg) {
+    h->c.initial_balance = cfg[0]; h->c.fee_rate = cfg[1]; h->c.slippage_rate = cfg[2]; h->c.min_price = cfg[3];
+    h->c.max_price = cfg[4]; h->c.volatility_base = cfg[5]; h->c.psychology_factor = cfg[6];
+    for (int64_t i = 0; i < h->n; ++i) h->e[i].cash = h->c.initial_balance;
+}
+
 /* reset(seed=s): random.seed(s); np.random.seed(s)  (:305-307).  The MarketSimulator is NOT re-created. */
 void orc_crypto_seed(orc_crypto *h, const uint64_t *seeds) {
     for (int64_t i = 0; i < h->n; ++i) { orc_py_seed(&h->e[i].P, seeds[i]); orc_np_seed(&h->e[i].L, (uint32_t)seeds[i]); }

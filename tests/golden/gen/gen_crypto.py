@@ -6,7 +6,9 @@ Protocol: env i is a fresh CryptoTradingEnv run
 crypto_trading_env.py:305-307); auto-reset = `env.reset()` without a seed right after a terminal step
 (streams and the MarketSimulator state continue, :257).  Actions: counter hash mod 5 (discrete) or
 hashed floats in [-1,1] (continuous).
-Outputs: tests/golden/crypto_discrete.npz, crypto_continuous.npz, crypto_kat.json
+Outputs: tests/golden/crypto_discrete.npz, crypto_continuous.npz, crypto_config.npz, crypto_kat.json
+crypto_config: the reference constructed with a non-default TradingConfig (every field the batched env's constructor forwards),
+the way crypto_trading_env/quick_demo.py:17-24 builds it.
 """
 import json
 import os
@@ -28,8 +30,8 @@ def cont_action(a_seed, i, t):
     return np.array([u0 / 2.0**23 - 1.0, u1 / 2.0**23 - 1.0], dtype=np.float32)
 
 
-def run_env(kind, seed, T, a_seed, i):
-    env = ref.CryptoTradingEnv(action_type=kind)
+def run_env(kind, seed, T, a_seed, i, config=None):
+    env = ref.CryptoTradingEnv(action_type=kind, config=ref.TradingConfig(**config) if config else None)
     obs, _ = env.reset(seed=seed)
     obs0 = obs.copy()
     D = obs.shape[0]
@@ -55,8 +57,8 @@ def run_env(kind, seed, T, a_seed, i):
     return obs0, A, O, R, TE, INFO, resets
 
 
-def make(name, kind, n_envs, T, seed0, a_seed):
-    rows = [run_env(kind, seed0 + i, T, a_seed, i) for i in range(n_envs)]
+def make(name, kind, n_envs, T, seed0, a_seed, config=None):
+    rows = [run_env(kind, seed0 + i, T, a_seed, i, config) for i in range(n_envs)]
     ridx, robs = [], []
     for i, r in enumerate(rows):
         for t, ob in r[6]:
@@ -70,7 +72,7 @@ def make(name, kind, n_envs, T, seed0, a_seed):
         obs=np.stack([r[2] for r in rows]), reward=np.stack([r[3] for r in rows]),
         terminated=np.stack([r[4] for r in rows]), info=np.stack([r[5] for r in rows]),
         reset_index=np.array(ridx, np.int32).reshape(-1, 2), reset_obs=np.array(robs, np.float32).reshape(-1, D),
-        versions=np.array(json.dumps(common.versions())))
+        versions=np.array(json.dumps(common.versions())), **({"config": np.array(json.dumps(config))} if config else {}))
     R = np.stack([r[3] for r in rows])
     print(name, "obs dim", D, "episodes", len(ridx), "sum reward", R.sum(), os.path.getsize(out), "bytes")
 
@@ -99,3 +101,7 @@ if __name__ == "__main__":
     kat_c1()
     make("crypto_discrete", "discrete", 6, 1100, seed0=100, a_seed=123)
     make("crypto_continuous", "continuous", 3, 400, seed0=500, a_seed=77)
+    # a small balance and a wide, fast market: episodes end on the 10x / <= 0 portfolio bounds and both price clips are reached
+    make("crypto_config", "discrete", 4, 1100, seed0=900, a_seed=31,
+         config=dict(initial_balance=2500.0, trading_fee_rate=0.002, slippage_rate=0.001, min_price=2000.0, max_price=60000.0,
+                     volatility_base=0.035, market_psychology_factor=0.25))

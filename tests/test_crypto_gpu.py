@@ -9,6 +9,8 @@ Tolerances (float-state env; BASELINE north_star "within a stated fp32 tolerance
     tracks the CPU; the fraction of envs whose trajectory left that band (last-place differences of the
     device log feeding the psychology feedback loop) is reported and bounded.
 """
+import json
+
 import numpy as np
 import pytest
 import torch
@@ -40,13 +42,15 @@ def _close_rew(a, b):
     return np.abs(a.astype(np.float64) - b.astype(np.float64)) <= REW_ATOL + REW_RTOL * np.abs(b.astype(np.float64))
 
 
-@pytest.mark.parametrize("name", ["crypto_discrete.npz", "crypto_continuous.npz"])
+# crypto_config: the reference constructed with a non-default TradingConfig (every field the constructor forwards to the kernels)
+@pytest.mark.parametrize("name", ["crypto_discrete.npz", "crypto_continuous.npz", "crypto_config.npz"])
 def test_matches_reference_fixture(cge, name):
     fx = golden(name)
     kind = str(fx["kind"])
     A = fx["actions"]
     n, T = A.shape[0], A.shape[1]
-    env = cge.CryptoVectorEnv(n, action_type=kind, autoreset_mode="SameStep")
+    config = json.loads(str(fx["config"])) if "config" in fx else None
+    env = cge.CryptoVectorEnv(n, action_type=kind, autoreset_mode="SameStep", config=config)
     obs, _ = env.reset(seed=int(fx["seed0"]))
     assert _close_obs(_np(obs), fx["obs0"]).all()
     exact = total = 0
@@ -106,6 +110,42 @@ def test_step_matches_oracle(cge, oracle, kind, mode):
     for f in ["regime", "step", "episodes", "needs_reset", "cash_kind"]:
         assert np.array_equal(_np(env.info(f))[ok], o.info(f)[ok]), f
     env.close()
+
+
+def test_config_knobs_step_and_rollout_match_oracle(cge, oracle):
+    """every TradingConfig field the constructor forwards (crypto_trading_env.py:28-38) against the oracle built with the
+    same config — step() in two autoreset modes, then the fused rollout (reward sums, done counts, final observation)."""
+    config = dict(initial_balance=400.0, trading_fee_rate=0.004, slippage_rate=0.002, min_price=5000.0, max_price=80000.0,
+                  volatility_base=0.05, market_psychology_factor=0.3)
+    n = 257
+    for mode, code in [("SameStep", oracle.SAME_STEP), ("NextStep", oracle.NEXT_STEP)]:
+        env = cge.CryptoVectorEnv(n, autoreset_mode=mode, config=config, max_steps=120)
+        o = oracle.CryptoOracle(n, "discrete", code, max_steps=120, config=config)
+        o.seed(np.arange(n, dtype=np.uint64) + np.uint64(11))
+        od, _ = env.reset(seed=11)
+        assert _close_obs(_np(od), o.reset()).all()
+        rng = np.random.default_rng(5)
+        diverged = np.zeros(n, bool)
+        for t in range(300):
+            a = rng.integers(0, 5, n).astype(np.int32)
+            od, rd, ted, _, _ = env.step(a)
+            oo, ro, teo, _ = o.step(a)
+            diverged |= ~np.isclose(_np(env.info("current_price")), o.info("current_price"), rtol=1e-9, atol=0)
+            ok = ~diverged
+            assert np.array_equal(_np(ted)[ok], teo.astype(bool)[ok]), (mode, t)
+            assert _close_obs(_np(od)[ok], oo[ok]).all() and _close_rew(_np(rd)[ok], ro[ok]).all(), (mode, t)
+        assert int(diverged.sum()) <= 1
+        obs, rs, dc = env.rollout(200, action_seed=9, t0=0)
+        oo, ro, do = o.rollout(200, 9, t0=0, env0=0)
+        ok = ~diverged
+        assert np.array_equal(_np(dc)[ok], do[ok]) and int(do.sum()) > n          # several episodes per env
+        assert np.allclose(_np(rs)[ok], ro[ok], rtol=1e-6, atol=1e-2)
+        assert _close_obs(_np(obs)[ok], oo[ok]).all()
+        for f in ["cash", "holdings"]:
+            assert np.allclose(_np(env.info(f))[ok], o.info(f)[ok], rtol=1e-9, atol=1e-9), f
+        env.close()
+    with pytest.raises(ValueError):
+        cge.CryptoVectorEnv(4, config=dict(history_length=30))       # fixed at 50 in this build: refused, not ignored
 
 
 def test_teacher_forced_single_steps(cge, oracle):

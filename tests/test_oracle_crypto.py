@@ -2,6 +2,7 @@
 crypto_trading_env/crypto_trading_env.py (tests/golden/gen/gen_crypto.py): float32 observations
 bit-for-bit, float64 rewards and info scalars bit-for-bit, flags exact."""
 import hashlib
+import json
 
 import numpy as np
 import pytest
@@ -9,13 +10,15 @@ import pytest
 from conftest import golden
 
 
-@pytest.mark.parametrize("name", ["crypto_discrete.npz", "crypto_continuous.npz"])
+# crypto_config: the reference built with a non-default TradingConfig (gen_crypto.py; crypto_trading_env/quick_demo.py:17-24)
+@pytest.mark.parametrize("name", ["crypto_discrete.npz", "crypto_continuous.npz", "crypto_config.npz"])
 def test_same_step_matches_reference_bitwise(oracle, name):
     fx = golden(name)
     kind = str(fx["kind"])
     A = fx["actions"]
     n, T = A.shape[0], A.shape[1]
-    o = oracle.CryptoOracle(n, kind, oracle.SAME_STEP)
+    config = json.loads(str(fx["config"])) if "config" in fx else None
+    o = oracle.CryptoOracle(n, kind, oracle.SAME_STEP, config=config)
     o.seed(np.arange(n, dtype=np.uint64) + np.uint64(int(fx["seed0"])))
     obs0 = o.reset()
     assert np.array_equal(obs0.view(np.uint32), fx["obs0"].view(np.uint32))
