@@ -11,15 +11,20 @@ from .vector_env import DeviceVectorEnv
 INFO_FIELDS = {"timestep": 0, "num_vehicles": 1, "light_phase": 2, "light_timer": 3, "vehicles_passed": 4,
                "total_waiting_time": 5, "queue_len": 6, "queue_dest": 7, "queue_wait": 8, "episodes": 9, "needs_reset": 10}
 LIGHT_PHASES = ("NS_GREEN", "NS_YELLOW", "EW_GREEN", "EW_YELLOW")   # config.py:17
-OBS_DIM = 130
+OBS_DIM = 130                    # default layout (9 intersections); an instance's own width is `env.obs_dim`
+SUPPORTED_INTERSECTIONS = (4, 9, 16)
 
 
 class TrafficVectorEnv(DeviceVectorEnv):
     """N independent TrafficManagementEnv instances (default 5x5 grid, 9 controlled intersections) stepped by
     one HIP kernel launch.
 
-    Spaces as the reference (environment.py:111-130): actions `MultiDiscrete([3]*9)` (0 maintain, 1 switch to
-    NS_GREEN, 2 switch to EW_GREEN), obs `Box(0, inf, (130,), float32)`; reward is the reference's cumulative
+    Constructor arguments as the reference's (environment.py:62-83): `grid_size=(rows, cols)`, `num_intersections` (the env
+    controls NI = min(num_intersections, rows*cols) of them), `max_vehicles`, `spawn_rate`.  Kernels are compiled for NI in
+    {4, 9, 16} — what the reference's own scripts build: simple_test.py:71-76 ((3,3), 4, 20, 0.4), the default ((5,5), 9, 50,
+    0.3), USAGE_EXAMPLES.md:32-38 ((6,6), 16, 80, 0.5) — over any grid.
+    Spaces as the reference (:108-130): actions `MultiDiscrete([3]*NI)` (0 maintain, 1 switch to NS_GREEN, 2 switch to
+    EW_GREEN), obs `Box(0, inf, (14*NI + 4,), float32)`; reward is the reference's cumulative
     expression (:287-311) returned as float32; terminated when timestep >= 1000; truncated always False.
     Bit-exact with the reference (integer state, float64 reward, float32 obs).  `reset(seed=s)` gives env i
     the private stream `random.seed(s + env_index0 + i)` (:145-146).
@@ -37,18 +42,25 @@ class TrafficVectorEnv(DeviceVectorEnv):
         cfg.num_intersections = int(num_intersections)
         cfg.max_vehicles, cfg.spawn_rate, cfg.max_steps = int(max_vehicles), float(spawn_rate), int(max_steps)
         cfg.autoreset_mode = self._mode_code
-        self.single_action_space = MultiDiscrete([3] * 9)
-        self.single_observation_space = Box(0.0, np.inf, (OBS_DIM,), np.float32)
+        self.grid_size = (int(grid_size[0]), int(grid_size[1]))
+        self.num_intersections = min(int(num_intersections), self.grid_size[0] * self.grid_size[1])       # environment.py:79
+        self.max_vehicles, self.spawn_rate, self.max_steps = int(max_vehicles), float(spawn_rate), int(max_steps)
+        self.obs_dim = 14 * self.num_intersections + 4                                                   # :108-121
+        self.single_action_space = MultiDiscrete([3] * self.num_intersections)
+        self.single_observation_space = Box(0.0, np.inf, (self.obs_dim,), np.float32)
         self.action_space = batch_space(self.single_action_space, self.num_envs)
         self.observation_space = batch_space(self.single_observation_space, self.num_envs)
         self.info_fields = tuple(info_fields)
         h = C.c_void_p()
         st = self._lib.cge_traffic_create(C.byref(cfg), self.num_envs, self._dev_index, self.env_index0, C.byref(h))
         if st == -3:
-            raise ValueError("only the reference's default layout (grid_size=(5,5), num_intersections=9) is compiled in")
+            raise ValueError(f"num_intersections={self.num_intersections} is not compiled into libcge_amd.so (supported: {SUPPORTED_INTERSECTIONS})")
+        if st == -1:
+            raise ValueError("TrafficVectorEnv: grid_size within 1..64 per side, 0 <= max_vehicles <= 127, max_steps <= 65535, "
+                             "max_vehicles * max_steps <= 262143 and spawn_rate >= 0 are required")
         _native.check(st, what="cge_traffic_create")
         self._h = h
-        self._obs_shape = (self.num_envs, OBS_DIM)
+        self._obs_shape = (self.num_envs, self.obs_dim)
         self.record_episode_statistics(record_episode_statistics)
 
     def reset(self, *, seed=None, options=None):
@@ -62,7 +74,7 @@ class TrafficVectorEnv(DeviceVectorEnv):
         return obs, self._infos()
 
     def step(self, actions):
-        a = self._as_device(actions, torch.int32, (self.num_envs, 9), "actions")
+        a = self._as_device(actions, torch.int32, (self.num_envs, self.num_intersections), "actions")
         obs = self._out("obs", self._obs_shape, torch.float32)
         rew = self._out("reward", (self.num_envs,), torch.float32)
         term = self._out("terminated", (self.num_envs,), torch.bool)
@@ -82,12 +94,12 @@ class TrafficVectorEnv(DeviceVectorEnv):
     def rollout(self, k_steps, actions=None, action_seed=0, t0=0, trajectory=False, want_obs=True, per_step=False):
         """k fused step()s in one launch; see SnakeVectorEnv.rollout.  reward_sum is float64."""
         k = int(k_steps)
-        a = None if actions is None else self._as_device(actions, torch.int32, (k, self.num_envs, 9), "actions")
+        a = None if actions is None else self._as_device(actions, torch.int32, (k, self.num_envs, self.num_intersections), "actions")
         obs, stride = None, 0
         if want_obs:
             if trajectory:
                 obs = self._out("traj", (k,) + self._obs_shape, torch.float32)
-                stride = self.num_envs * OBS_DIM
+                stride = self.num_envs * self.obs_dim
             else:
                 obs = self._out("obs", self._obs_shape, torch.float32)
         rs = self._out("reward_sum", (self.num_envs,), torch.float64)

@@ -215,7 +215,8 @@ const char *cge_crypto_last_kernel(const cge_crypto *h);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Traffic  (traffic_management_env/environment.py: TrafficManagementEnv, utils.py, config.py)  */
-/*   obs float32 (130,) (:313-363)   action int32[9] in {0 maintain,1 NS_GREEN,2 EW_GREEN}       */
+/*   obs float32 (14 NI + 4,) (:313-363; 130 for the default NI = 9 intersections)               */
+/*   action int32[NI] in {0 maintain,1 NS_GREEN,2 EW_GREEN}                                      */
 /*   State is the collapsed form of SURVEY.md 8a (queue length / waiting sum / arrivals-at-      */
 /*   destination per queue, counters per intersection, vehicle count): _update_vehicles          */
 /*   (:251-269) never moves a vehicle, so nothing else is observable.  Bit-exact: integer state,  */
@@ -224,15 +225,17 @@ const char *cge_crypto_last_kernel(const cge_crypto *h);
 typedef struct cge_traffic cge_traffic;
 
 typedef struct {                 /* TrafficManagementEnv.__init__ kwargs (:61-66) + config.py */
-    int32_t grid_rows, grid_cols;    /* (5, 5) — the only grid compiled in */
-    int32_t num_intersections;       /* 9 */
-    int32_t max_vehicles;            /* 50; <= 63 and max_vehicles*max_steps <= 65535 */
+    int32_t grid_rows, grid_cols;    /* (5, 5); any grid of 1..64 rows / columns: the routes walk the whole grid (utils.py:196-214) */
+    int32_t num_intersections;       /* 9; the env uses NI = min(num_intersections, rows*cols) (:79).  Kernels are compiled for NI in
+                                      * {4, 9, 16} — the layouts the reference's scripts build (simple_test.py:71-76, config.py:6-7,
+                                      * USAGE_EXAMPLES.md:32-38); any other NI: CGE_ERR_UNSUPPORTED */
+    int32_t max_vehicles;            /* 50; <= 127 and max_vehicles*max_steps <= 262143 (queue word: len:7 dest:7 wait:18) */
     double spawn_rate;               /* 0.3 */
     int32_t max_steps;               /* MAX_TIMESTEPS = 1000 */
     int32_t autoreset_mode;          /* CGE_AUTORESET_* */
 } cge_traffic_config;
 
-enum { /* cge_traffic_info field ids (int32 per env; `index` selects the intersection 0..8 or queue 0..35 = 4*i+dir) */
+enum { /* cge_traffic_info field ids (int32 per env; `index` selects the intersection 0..NI-1 or queue 0..4NI-1 = 4*i+dir) */
     CGE_TRAFFIC_INFO_TIMESTEP = 0,
     CGE_TRAFFIC_INFO_NUM_VEHICLES = 1,
     CGE_TRAFFIC_INFO_LIGHT_PHASE = 2,       /* 0 NS_GREEN 1 NS_YELLOW 2 EW_GREEN 3 EW_YELLOW */

@@ -107,7 +107,10 @@ def _declare(L):
     L.orc_traffic_rollout.argtypes = [vp, i32, u64, i64, i64, vp, vp, vp]
     L.orc_traffic_info.argtypes = [vp, i32, i32, vp]
     L.orc_traffic_total_reward.argtypes = [vp, vp]
-    L.orc_traffic_state_bytes.argtypes = []; L.orc_traffic_state_bytes.restype = C.c_size_t
+    L.orc_traffic_state_bytes.argtypes = [vp]; L.orc_traffic_state_bytes.restype = C.c_size_t
+    L.orc_traffic_set_layout.argtypes = [vp, i32, i32, i32, i32, dbl]; L.orc_traffic_set_layout.restype = i32
+    L.orc_traffic_obs_dim.argtypes = [vp]; L.orc_traffic_obs_dim.restype = i32
+    L.orc_traffic_num_intersections.argtypes = [vp]; L.orc_traffic_num_intersections.restype = i32
     L.orc_traffic_get_state.argtypes = [vp, vp]
     L.orc_traffic_set_state.argtypes = [vp, vp]
 
@@ -388,16 +391,21 @@ TRAFFIC_INFO = {"timestep": 0, "num_vehicles": 1, "light_phase": 2, "light_timer
 
 
 class TrafficOracle(_EpisodeStats):
-    """Batch of independent TrafficManagementEnv restatements (oracle/orc_traffic.c)."""
+    """Batch of independent TrafficManagementEnv restatements (oracle/orc_traffic.c).  grid_size / num_intersections / max_vehicles /
+    spawn_rate are the reference constructor's arguments (environment.py:62-83); num_intersections <= 16 here."""
     _name = "traffic"
 
-    def __init__(self, n, mode=SAME_STEP, max_steps=None):
+    def __init__(self, n, mode=SAME_STEP, max_steps=None, grid_size=(5, 5), num_intersections=9, max_vehicles=50, spawn_rate=0.3):
         self.n, self.mode = int(n), int(mode)
         self.h = lib().orc_traffic_create(self.n, self.mode)
         if not self.h:
             raise ValueError("orc_traffic_create failed")
         if max_steps is not None:
             lib().orc_traffic_set_max_steps(self.h, int(max_steps))
+        if lib().orc_traffic_set_layout(self.h, int(grid_size[0]), int(grid_size[1]), int(num_intersections), int(max_vehicles), float(spawn_rate)):
+            raise ValueError("layout outside the oracle's capacity (num_intersections <= 16)")
+        self.obs_dim = int(lib().orc_traffic_obs_dim(self.h))
+        self.ni = int(lib().orc_traffic_num_intersections(self.h))
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -410,15 +418,15 @@ class TrafficOracle(_EpisodeStats):
         lib().orc_traffic_seed(self.h, _p(seeds))
 
     def reset(self, mask=None):
-        obs = np.zeros((self.n, TRAFFIC_OBS), np.float32)
+        obs = np.zeros((self.n, self.obs_dim), np.float32)
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
         lib().orc_traffic_reset(self.h, _p(m), _p(obs))
         return obs
 
     def step(self, actions, want_final=False):
         a = np.ascontiguousarray(actions, dtype=np.int32)
-        assert a.shape == (self.n, 9)
-        obs = np.zeros((self.n, TRAFFIC_OBS), np.float32)
+        assert a.shape == (self.n, self.ni)
+        obs = np.zeros((self.n, self.obs_dim), np.float32)
         rew = np.zeros(self.n, np.float32)
         rew64 = np.zeros(self.n, np.float64)
         te = np.zeros(self.n, np.uint8)
@@ -429,7 +437,7 @@ class TrafficOracle(_EpisodeStats):
         return (obs, rew, te, tr, fin) if want_final else (obs, rew, te, tr)
 
     def rollout(self, k, a_seed, t0=0, env0=0, want_obs=True):
-        obs = np.zeros((self.n, TRAFFIC_OBS), np.float32) if want_obs else None
+        obs = np.zeros((self.n, self.obs_dim), np.float32) if want_obs else None
         rs = np.zeros(self.n, np.float64)
         dc = np.zeros(self.n, np.int32)
         lib().orc_traffic_rollout(self.h, k, a_seed, t0, env0, _p(obs), _p(rs), _p(dc))
@@ -446,13 +454,13 @@ class TrafficOracle(_EpisodeStats):
         return out
 
     def get_state(self):
-        buf = np.zeros((self.n, lib().orc_traffic_state_bytes()), np.uint8)
+        buf = np.zeros((self.n, lib().orc_traffic_state_bytes(self.h)), np.uint8)
         lib().orc_traffic_get_state(self.h, _p(buf))
         return buf
 
     def set_state(self, buf):
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
-        assert buf.shape == (self.n, lib().orc_traffic_state_bytes())
+        assert buf.shape == (self.n, lib().orc_traffic_state_bytes(self.h))
         lib().orc_traffic_set_state(self.h, _p(buf))
 
 

@@ -4,7 +4,9 @@ traffic_management_env/{environment,utils,config}.py (unmodified, imported from 
 Protocol: env i is a fresh TrafficManagementEnv() run alone after
 `reset(seed=S+i)` (seeds the global `random`, environment.py:145-147); auto-reset = `env.reset()` with no
 seed after a terminal step (stream continues).  Actions: counter hash mod 3 per (env, t, intersection).
-Outputs: tests/golden/traffic_default.npz, traffic_kat.json
+Outputs: tests/golden/traffic_hash.npz, traffic_lazy.npz, traffic_kat.json and, for the constructor arguments the reference's own
+scripts vary, traffic_3x3.npz (simple_test.py:71-76: grid (3,3), 4 intersections, 20 vehicles, spawn 0.4) and traffic_6x6.npz
+(USAGE_EXAMPLES.md:32-38: grid (6,6), 16 intersections, 80 vehicles, spawn 0.5).
 """
 import json
 import os
@@ -30,22 +32,23 @@ def internal(env):
     return out
 
 
-def run_env(seed, T, a_seed, i, policy):
-    env = TrafficManagementEnv()
+def run_env(seed, T, a_seed, i, policy, ctor=None):
+    env = TrafficManagementEnv(**(ctor or {}))
+    ni = env.num_intersections
     obs, _ = env.reset(seed=seed)
     obs0 = obs.copy()
-    O = np.zeros((T, 130), np.float32)
+    O = np.zeros((T, obs.shape[0]), np.float32)
     R = np.zeros(T, np.float64)
     TE = np.zeros(T, np.uint8)
-    A = np.zeros((T, 9), np.int32)
-    S = np.zeros((T, 9 * 8 + 2), np.int32)
+    A = np.zeros((T, ni), np.int32)
+    S = np.zeros((T, ni * 8 + 2), np.int32)
     resets = []
     for t in range(T):
         if policy == "hash":
-            a = np.array([common.hash_action(a_seed, i, t, 3, j) for j in range(9)], np.int32)
+            a = np.array([common.hash_action(a_seed, i, t, 3, j) for j in range(ni)], np.int32)
         else:  # mostly "maintain" so lights run on their own random timers (exercises randint(5,30) heavily)
             a = np.array([common.hash_action(a_seed, i, t, 3, j) if common.hash_action(a_seed, i, t, 10, 16 + j) == 0 else 0
-                          for j in range(9)], np.int32)
+                          for j in range(ni)], np.int32)
         obs, rew, term, trunc, info = env.step(a)
         assert not trunc
         A[t] = a; O[t] = obs; R[t] = rew; TE[t] = term; S[t] = internal(env)
@@ -55,8 +58,8 @@ def run_env(seed, T, a_seed, i, policy):
     return obs0, A, O, R, TE, S, resets
 
 
-def make(name, n_envs, T, seed0, a_seed, policy):
-    rows = [run_env(seed0 + i, T, a_seed, i, policy) for i in range(n_envs)]
+def make(name, n_envs, T, seed0, a_seed, policy, ctor=None):
+    rows = [run_env(seed0 + i, T, a_seed, i, policy, ctor) for i in range(n_envs)]
     ridx, robs = [], []
     for i, r in enumerate(rows):
         for t, ob in r[6]:
@@ -66,8 +69,8 @@ def make(name, n_envs, T, seed0, a_seed, policy):
         out, seed0=np.int64(seed0), a_seed=np.int64(a_seed), policy=np.array(policy),
         obs0=np.stack([r[0] for r in rows]), actions=np.stack([r[1] for r in rows]), obs=np.stack([r[2] for r in rows]),
         reward=np.stack([r[3] for r in rows]), terminated=np.stack([r[4] for r in rows]), internal=np.stack([r[5] for r in rows]),
-        reset_index=np.array(ridx, np.int32).reshape(-1, 2), reset_obs=np.array(robs, np.float32).reshape(-1, 130),
-        versions=np.array(json.dumps(common.versions())))
+        reset_index=np.array(ridx, np.int32).reshape(-1, 2), reset_obs=np.array(robs, np.float32).reshape(-1, rows[0][0].shape[0]),
+        versions=np.array(json.dumps(common.versions())), **({"ctor": np.array(json.dumps(ctor))} if ctor else {}))
     R = np.stack([r[3] for r in rows])
     print(name, "episodes", len(ridx), "sum reward", R.sum(), os.path.getsize(out), "bytes")
 
@@ -97,3 +100,7 @@ if __name__ == "__main__":
     kat_t1()
     make("traffic_hash", 6, 1100, seed0=200, a_seed=123, policy="hash")
     make("traffic_lazy", 6, 1100, seed0=300, a_seed=55, policy="lazy")
+    make("traffic_3x3", 5, 1100, seed0=400, a_seed=77, policy="lazy",
+         ctor=dict(grid_size=(3, 3), num_intersections=4, max_vehicles=20, spawn_rate=0.4))       # simple_test.py:71-76
+    make("traffic_6x6", 4, 1100, seed0=500, a_seed=99, policy="lazy",
+         ctor=dict(grid_size=(6, 6), num_intersections=16, max_vehicles=80, spawn_rate=0.5))      # USAGE_EXAMPLES.md:32-38

@@ -2,6 +2,7 @@
 reference's own traffic_management_env (tests/golden/gen/gen_traffic.py): float32 obs bit-for-bit,
 float64 rewards bit-for-bit, flags and every observable internal counter exact."""
 import hashlib
+import json
 
 import numpy as np
 import pytest
@@ -9,12 +10,16 @@ import pytest
 from conftest import golden
 
 
-@pytest.mark.parametrize("name", ["traffic_hash.npz", "traffic_lazy.npz"])
+# traffic_3x3 / traffic_6x6: the reference constructed the way its own scripts do (simple_test.py:71-76, USAGE_EXAMPLES.md:32-38):
+# other grid, number of intersections (obs 60 / 228 wide), vehicle cap and spawn rate
+@pytest.mark.parametrize("name", ["traffic_hash.npz", "traffic_lazy.npz", "traffic_3x3.npz", "traffic_6x6.npz"])
 def test_same_step_matches_reference_bitwise(oracle, name):
     fx = golden(name)
     A = fx["actions"]
-    n, T = A.shape[0], A.shape[1]
-    o = oracle.TrafficOracle(n, oracle.SAME_STEP)
+    n, T, ni = A.shape[0], A.shape[1], A.shape[2]
+    ctor = json.loads(str(fx["ctor"])) if "ctor" in fx else {}
+    o = oracle.TrafficOracle(n, oracle.SAME_STEP, **ctor)
+    assert o.ni == ni and o.obs_dim == fx["obs"].shape[2]
     o.seed(np.arange(n, dtype=np.uint64) + np.uint64(int(fx["seed0"])))
     assert np.array_equal(o.reset().view(np.uint32), fx["obs0"].view(np.uint32))
     reset_at = {(int(i), int(t)): k for k, (i, t) in enumerate(fx["reset_index"])}
@@ -29,14 +34,14 @@ def test_same_step_matches_reference_bitwise(oracle, name):
             assert np.array_equal(obs[i], fx["reset_obs"][reset_at[(int(i), t)]])
         S = fx["internal"][:, t]
         live = ~done
-        for it in range(9):
+        for it in range(ni):
             assert np.array_equal(o.info("light_phase", it)[live], S[live, it * 8 + 0])
             assert np.array_equal(o.info("light_timer", it)[live], S[live, it * 8 + 1])
             assert np.array_equal(o.info("vehicles_passed", it)[live], S[live, it * 8 + 2])
             assert np.array_equal(o.info("total_waiting_time", it)[live], S[live, it * 8 + 3])
             for d in range(4):
                 assert np.array_equal(o.info("queue_len", it * 4 + d)[live], S[live, it * 8 + 4 + d])
-        assert np.array_equal(o.info("num_vehicles")[live], S[live, 72])
+        assert np.array_equal(o.info("num_vehicles")[live], S[live, 8 * ni])
     assert len(reset_at) == n
 
 

@@ -1,6 +1,8 @@
 """GPU parity tests for the traffic hot path (through the C ABI via TrafficVectorEnv): bit-exact obs
 (float32), rewards (float32 of the bit-identical float64), flags and internal counters against the golden
 vectors recorded from the reference and against the CPU oracle."""
+import json
+
 import numpy as np
 import pytest
 import torch
@@ -22,12 +24,15 @@ def _np(t):
     return t.cpu().numpy()
 
 
-@pytest.mark.parametrize("name", ["traffic_hash.npz", "traffic_lazy.npz"])
+# traffic_3x3 / traffic_6x6: the reference built the way its own scripts do (simple_test.py:71-76, USAGE_EXAMPLES.md:32-38)
+@pytest.mark.parametrize("name", ["traffic_hash.npz", "traffic_lazy.npz", "traffic_3x3.npz", "traffic_6x6.npz"])
 def test_same_step_matches_reference_fixture(cge, name):
     fx = golden(name)
     A = fx["actions"]
-    n, T = A.shape[0], A.shape[1]
-    env = cge.TrafficVectorEnv(n, autoreset_mode="SameStep")
+    n, T, ni = A.shape[0], A.shape[1], A.shape[2]
+    ctor = json.loads(str(fx["ctor"])) if "ctor" in fx else {}
+    env = cge.TrafficVectorEnv(n, autoreset_mode="SameStep", **ctor)
+    assert env.num_intersections == ni and env.obs_dim == fx["obs"].shape[2]
     obs, _ = env.reset(seed=int(fx["seed0"]))
     assert np.array_equal(_np(obs), fx["obs0"])
     reset_at = {(int(i), int(t)): k for k, (i, t) in enumerate(fx["reset_index"])}
@@ -43,12 +48,12 @@ def test_same_step_matches_reference_fixture(cge, name):
             assert np.array_equal(obs[i], fx["reset_obs"][reset_at[(int(i), t)]])
         if t % 100 == 7:
             S, live = fx["internal"][:, t], ~te
-            for it in range(9):
+            for it in range(ni):
                 assert np.array_equal(_np(env.info("light_phase", it))[live], S[live, it * 8])
                 assert np.array_equal(_np(env.info("light_timer", it))[live], S[live, it * 8 + 1])
                 assert np.array_equal(_np(env.info("vehicles_passed", it))[live], S[live, it * 8 + 2])
                 assert np.array_equal(_np(env.info("total_waiting_time", it))[live], S[live, it * 8 + 3])
-            assert np.array_equal(_np(env.info("num_vehicles"))[live], S[live, 72])
+            assert np.array_equal(_np(env.info("num_vehicles"))[live], S[live, 8 * ni])
     env.close()
 
 
@@ -76,6 +81,75 @@ def test_step_matches_oracle_all_modes(cge, oracle, mode):
     for q in range(36):
         for f in ["queue_len", "queue_dest", "queue_wait"]:
             assert np.array_equal(_np(env.info(f, q)), o.info(f, q)), (f, q)
+    env.close()
+
+
+LAYOUTS = [dict(grid_size=(3, 3), num_intersections=4, max_vehicles=20, spawn_rate=0.4),          # simple_test.py:71-76
+           dict(grid_size=(6, 6), num_intersections=16, max_vehicles=80, spawn_rate=0.5),         # USAGE_EXAMPLES.md:32-38
+           dict(grid_size=(2, 7), num_intersections=9, max_vehicles=5, spawn_rate=0.9),           # a non-square grid, a tight vehicle cap
+           dict(grid_size=(2, 2), num_intersections=9, max_vehicles=127, spawn_rate=1.0),         # clamped to 4 intersections; always spawns
+           dict(grid_size=(5, 5), num_intersections=9, max_vehicles=50, spawn_rate=0.0)]          # never spawns
+
+
+@pytest.mark.parametrize("ctor", LAYOUTS, ids=lambda c: f"{c['grid_size'][0]}x{c['grid_size'][1]}_{c['num_intersections']}_{c['max_vehicles']}_{c['spawn_rate']}")
+def test_layouts_and_knobs_match_oracle(cge, oracle, ctor):
+    """Every constructor argument the reference takes (environment.py:62-83) against the oracle built with the same ones:
+    step() with explicit actions in SameStep mode through a short time limit, then the fused rollout on top, a state round
+    trip through the oracle, and the rollout's trajectory against step() on a twin."""
+    n, limit = 200, 90
+    env = cge.TrafficVectorEnv(n, autoreset_mode="SameStep", env_index0=5, max_steps=limit, **ctor)
+    o = oracle.TrafficOracle(n, oracle.SAME_STEP, max_steps=limit, **ctor)
+    ni = env.num_intersections
+    assert ni == o.ni and env.obs_dim == o.obs_dim == 14 * ni + 4
+    assert env.single_action_space.nvec.shape == (ni,) and env.single_observation_space.shape == (env.obs_dim,)
+    o.seed(np.arange(n, dtype=np.uint64) + np.uint64(5 + 21))
+    od, _ = env.reset(seed=21)
+    assert np.array_equal(_np(od), o.reset())
+    rng = np.random.default_rng(8)
+    for t in range(2 * limit + 10):
+        a = rng.integers(0, 3, (n, ni)).astype(np.int32)
+        if t % 3:
+            a[rng.random((n, ni)) < 0.8] = 0
+        od, rd, ted, _, info = env.step(a)
+        oo, ro, teo, _, fo = o.step(a, want_final=True)
+        assert np.array_equal(_np(od).view(np.uint32), oo.view(np.uint32)), t
+        assert np.array_equal(_np(rd), ro) and np.array_equal(_np(ted), teo.astype(bool)), t
+        done = teo.astype(bool)
+        assert np.array_equal(_np(info["final_obs"])[done], fo[done]), t
+    obs, rs, dc = env.rollout(150, action_seed=9, t0=3)
+    oo, ro, do = o.rollout(150, 9, t0=3, env0=5)
+    assert np.array_equal(_np(obs), oo) and np.array_equal(_np(rs), ro) and np.array_equal(_np(dc), do) and do.min() >= 1
+    assert np.array_equal(_np(env.total_reward()), o.total_reward())
+    for q in range(4 * ni):
+        for f in ["queue_len", "queue_dest", "queue_wait"]:
+            assert np.array_equal(_np(env.info(f, q)), o.info(f, q)), (f, q)
+    assert bool((env.info("num_vehicles") <= max(ctor["max_vehicles"], 0)).all())
+    if ctor["spawn_rate"] == 0.0:
+        assert int(env.info("num_vehicles").max()) == 0
+    o2 = oracle.TrafficOracle(n, oracle.SAME_STEP, max_steps=limit, **ctor)
+    o2.set_state(env.get_state())
+    twin = cge.TrafficVectorEnv(n, autoreset_mode="SameStep", env_index0=5, max_steps=limit, **ctor)
+    twin.set_state(o2.get_state())
+    assert np.array_equal(twin.get_state(), env.get_state())
+    acts = torch.randint(0, 3, (40, n, ni), dtype=torch.int32, device="cuda")
+    traj, rt, tt, rs, dc = env.rollout(40, actions=acts, trajectory=True, per_step=True)
+    for t in range(40):
+        ob, r, te, _, _ = twin.step(acts[t])
+        assert torch.equal(ob, traj[t]) and torch.equal(r, rt[t]) and torch.equal(te, tt[t]), t
+    env.close(); twin.close()
+
+
+def test_unsupported_layouts_and_out_of_range_knobs_are_refused(cge):
+    with pytest.raises(ValueError, match="not compiled"):
+        cge.TrafficVectorEnv(4, grid_size=(5, 5), num_intersections=7)
+    with pytest.raises(ValueError):
+        cge.TrafficVectorEnv(4, max_vehicles=128)
+    with pytest.raises(ValueError):
+        cge.TrafficVectorEnv(4, max_vehicles=100, max_steps=5000)       # a queue's waiting sum would not fit its 18 bits
+    with pytest.raises(ValueError):
+        cge.TrafficVectorEnv(4, spawn_rate=-0.1)
+    env = cge.make_vec("TrafficManagement-v0", 8, grid_size=(3, 3), num_intersections=4, max_vehicles=20, spawn_rate=0.4)
+    assert env.num_intersections == 4 and env.reset(seed=1)[0].shape == (8, 60)
     env.close()
 
 
