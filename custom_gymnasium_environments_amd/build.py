@@ -12,8 +12,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcge_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -fno-strict-aliasing: the obs staging code writes an LDS tile through float pointers and streams it out through uint32_t / uint4
+# ones; under the type-based aliasing rules those float stores are dead, and hipcc did drop them (round 3, traffic staging)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-         "-Wno-unused-local-typedef", "-fno-fast-math", "-ffp-contract=off"]
+         "-Wno-unused-local-typedef", "-fno-fast-math", "-ffp-contract=off", "-fno-strict-aliasing"]
 
 
 def sources():

@@ -318,9 +318,11 @@ __device__ __forceinline__ void fill_chunk(const Env<NI> &e, const ObsTotals &t,
     ((out[Js] = obs_val<NI, BASE + Js>(e, t)), ...);
 }
 
+// (stored as the dwords they are read back as: float stores that are only ever read through the tile's uint32_t pointer are, by the
+// type-based aliasing rules, dead to the compiler — it dropped whole chunks of them)
 template <int NI, int BASE, int... Js>
-__device__ __forceinline__ void stage_chunk(const Env<NI> &e, const ObsTotals &t, float *row, std::integer_sequence<int, Js...>) {
-    ((row[Js] = obs_val<NI, BASE + Js>(e, t)), ...);
+__device__ __forceinline__ void stage_chunk(const Env<NI> &e, const ObsTotals &t, uint32_t *row, std::integer_sequence<int, Js...>) {
+    ((row[Js] = __float_as_uint(obs_val<NI, BASE + Js>(e, t))), ...);
 }
 
 // OWN rows: chunk C of 32 values (or the last OBS % 32) straight from registers
@@ -341,7 +343,7 @@ __device__ __forceinline__ void staged_chunks(const Env<NI> &e, const ObsTotals 
     using L = Lay<NI>;
     if constexpr (C < L::NCH) {
         const uint32_t lane = threadIdx.x & 63u;
-        float *row = reinterpret_cast<float *>(tile) + lane * L::ROW;
+        uint32_t *row = tile + lane * L::ROW;
         stage_chunk<NI, C * L::CW>(e, t, row, std::make_integer_sequence<int, L::CW>{});
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         {

@@ -131,6 +131,7 @@ def _declare(L):
     L.orc_climate_rollout.argtypes = [vp, i32, u64, i64, i64, vp, vp, vp]
     L.orc_climate_info.argtypes = [vp, i32, vp]
     L.orc_climate_hash_action.argtypes = [u64, u64, u64, vp, vp]
+    L.orc_climate_set_max_occupancy.argtypes = [vp, i32]
 
     L.orc_fleet_create.argtypes = [i64, i32]; L.orc_fleet_create.restype = vp
     L.orc_fleet_destroy.argtypes = [vp]
@@ -539,8 +540,14 @@ CLIMATE_INFO = {"room_temp": 0, "outside_temp": 1, "ac_setting": 2, "energy_usag
 
 
 class ClimateOracle(_SimpleOracle):
-    """Batch of independent SmartClimateEnv restatements (oracle/orc_climate.c)."""
+    """Batch of independent SmartClimateEnv restatements (oracle/orc_climate.c).  max_occupancy / episode_minutes (= max_steps) are the
+    reference constructor's arguments (smartclimate/env.py:16-28)."""
     _name, _obs = "climate", CLIMATE_OBS
+
+    def __init__(self, n, mode=SAME_STEP, max_steps=None, max_occupancy=None):
+        super().__init__(n, mode, max_steps)
+        if max_occupancy is not None:
+            lib().orc_climate_set_max_occupancy(self.h, int(max_occupancy))
 
     def step(self, ac_temp, lights, want_final=False):
         ac = np.ascontiguousarray(ac_temp, dtype=np.float32).reshape(self.n)

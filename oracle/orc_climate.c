@@ -176,6 +176,9 @@ void orc_climate_info(const orc_climate *h, int field, double *out) {
 /* Time-limit override for the short-horizon parity tests (the reference's limit is a constructor constant /
  * config value; the device ABI takes it in its config struct).  Call before reset(). */
 void orc_climate_set_max_steps(orc_climate *h, int v) { h->episode_minutes = v; }
+/* SmartClimateEnv(max_occupancy=...) (env.py:18,26): bounds the reset draw integers(0, max_occupancy + 1) (:50) and the clip in
+ * update_occupancy (utils.py:21).  Call right after create. */
+void orc_climate_set_max_occupancy(orc_climate *h, int v) { h->max_occupancy = v; }
 
 /* return and length of each env's last finished episode (orc_epstats.h) */
 void orc_climate_episode_stats(const orc_climate *h, double *ret, int32_t *len) { eps_get(&h->eps, h->n, ret, len); }

@@ -4,7 +4,8 @@ smartclimate_rl-main/smartclimate/{env,utils}.py (unmodified, imported from /roo
 Protocol (SURVEY.md 8c KAT-K1 / 8d config 5): env i = SmartClimateEnv(seed=S+i) then reset(seed=S+i) (a private
 np.random.default_rng, env.py:30,63-65); auto-reset = reset() with no seed (generator continues).  Actions from the
 counter hash: ac_temp = float32(16 + 16*u24) with u24 = hash(.., j=0) >> 40, lights[k] = hash(.., n=2, j=1+k).
-Outputs: tests/golden/climate_hash.npz, climate_kat.json
+Outputs: tests/golden/climate_hash.npz, climate_kat.json, and climate_small.npz: the reference constructed with
+max_occupancy=3, episode_minutes=300 (the constructor arguments of smartclimate/env.py:16-28 that reach the dynamics).
 """
 import json
 import logging
@@ -26,8 +27,8 @@ def hash_act(a_seed, i, t):
     return ac, lights
 
 
-def run_env(seed, T, a_seed, i, extreme):
-    env = SmartClimateEnv(seed=seed, log_level=logging.ERROR)
+def run_env(seed, T, a_seed, i, extreme, ctor=None):
+    env = SmartClimateEnv(seed=seed, log_level=logging.ERROR, **(ctor or {}))
     obs, _ = env.reset(seed=seed)
     obs0 = obs.copy()
     O = np.zeros((T, 9), np.float32); R = np.zeros(T, np.float64); TE = np.zeros(T, np.uint8)
@@ -47,8 +48,8 @@ def run_env(seed, T, a_seed, i, extreme):
     return obs0, AC, LI, O, R, TE, S, resets
 
 
-def make(name, n_envs, T, seed0, a_seed, extreme):
-    rows = [run_env(seed0 + i, T, a_seed, i, extreme) for i in range(n_envs)]
+def make(name, n_envs, T, seed0, a_seed, extreme, ctor=None):
+    rows = [run_env(seed0 + i, T, a_seed, i, extreme, ctor) for i in range(n_envs)]
     ridx, robs = [], []
     for i, r in enumerate(rows):
         for t, ob in r[7]:
@@ -60,7 +61,7 @@ def make(name, n_envs, T, seed0, a_seed, extreme):
         obs=np.stack([r[3] for r in rows]), reward=np.stack([r[4] for r in rows]), terminated=np.stack([r[5] for r in rows]),
         state=np.stack([r[6] for r in rows]),
         reset_index=np.array(ridx, np.int32).reshape(-1, 2), reset_obs=np.array(robs, np.float32).reshape(-1, 9),
-        versions=np.array(json.dumps(common.versions())))
+        versions=np.array(json.dumps(common.versions())), **({"ctor": np.array(json.dumps(ctor))} if ctor else {}))
     R = np.stack([r[4] for r in rows])
     print(name, "episodes", len(ridx), "sum reward", R.sum(), os.path.getsize(out), "bytes")
 
@@ -91,3 +92,4 @@ if __name__ == "__main__":
     logging.disable(logging.CRITICAL)
     kat_k1()
     make("climate_hash", 8, 3000, seed0=600, a_seed=123, extreme=True)
+    make("climate_small", 6, 1000, seed0=700, a_seed=41, extreme=True, ctor=dict(max_occupancy=3, episode_minutes=300))

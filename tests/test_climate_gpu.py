@@ -4,6 +4,8 @@ Float-state env (BASELINE north_star: "within a stated fp32 tolerance"): obs |d|
 |d| <= 1e-4 + 1e-6|x| — the device can differ from the CPU only in the last place of log1p/exp inside the
 ziggurat's wedge/tail (1.5 % of normals); the fraction of bit-identical obs values is reported and must stay
 > 0.9999.  Discrete quantities (people, lights, step, flags) are exact."""
+import json
+
 import numpy as np
 import pytest
 import torch
@@ -29,11 +31,14 @@ def _close(a, b, atol, rtol=1e-6):
     return np.abs(a.astype(np.float64) - b.astype(np.float64)) <= atol + rtol * np.abs(b.astype(np.float64))
 
 
-def test_same_step_matches_reference_fixture(cge):
-    fx = golden("climate_hash.npz")
+# climate_small: the reference constructed with max_occupancy=3, episode_minutes=300 (smartclimate/env.py:16-28)
+@pytest.mark.parametrize("name", ["climate_hash.npz", "climate_small.npz"])
+def test_same_step_matches_reference_fixture(cge, name):
+    fx = golden(name)
     AC, LI = fx["ac_temp"], fx["lights"]
     n, T = AC.shape
-    env = cge.ClimateVectorEnv(n, autoreset_mode="SameStep")
+    ctor = json.loads(str(fx["ctor"])) if "ctor" in fx else {}
+    env = cge.ClimateVectorEnv(n, autoreset_mode="SameStep", **ctor)
     obs, _ = env.reset(seed=int(fx["seed0"]))
     assert _close(_np(obs), fx["obs0"], 1e-6).all()
     reset_at = {(int(i), int(t)): k for k, (i, t) in enumerate(fx["reset_index"])}
@@ -77,6 +82,35 @@ def test_step_matches_oracle_all_modes(cge, oracle, mode):
     for f in ["room_temp", "outside_temp", "energy_usage", "total_reward"]:
         assert np.allclose(_np(env.info(f)), o.info(f), rtol=1e-10, atol=1e-9), f
     env.close()
+
+
+@pytest.mark.parametrize("max_occupancy,minutes", [(1, 77), (15, 200)])
+def test_constructor_knobs_match_oracle(cge, oracle, max_occupancy, minutes):
+    """max_occupancy / episode_minutes (smartclimate/env.py:16-28) against the oracle built with the same values: step() through
+    several episodes, then the fused rollout; occupancy reaches its bound."""
+    n = 300
+    env = cge.ClimateVectorEnv(n, autoreset_mode="SameStep", env_index0=2, max_occupancy=max_occupancy, episode_minutes=minutes)
+    o = oracle.ClimateOracle(n, oracle.SAME_STEP, max_steps=minutes, max_occupancy=max_occupancy)
+    o.seed(np.arange(n, dtype=np.uint64) + np.uint64(2 + 19))
+    od, _ = env.reset(seed=19)
+    assert _close(_np(od), o.reset(), 1e-6).all()
+    rng = np.random.default_rng(3)
+    top = 0
+    for t in range(2 * minutes + 5):
+        ac = rng.uniform(10, 38, (n, 1)).astype(np.float32)
+        li = rng.integers(0, 2, (n, 4)).astype(np.int8)
+        od, rd, ted, _, _ = env.step((ac, li))
+        oo, ro, teo, _ = o.step(ac, li)
+        assert _close(_np(od), oo, 1e-6).all() and np.array_equal(_np(od)[:, 1], oo[:, 1]), t
+        assert _close(_np(rd), ro, 1e-4).all() and np.array_equal(_np(ted), teo.astype(bool)), t
+        top = max(top, int(oo[:, 1].max()))
+    assert top == max_occupancy and int(o.info("episodes").min()) == 2
+    obs, rs, dc = env.rollout(150, action_seed=4, t0=1)
+    oo, ro, do = o.rollout(150, 4, t0=1, env0=2)
+    assert _close(_np(obs), oo, 1e-6).all() and np.array_equal(_np(dc), do) and np.allclose(_np(rs), ro, rtol=1e-9, atol=1e-6)
+    env.close()
+    with pytest.raises(Exception):
+        cge.ClimateVectorEnv(4, max_occupancy=16)                        # the record keeps num_people in 4 bits: refused, not wrapped
 
 
 def test_rollout_config5_size_and_sharding(cge, oracle):

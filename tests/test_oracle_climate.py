@@ -1,17 +1,22 @@
 """Pins oracle/orc_climate.c against golden vectors produced by running the reference's own smartclimate
 package (tests/golden/gen/gen_climate.py): float32 obs bit-for-bit, float64 rewards/state bit-for-bit."""
 import hashlib
+import json
 
 import numpy as np
+import pytest
 
 from conftest import golden
 
 
-def test_same_step_matches_reference_bitwise(oracle):
-    fx = golden("climate_hash.npz")
+# climate_small: the reference constructed with max_occupancy=3, episode_minutes=300 (smartclimate/env.py:16-28)
+@pytest.mark.parametrize("name", ["climate_hash.npz", "climate_small.npz"])
+def test_same_step_matches_reference_bitwise(oracle, name):
+    fx = golden(name)
     AC, LI = fx["ac_temp"], fx["lights"]
     n, T = AC.shape
-    o = oracle.ClimateOracle(n, oracle.SAME_STEP)
+    ctor = json.loads(str(fx["ctor"])) if "ctor" in fx else {}
+    o = oracle.ClimateOracle(n, oracle.SAME_STEP, max_steps=ctor.get("episode_minutes"), max_occupancy=ctor.get("max_occupancy"))
     o.seed(np.arange(n, dtype=np.uint64) + np.uint64(int(fx["seed0"])))
     assert np.array_equal(o.reset().view(np.uint32), fx["obs0"].view(np.uint32))
     reset_at = {(int(i), int(t)): k for k, (i, t) in enumerate(fx["reset_index"])}
@@ -29,7 +34,9 @@ def test_same_step_matches_reference_bitwise(oracle):
         assert np.array_equal(o.info("room_temp")[live], S[live, 0]) and np.array_equal(o.info("outside_temp")[live], S[live, 1])
         assert np.array_equal(o.info("energy_usage")[live], S[live, 2]) and np.array_equal(o.info("comfort_time")[live], S[live, 3])
         assert np.array_equal(o.info("total_reward")[live], S[live, 4])
-    assert len(reset_at) == 2 * n
+    assert len(reset_at) == int(fx["terminated"].sum()) >= 2 * n
+    if ctor:
+        assert fx["obs"][:, :, 1].max() == ctor["max_occupancy"]          # the occupancy clip is reached
 
 
 def test_kat_k1(oracle):
