@@ -51,3 +51,39 @@ def test_without_a_gpu_the_real_path_refuses_loudly():
     import torch
     if torch.cuda.device_count() == 0:
         assert p.returncode != 0 and "no CPU path" in (p.stderr + p.stdout)
+
+
+def _check_split(p, n):
+    """placement A of BASELINE config 5: the eight env types dealt round-robin over the ranks, total work fixed -> strong scaling"""
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == n and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "strong"
+    assert out["unit"] == "env-steps/s" and out["value"] > 0 and "DRY RUN" in out["data"]
+    assert out["config"]["workload"].startswith("hetero_split_131k")
+    # rank 0 holds types 0, n, 2n, ... of the sorted type list
+    types = sorted(["snake", "crypto", "traffic", "parking", "climate", "fleet", "manufacturing", "hospital"])
+    assert out["config"]["env_types"] == types[0::n]
+    return out
+
+
+def test_hetero_split_one_type_per_rank_at_8():
+    p = _run([sys.executable, "bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1", "--workload", "hetero_split_131k"],
+             {"CGE_BENCH_DRYRUN": "1", "OMP_NUM_THREADS": "1"})
+    _check_split(p, 8)
+
+
+def test_hetero_split_uneven_dealing_at_3():
+    """8 types over 3 ranks: ranks hold 3, 3 and 2 types — a rank with fewer types must still meet every barrier"""
+    p = _run([sys.executable, "bench.py", "--gpus", "3", "--steps", "3", "--warmup", "1", "--workload", "hetero_split_131k"],
+             {"CGE_BENCH_DRYRUN": "1", "OMP_NUM_THREADS": "1"})
+    _check_split(p, 3)
+
+
+def test_hetero_coresident_weak_scaling_at_2():
+    p = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "hetero_131k"],
+             {"CGE_BENCH_DRYRUN": "1", "OMP_NUM_THREADS": "1"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["scaling"] == "weak" and out["n_gpus"] == 2 and len(out["config"]["env_types"]) == 8
