@@ -70,7 +70,11 @@ WORKLOADS = {
     "snake_1m": dict(env="snake", n=1 << 20, desc="SnakeEnv 10x10, 1,048,576 parallel envs per GPU, random actions, fused auto-reset"),
     "snake_64k": dict(env="snake", n=1 << 16, desc="SnakeEnv 10x10, 65,536 envs per GPU (quick check)"),
     "crypto_1m": dict(env="crypto", n=1 << 20, desc="crypto_trading_env discrete, 1,048,576 parallel envs per GPU"),
-    "traffic_262k": dict(env="traffic", n=1 << 18, desc="traffic_management_env (9 intersections), 262,144 parallel envs per GPU"),
+    # episode_start: every env is re-seeded and reset right before each timed region, so the K timed steps are steps 1..K of an
+    # episode — the spawn phase (the RNG-heavy one: the reference stops spawning at 50 vehicles, ~step 200) is inside the window,
+    # and --steps 1000 times exactly one whole episode
+    "traffic_262k": dict(env="traffic", n=1 << 18, episode_start=True,
+                         desc="traffic_management_env (9 intersections), 262,144 parallel envs per GPU, timed from the start of an episode"),
     "parking_131k": dict(env="parking", n=1 << 17, desc="smart_parking_env, 131,072 parallel envs per GPU"),
     "climate_131k": dict(env="climate", n=1 << 17, desc="smartclimate, 131,072 parallel envs per GPU"),
     "fleet_131k": dict(env="fleet", n=1 << 17, desc="fleet_management_env, 131,072 parallel envs per GPU"),
@@ -432,13 +436,20 @@ def main():
         count(nm, "rollout", min(kc[nm], K))
     sync()
     run_rollout(max(W, 1), K)                                        # W untimed warm-up steps
-    results["rollout"] = timed(lambda: run_rollout(K, K + max(W, 1)), "rollout")
+
+    def restart_episodes():
+        if wl.get("episode_start"):
+            for e in envs.values():
+                e.reset(seed=0)
+    restart_episodes()
+    results["rollout"] = timed(lambda: run_rollout(K, 0 if wl.get("episode_start") else K + max(W, 1)), "rollout")
     if not dry:
         for e in envs.values():                                      # the trajectory buffers are not needed by the API leg
             e._bufs.pop("traj", None)
         torch.cuda.empty_cache()
     actions = {nm: (None if dry else make_actions(nm, K + W, n, dev)) for nm in names}  # API path: K step() calls, HBM-resident actions
     run_steps(actions, 0, W)
+    restart_episodes()
     results["step"] = timed(lambda: run_steps(actions, W, W + K), "step")
     if "snake" in envs:
         assert envs["snake"].invalid_action_count() == 0
@@ -485,7 +496,9 @@ def main():
                                  f"fused rollout: {kc[names[0]]} steps per launch, every step's obs / reward / flag written to its own slot of a "
                                  f"[{kc[names[0]]}, N, ...] trajectory in HBM, device-side action hash")
                                 if head == "rollout" else "K C-ABI step() calls through the VectorEnv facade, HBM-resident actions"),
-                       "autoreset": "SameStep", "parallelism": f"env-sharded x{world}, no data-path collective"},
+                       "autoreset": "SameStep", "parallelism": f"env-sharded x{world}, no data-path collective",
+                       "episode_phase": (f"steps 1..{K} of an episode (envs reset right before the timed region)" if wl.get("episode_start")
+                                         else f"steady state: the timed region starts {K + max(W, 1) + min(kc[names[0]], K)} steps after reset")},
             "roofline": hb["roofline"] if len(names) == 1 else hb["roofline"].get("snake", hb["roofline"][names[0]]),
         }
         if dry:

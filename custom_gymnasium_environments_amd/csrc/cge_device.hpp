@@ -64,9 +64,13 @@ __device__ __forceinline__ void mt_load_run(const uint32_t *__restrict__ src, ui
 // The stream cursor lives in the ENV's state record, not in the block, so a draw never starts with a
 // dependent "load the cursor" round trip:
 //   pos    next word index, 0..623
-//   pretw  words in [pos, pretw) are already twisted (a CPython state imported by set_state); 0 or 624
-// Words are twisted one at a time, in place, exactly when they are consumed (incremental form of
-// the reference generator's 624-word batch regeneration; identical output sequence).
+//   pretw  words in [pos, pretw) are already twisted ("ready"): 0 (nothing), 624 (a CPython state imported by set_state: the whole
+//          generation), or — streams advanced by mt_make_ready() below — a multiple of 32 up to 624 + 32, where the part beyond 624
+//          means words [0, pretw - 624) of the NEXT generation
+// Words are twisted in place (incremental form of the reference generator's 624-word batch regeneration; identical output
+// sequence): one at a time exactly when they are consumed (MtStream, MtWindow, the LDS queues), or a 32-word chunk at a time
+// AHEAD of the cursor (mt_make_ready) so that the draws themselves are plain loads and nothing is written back per draw.
+__host__ __device__ __forceinline__ uint32_t mt_wrap_ready(uint32_t pretw) { return pretw > (uint32_t)MT_N ? pretw - (uint32_t)MT_N : 0u; }   // the cursor wrapped into the next generation
 
 __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
     y ^= y >> 11;
@@ -78,6 +82,78 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
 __device__ __forceinline__ uint32_t mt_twist(uint32_t a, uint32_t b, uint32_t c) {
     const uint32_t t = (a & 0x80000000u) | (b & 0x7fffffffu);
     return c ^ (t >> 1) ^ ((t & 1u) ? 0x9908b0dfu : 0u);
+}
+
+// ------------------------------------------------------------------ twist-ahead chunks
+// A draw that twists its own words costs a window of w[pos..], a window of w[pos+397..] and a write-back of the consumed words —
+// for crypto's 10-word step window that is 3-4 scattered 128-byte lines fetched and a 40-byte PARTIAL-line write per env, stream
+// and step (round 2: after a block's first wrap these commits alone cost step() ~150 us per 1M envs, and the generator traffic
+// was the whole gap between obliged and moved bytes).  Twisting a 32-word chunk (one 128-byte line) at a time ahead of the cursor
+// turns that into one full-line write per ~3 steps, and the per-step draw into a plain load of ready words.
+//   pretw codes: a multiple of 32, 624, or 624 + 32; stored in 5 bits as mt_ready_encode(pretw).
+constexpr int MT_CHUNK = 32;
+__host__ __device__ __forceinline__ uint32_t mt_ready_decode(uint32_t q) { return q <= 19u ? 32u * q : (uint32_t)MT_N + 32u * (q - 20u); }   // q in 0..21
+__host__ __device__ __forceinline__ uint32_t mt_ready_encode(uint32_t pretw) { return pretw < (uint32_t)MT_N ? pretw / 32u : 20u + (pretw - (uint32_t)MT_N) / 32u; }
+// Twists, in place, the words from `lo` (unwrapped: >= 624 means word lo - 624 of the next generation) to the end of lo's 32-word
+// chunk, for the lanes with `go`; words of the chunk below lo keep their (already twisted) values.  Returns the new ready mark.
+// One lane = one block: 17 sixteen-byte loads (the chunk + 1 word, and the words 397 ahead — the piece that straddles word 623
+// runs into mirror word 624 = word 0, exactly the word it needs), 8 stores of the whole line (+4 for the mirror of words 0..15).
+__device__ __forceinline__ uint32_t mt_twist_chunk(uint32_t *__restrict__ blk, uint32_t lo, bool go) {
+    const uint32_t gen = lo >= (uint32_t)MT_N ? (uint32_t)MT_N : 0u, base = lo - gen, c0 = base & ~31u;
+    const uint32_t len = (uint32_t)MT_N - c0 < 32u ? (uint32_t)MT_N - c0 : 32u;   // the last chunk holds 16 words
+    if (go) {
+        uint32_t a[MT_CHUNK + 1], c[MT_CHUNK];
+#pragma unroll
+        for (int q = 0; q < MT_CHUNK; q += 4) {
+            if ((uint32_t)q < len) {
+                const MtQuad v = *reinterpret_cast<const MtQuad *>(blk + c0 + q);
+                a[q] = v.a; a[q + 1] = v.b; a[q + 2] = v.c; a[q + 3] = v.d;
+                uint32_t ci = c0 + (uint32_t)q + MT_M;                        // == 1 mod 4: 621 is the only piece that touches the mirror
+                ci -= ci > (uint32_t)MT_N ? MT_N : 0;
+                const MtQuad w = *reinterpret_cast<const MtQuad *>(blk + ci);
+                c[q] = w.a; c[q + 1] = w.b; c[q + 2] = w.c; c[q + 3] = w.d;
+            }
+        }
+        a[MT_CHUNK] = 0;
+        const uint32_t nxt = blk[c0 + len];                                    // word c0 + len <= 624 (mirror of word 0)
+#pragma unroll
+        for (int j = 0; j < MT_CHUNK; ++j) {
+            if ((uint32_t)j < len) {
+                const uint32_t b = (uint32_t)(j + 1) < len ? a[j + 1] : nxt;
+                const uint32_t y = mt_twist(a[j], b, c[j]);
+                a[j] = c0 + (uint32_t)j < base ? a[j] : y;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < MT_CHUNK; q += 4) {
+            if ((uint32_t)q < len) {
+                *reinterpret_cast<MtQuad *>(blk + c0 + q) = MtQuad{a[q], a[q + 1], a[q + 2], a[q + 3]};
+                if (c0 == 0u && q < MT_PAD) *reinterpret_cast<MtQuad *>(blk + MT_N + q) = MtQuad{a[q], a[q + 1], a[q + 2], a[q + 3]};
+            }
+        }
+    }
+    return gen + c0 + len;
+}
+// Makes words [pos, pos + need) ready (need <= 32; pos < 624).  Wave-convergent: as long as any lane of the wave is short, the
+// short lanes twist their next chunk (one or two rounds); call it with all lanes of the wave.
+__device__ __forceinline__ void mt_make_ready(uint32_t *__restrict__ blk, uint32_t pos, uint32_t &pretw, uint32_t need, bool active = true) {
+#pragma unroll 1
+    while (__ballot(active && pos + need > pretw)) {
+        const bool go = active && pos + need > pretw;
+        const uint32_t t = mt_twist_chunk(blk, pretw > pos ? pretw : pos, go);
+        if (go) pretw = t;
+    }
+}
+// W ready words from the cursor on (after mt_make_ready): tempered; words past 623 come from the mirror
+template <int W>
+__device__ __forceinline__ void mt_load_ready(const uint32_t *__restrict__ blk, uint32_t pos, uint32_t (&w)[W]) {
+    static_assert(W <= MT_PAD, "the run may extend into the 16 mirror words");
+    mt_load_run<W>(blk + pos, w);
+}
+__device__ __forceinline__ void mt_advance(uint32_t &pos, uint32_t &pretw, uint32_t used) {
+    uint32_t p = pos + used;
+    if (p >= (uint32_t)MT_N) { p -= MT_N; pretw = mt_wrap_ready(pretw); }
+    pos = p;
 }
 
 // Serial stream: one memory round trip per draw (3 independent loads + 1 store).  For rare/long paths.
@@ -98,7 +174,7 @@ struct MtStream {
             mt_store(w, p, y);
         }
         ++p;
-        if (p == MT_N) { p = 0; pretw = 0; }
+        if (p == MT_N) { p = 0; pretw = mt_wrap_ready(pretw); }
         pos = p;
         return mt_temper(y);
     }
@@ -184,7 +260,7 @@ struct MtWindow {
             }
         }
         uint32_t p = pos + used;
-        if (p >= (uint32_t)MT_N) { p -= MT_N; pretw = 0; }
+        if (p >= (uint32_t)MT_N) { p -= MT_N; pretw = mt_wrap_ready(pretw); }
         pos = p;
     }
 };
@@ -288,7 +364,7 @@ struct LdsDraws {
             }
         }
         uint32_t p = pos + cur;
-        if (p >= (uint32_t)MT_N) { p -= MT_N; pretw = 0; }
+        if (p >= (uint32_t)MT_N) { p -= MT_N; pretw = mt_wrap_ready(pretw); }
         pos = p;
         cur = 0;
         filled = false;
@@ -444,7 +520,7 @@ struct LdsBulkDraws {
             }
         }
         uint32_t p = pos + cur;
-        if (p >= (uint32_t)MT_N) { p -= MT_N; pretw = 0; }
+        if (p >= (uint32_t)MT_N) { p -= MT_N; pretw = mt_wrap_ready(pretw); }
         pos = p;
         cur = 0;
         filled = false;
@@ -527,7 +603,7 @@ struct RingDraws {
     }
     __device__ __forceinline__ void advance(uint32_t n) {
         pos += n;
-        if (pos >= (uint32_t)MT_N) { pos -= MT_N; pretw = 0; }
+        if (pos >= (uint32_t)MT_N) { pos -= MT_N; pretw = mt_wrap_ready(pretw); }
     }
     // NB runs per round trip: loads of all of them first, then twist and park
     template <int NB>
@@ -711,7 +787,7 @@ __device__ __forceinline__ void coop_flush(LdsBulkDraws<W> &d, int row_stride) {
     }
     if (d.filled) {
         uint32_t p = d.pos + d.cur;
-        if (p >= (uint32_t)MT_N) { p -= MT_N; d.pretw = 0; }
+        if (p >= (uint32_t)MT_N) { p -= MT_N; d.pretw = mt_wrap_ready(d.pretw); }
         d.pos = p; d.cur = 0; d.filled = false;
     }
 }

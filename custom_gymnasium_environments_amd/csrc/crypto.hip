@@ -19,11 +19,11 @@
 // appends exactly one candle; a reset rewrites all 50 slots and adopts the batch phase), so slot
 // indices are wave-uniform and every history access is a coalesced 8- or 16-byte-per-lane stream.
 // Dominant traffic per env-step: 1200 B history read + 1044 B obs write (+ 24 B new candle, 128 B
-// scalars, RNG windows) — HBM-bound, no reuse, no MFMA-shaped work.
+// scalars, RNG words) — HBM-bound, no reuse, no MFMA-shaped work.
 //
-// The (N,261) float32 obs is a per-env scaled transpose of the SoA history: each wave stages 10
-// candles x 64 envs in LDS (row stride 51 dwords -> conflict-free) and streams the 200-byte row
-// segments out with fully used 256-byte store instructions.
+// Kernels: resident_kernel (step() and the fused rollout: four waves over 64 envs whose 50-candle window lives in LDS, see below),
+// reset_kernel, init_kernel, info_kernel.  Generator words are twisted a 32-word chunk at a time AHEAD of the cursors
+// (cge_device.hpp: mt_make_ready), so a step's draws are plain loads of ready words and nothing is written back per draw.
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -39,8 +39,9 @@ constexpr int HLEN = 50;
 constexpr int OBS = 261;
 constexpr int CH = 12;            // candles per chunk: 60 floats = 15 sixteen-byte stores per row
 constexpr int ROW = CH * 5 + 1;   // LDS row stride (dwords), odd
-constexpr int WP = 10;            // P window: trade slippage + volume + regime test + high + low = 5 doubles
-constexpr int WL = 8;             // L window: two polar-method attempts
+constexpr int WP = 10;            // P words per step: trade slippage + volume + regime test + high + low = 5 doubles
+constexpr int WL = 8;             // L words per gaussian pair: two polar-method attempts
+constexpr int MAX_STEPS_LIMIT = 16383;   // `step` has 14 bits in the record
 constexpr int BLOCK = 64;
 enum { BULL = 0, BEAR = 1, SIDEWAYS = 2, CRASH = 3, RECOVERY = 4 };
 
@@ -71,39 +72,53 @@ struct Params {
     int32_t *ep_len;
 };
 
-__device__ __forceinline__ double mk_double(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
+__host__ __device__ __forceinline__ double mk_double(uint32_t lo, uint32_t hi) { const uint64_t u = ((uint64_t)hi << 32) | lo; double x; memcpy(&x, &u, 8); return x; }
+__host__ __device__ __forceinline__ uint32_t lo32(double x) { uint64_t u; memcpy(&u, &x, 8); return (uint32_t)u; }
+__host__ __device__ __forceinline__ uint32_t hi32(double x) { uint64_t u; memcpy(&u, &x, 8); return (uint32_t)(u >> 32); }
 __device__ __forceinline__ double u53(uint32_t a, uint32_t b) { return ((a >> 5) * 67108864.0 + (b >> 6)) / 9007199254740992.0; }
 __device__ __forceinline__ double clipd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
+// record: four uint4 (column c of env i at scal[c*n + i])
+//   a: cash | holdings     b: close | psych     c: trend | cached gaussian
+//   d.x: step:14 | regime:3 @14 | has_gauss @17 | cash_kind:2 @18 | needs_reset @20 | episodes[10:0] @21
+//   d.y: ppos:10 | P ready mark:5 @10 | lpos:10 @15 | L ready mark:5 @25 | episodes[12:11] @30      d.zw: episode return (float64)
+// ready mark: words [pos, pretw) of the stream are already twisted; 5-bit code of cge_device.hpp (mt_ready_encode)
 struct Env {
     double cash, holdings, close, psych, trend, gauss;
     double ep_return;                      // float64 sum of the running episode's rewards, step order
-    uint32_t step, regime, has_gauss, cash_kind, needs_reset, episodes;   // episodes: 19 bits (saturates at 524,287)
+    uint32_t step, regime, has_gauss, cash_kind, needs_reset, episodes;   // episodes: 13 bits (saturates at 8,191)
     uint32_t ppos, ppretw, lpos, lpretw;
+    static constexpr uint32_t MAX_EPISODES = 0x1FFFu;
 
-    __device__ __forceinline__ void load(const uint4 *__restrict__ s, int64_t n, int64_t i) {
-        const uint4 a = s[i], b = s[n + i], c = s[2 * n + i], d = s[3 * n + i];
+    __host__ __device__ __forceinline__ void unpack(const uint4 &a, const uint4 &b, const uint4 &c, const uint4 &d) {
         cash = mk_double(a.x, a.y); holdings = mk_double(a.z, a.w);
         close = mk_double(b.x, b.y); psych = mk_double(b.z, b.w);
         trend = mk_double(c.x, c.y); gauss = mk_double(c.z, c.w);
-        step = d.x & 0xffffu; regime = (d.x >> 16) & 7u; has_gauss = (d.x >> 19) & 1u;
-        cash_kind = (d.x >> 20) & 3u; needs_reset = (d.x >> 22) & 1u;
-        ppos = d.y & 1023u; ppretw = (d.y & 1024u) ? (uint32_t)MT_N : 0u;
-        lpos = (d.y >> 11) & 1023u; lpretw = (d.y & (1u << 21)) ? (uint32_t)MT_N : 0u;
-        episodes = (d.x >> 23) | ((d.y >> 22) << 9);
+        step = d.x & 0x3fffu; regime = (d.x >> 14) & 7u; has_gauss = (d.x >> 17) & 1u;
+        cash_kind = (d.x >> 18) & 3u; needs_reset = (d.x >> 20) & 1u;
+        ppos = d.y & 1023u; ppretw = mt_ready_decode((d.y >> 10) & 31u);
+        lpos = (d.y >> 15) & 1023u; lpretw = mt_ready_decode((d.y >> 25) & 31u);
+        episodes = (d.x >> 21) | ((d.y >> 30) << 11);
         ep_return = mk_double(d.z, d.w);
     }
+    __host__ __device__ __forceinline__ void pack(uint4 &a, uint4 &b, uint4 &c, uint4 &d) const {
+        a = make_uint4(lo32(cash), hi32(cash), lo32(holdings), hi32(holdings));
+        b = make_uint4(lo32(close), hi32(close), lo32(psych), hi32(psych));
+        c = make_uint4(lo32(trend), hi32(trend), lo32(gauss), hi32(gauss));
+        const uint32_t ep = episodes < MAX_EPISODES ? episodes : MAX_EPISODES;
+        // a ready mark at or below the cursor means "nothing ready": 0 says the same and always fits the code
+        const uint32_t pq = ppretw > ppos ? mt_ready_encode(ppretw) : 0u, lq = lpretw > lpos ? mt_ready_encode(lpretw) : 0u;
+        d = make_uint4(step | (regime << 14) | (has_gauss << 17) | (cash_kind << 18) | (needs_reset << 20) | ((ep & 2047u) << 21),
+                       ppos | (pq << 10) | (lpos << 15) | (lq << 25) | ((ep >> 11) << 30), lo32(ep_return), hi32(ep_return));
+    }
+    __device__ __forceinline__ void load(const uint4 *__restrict__ s, int64_t n, int64_t i) {
+        const uint4 a = s[i], b = s[n + i], c = s[2 * n + i], d = s[3 * n + i];
+        unpack(a, b, c, d);
+    }
     __device__ __forceinline__ void store(uint4 *__restrict__ s, int64_t n, int64_t i) const {
-        s[i] = make_uint4((uint32_t)__double2loint(cash), (uint32_t)__double2hiint(cash),
-                          (uint32_t)__double2loint(holdings), (uint32_t)__double2hiint(holdings));
-        s[n + i] = make_uint4((uint32_t)__double2loint(close), (uint32_t)__double2hiint(close),
-                              (uint32_t)__double2loint(psych), (uint32_t)__double2hiint(psych));
-        s[2 * n + i] = make_uint4((uint32_t)__double2loint(trend), (uint32_t)__double2hiint(trend),
-                                  (uint32_t)__double2loint(gauss), (uint32_t)__double2hiint(gauss));
-        const uint32_t ep = episodes < 0x7FFFFu ? episodes : 0x7FFFFu;
-        s[3 * n + i] = make_uint4(step | (regime << 16) | (has_gauss << 19) | (cash_kind << 20) | (needs_reset << 22) | ((ep & 511u) << 23),
-                                  ppos | (ppretw ? 1024u : 0u) | (lpos << 11) | (lpretw ? (1u << 21) : 0u) | ((ep >> 9) << 22),
-                                  (uint32_t)__double2loint(ep_return), (uint32_t)__double2hiint(ep_return));
+        uint4 a, b, c, d;
+        pack(a, b, c, d);
+        s[i] = a; s[n + i] = b; s[2 * n + i] = c; s[3 * n + i] = d;
     }
 };
 
@@ -167,14 +182,8 @@ __device__ __forceinline__ double price_update(Env &e, const Cfg &c, double curr
 // Candle k of the fresh history goes to slot (phase + k) % 50: the env adopts the batch-wide ring phase.
 constexpr int RW_P = 32, RW_L = 16;
 static_assert(RW_P + RW_L <= ROW, "the reset's draw windows live in the lane's obs-tile row");
-// fused rollouts keep one window per stream parked in LDS for all k steps (env_step<true>): every 128-byte line of a generator
-// block is then fetched once per ~4 (CPython stream) / ~12 (NumPy stream) steps instead of 2-3 partial lines per step and stream
-constexpr int KW_P = 48, KW_L = 32, KROW = KW_P + KW_L + 1;
-using RollP = LdsDrawsCall<KW_P>;
-using RollL = LdsDrawsCall<KW_L>;
-
-// Where the 50-candle window lives.  HistGlobal: the [50][N] arrays in HBM (step(), the parked-window rollout).  HistLds: the
-// resident rollout's copy in LDS ([50][64] per wave, loaded once per launch), with every new candle also written through to HBM.
+// Where the 50-candle window lives.  HistGlobal: the [50][N] arrays in HBM (reset()).  HistLds: the resident kernel's copy in LDS
+// ([50][64] per workgroup, loaded once per launch), with every new candle also written through to HBM.
 struct HistGlobal {
     double *closes;
     float4 *ohlv;
@@ -265,28 +274,16 @@ __device__ __forceinline__ void sell_apply(Env &e, const Cfg &c, double qty, dou
     if (c.continuous) e.cash_kind = 2;
 }
 
-// One reference step() (:342-398) for one env; writes the new candle into slot `phase`.
-// Returns terminated; reward in float64.
-// MODE 0 (step()): two register windows loaded here and committed below.  MODE 1 (PARKED): the draws come from the rollout's
-// LDS-parked windows (dp / dl hold >= WP / WL words: ensure_inline at the top of the step).  MODE 2 (resident rollout): the register
-// windows arrive loaded — issued at the end of the previous step, ahead of that step's observation stores, so that the in-order
-// vmcnt never makes this step wait for them — and the next step's are issued before returning.
-constexpr int M_STEP = 0, M_PARKED = 1, M_RESIDENT = 2, M_SPLIT = 3;
-// M_SPLIT (resident rollout, wave A): env_step stops after the P-stream section — trade, volume, regime, the high / low uniforms, P
-// commit and the prefetch of the next P window — and hands these out; the step is completed by finish_step() once the gaussian
-// (drawn by another wave) is there.
+// One reference step() (:342-398) is split between the waves of the resident kernel.  market_step() is the first half, wave A's: the
+// trade (_execute_action :400-447) and the CPython-stream draws of the step — [slippage] volume regime-test high low, 4-5 doubles =
+// 8-10 words, handed in as `pw`: the WP READY words at the stream's cursor (mt_make_ready + a plain load, issued at the end of the
+// previous step).  The 1 % regime switch continues draw by draw (MtStream).  finish_step() completes the step once the gaussian
+// (drawn by wave B) is there.
 struct SplitOut { double price, volume, u_hi, u_lo; };
-template <int MODE, class H>
-__device__ __forceinline__ bool env_step(Env &e, const Params &p, int64_t i, H &hist, int phase, int32_t a_disc, float a_buy, float a_sell,
-                                         double &reward, RollP &dp, RollL &dl, MtWindow<WP> &wp, MtWindow<WL> &wl, SplitOut *so = nullptr) {
-    constexpr bool PARKED = MODE == M_PARKED;
+__device__ __forceinline__ void market_step(Env &e, const Params &p, int64_t i, int32_t a_disc, float a_buy, float a_sell,
+                                            double &reward, const uint32_t (&pw)[WP], SplitOut &so) {
     const Cfg &c = p.cfg;
     uint32_t *__restrict__ blkP = p.mtP + i * MT_STRIDE;
-    uint32_t *__restrict__ blkL = p.mtL + i * MT_STRIDE;
-    if constexpr (MODE == M_STEP) {
-        wp.load(blkP, e.ppos);
-        if (!e.has_gauss) wl.load(blkL, e.lpos);
-    }
 
     // ---- _execute_action :400-447
     const double price = e.close;
@@ -315,11 +312,10 @@ __device__ __forceinline__ bool env_step(Env &e, const Params &p, int64_t i, H &
     if (kind == 1) traded = buy_guard(e, amount, amount_f32);
     else if (kind == 2) traded = !(amount <= 0.0 || e.holdings < amount);
 
-    // ---- P draws of the common path, all from the window: [slippage] volume regime-test high low
+    // ---- P draws of the common path: [slippage] volume regime-test high low
     double U[5];
 #pragma unroll
-    for (int q = 0; q < 5; ++q)
-        U[q] = PARKED ? u53(dp.peek(2 * q), dp.peek(2 * q + 1)) : u53(wp.draw(2 * q, e.ppos, e.ppretw), wp.draw(2 * q + 1, e.ppos, e.ppretw));
+    for (int q = 0; q < 5; ++q) U[q] = u53(mt_temper(pw[2 * q]), mt_temper(pw[2 * q + 1]));
     if (traded) {
         if (kind == 1) buy_apply(e, c, amount, amount_f32, price, U[0]);
         else sell_apply(e, c, amount, price, U[0]);
@@ -330,95 +326,21 @@ __device__ __forceinline__ bool env_step(Env &e, const Params &p, int64_t i, H &
     const double volume = 0.5 + (2.0 - 0.5) * (traded ? U[1] : U[0]);     // :349
     const double ureg = traded ? U[2] : U[1];
     const uint32_t tq = traded ? 1u : 0u;
-    const bool regime_switch = ureg < 0.01;                       // :135
     double u_hi = traded ? U[3] : U[2], u_lo = traded ? U[4] : U[3];
-    if (regime_switch) {
-        // rare: consume the window up to the regime test, continue draw by draw
-        if constexpr (PARKED) {
-            dp.skip(2u * (tq + 2u));
-            update_regime(e, dp);
-            u_hi = dp.random53();
-            u_lo = dp.random53();
-        } else {
-            wp.commit(blkP, e.ppos, e.ppretw, 2u * (tq + 2u));
-            MtStream sp(blkP, e.ppos, e.ppretw);
-            update_regime(e, sp);
-            u_hi = sp.random53();
-            u_lo = sp.random53();
-            e.ppos = sp.pos; e.ppretw = sp.pretw;
-        }
+    if (ureg < 0.01) {                                            // :135 — rare: consume up to the regime test, continue draw by draw
+        mt_advance(e.ppos, e.ppretw, 2u * (tq + 2u));
+        MtStream sp(blkP, e.ppos, e.ppretw);
+        update_regime(e, sp);
+        u_hi = sp.random53();
+        u_lo = sp.random53();
+        e.ppos = sp.pos; e.ppretw = sp.pretw;
     } else {
-        if constexpr (PARKED) dp.skip(2u * (tq + 4u));
-        else wp.commit(blkP, e.ppos, e.ppretw, 2u * (tq + 4u));
+        mt_advance(e.ppos, e.ppretw, 2u * (tq + 4u));
     }
-    if constexpr (MODE == M_SPLIT) {
-        so->price = price; so->volume = volume; so->u_hi = u_hi; so->u_lo = u_lo;
-        wp.load(blkP, e.ppos);                                     // the next step's P window (its cursor is final)
-        return false;
-    }
-    // ---- gaussian (family L): cached half, or up to two polar attempts from the window, else serial
-    double g;
-    if (e.has_gauss) {
-        e.has_gauss = 0;
-        g = e.gauss;
-        e.gauss = 0.0;
-    } else {
-        uint32_t lw[WL];
-#pragma unroll
-        for (int j = 0; j < WL; ++j) lw[j] = PARKED ? dl.peek(j) : wl.draw(j, e.lpos, e.lpretw);
-        double x1 = 2.0 * u53(lw[0], lw[1]) - 1.0;
-        double x2 = 2.0 * u53(lw[2], lw[3]) - 1.0;
-        double r2 = x1 * x1 + x2 * x2;
-        uint32_t used = 4;
-        bool ok = !(r2 >= 1.0 || r2 == 0.0);
-        if (!ok) {
-            x1 = 2.0 * u53(lw[4], lw[5]) - 1.0;
-            x2 = 2.0 * u53(lw[6], lw[7]) - 1.0;
-            r2 = x1 * x1 + x2 * x2;
-            used = 8;
-            ok = !(r2 >= 1.0 || r2 == 0.0);
-        }
-        if constexpr (PARKED) {
-            dl.skip(used);
-            if (!ok) {
-                do {
-                    x1 = 2.0 * dl.random53() - 1.0;
-                    x2 = 2.0 * dl.random53() - 1.0;
-                    r2 = x1 * x1 + x2 * x2;
-                } while (r2 >= 1.0 || r2 == 0.0);
-            }
-        } else {
-            wl.commit(blkL, e.lpos, e.lpretw, used);
-            if (!ok) {
-                MtStream sl(blkL, e.lpos, e.lpretw);
-                do {
-                    x1 = 2.0 * sl.random53() - 1.0;
-                    x2 = 2.0 * sl.random53() - 1.0;
-                    r2 = x1 * x1 + x2 * x2;
-                } while (r2 >= 1.0 || r2 == 0.0);
-                e.lpos = sl.pos; e.lpretw = sl.pretw;
-            }
-        }
-        const double f = sqrt(-2.0 * log(r2) / r2);
-        e.gauss = f * x1;
-        e.has_gauss = 1;
-        g = f * x2;
-    }
-    const double np_ = price_update(e, c, price, volume, g);
-    const double hi = np_ * (1.0 + (1.02 - 1.0) * u_hi);          // :353
-    const double lo = np_ * (0.98 + (1.0 - 0.98) * u_lo);         // :354
-    hist.put(phase, np_, make_float4((float)price, (float)hi, (float)lo, (float)volume));   // append + pop(0), :359-365; open = previous close :355
-    e.close = np_;
-    if constexpr (MODE == M_RESIDENT) {                            // the next step's windows (cursors are final for this step)
-        wp.load(blkP, e.ppos);
-        if (!e.has_gauss) wl.load(blkL, e.lpos);
-    }
-    const double pv = e.cash + e.holdings * np_;
-    e.step += 1;
-    return e.step >= (uint32_t)c.max_steps || pv <= 0.0 || pv >= c.initial_balance * 10.0;   // :382-386
+    so.price = price; so.volume = volume; so.u_hi = u_hi; so.u_lo = u_lo;
 }
 
-// second half of a split step: price, candle, termination (the tail of env_step above)
+// second half of a step: price, candle, termination (:350-386)
 template <class H>
 __device__ __forceinline__ bool finish_step(Env &e, const Params &p, H &hist, int phase, const SplitOut &so, double g) {
     const Cfg &c = p.cfg;
@@ -432,33 +354,28 @@ __device__ __forceinline__ bool finish_step(Env &e, const Params &p, H &hist, in
     return e.step >= (uint32_t)c.max_steps || pv <= 0.0 || pv >= c.initial_balance * 10.0;   // :382-386
 }
 
-// one legacy_gauss() value from the NumPy stream whose state (cursor, cached half) is in `e`: the gaussian block of env_step for a
-// wave that owns nothing but that stream
-__device__ __forceinline__ double draw_gauss(Env &e, uint32_t *__restrict__ blkL) {
+// one legacy_gauss() value (polar method) from the NumPy stream whose state (cursor, ready mark, cached half) is in `e`.  `lw`: the
+// WL ready words at the cursor (two attempts); only a third attempt (4.6 % of the pairs) goes draw by draw.
+__device__ __forceinline__ double draw_gauss(Env &e, uint32_t *__restrict__ blkL, const uint32_t (&lw)[WL]) {
     if (e.has_gauss) {
         e.has_gauss = 0;
         const double g = e.gauss;
         e.gauss = 0.0;
         return g;
     }
-    MtWindow<WL> wl;
-    wl.load(blkL, e.lpos);
-    uint32_t lw[WL];
-#pragma unroll
-    for (int j = 0; j < WL; ++j) lw[j] = wl.draw(j, e.lpos, e.lpretw);
-    double x1 = 2.0 * u53(lw[0], lw[1]) - 1.0;
-    double x2 = 2.0 * u53(lw[2], lw[3]) - 1.0;
+    double x1 = 2.0 * u53(mt_temper(lw[0]), mt_temper(lw[1])) - 1.0;
+    double x2 = 2.0 * u53(mt_temper(lw[2]), mt_temper(lw[3])) - 1.0;
     double r2 = x1 * x1 + x2 * x2;
     uint32_t used = 4;
     bool ok = !(r2 >= 1.0 || r2 == 0.0);
     if (!ok) {
-        x1 = 2.0 * u53(lw[4], lw[5]) - 1.0;
-        x2 = 2.0 * u53(lw[6], lw[7]) - 1.0;
+        x1 = 2.0 * u53(mt_temper(lw[4]), mt_temper(lw[5])) - 1.0;
+        x2 = 2.0 * u53(mt_temper(lw[6]), mt_temper(lw[7])) - 1.0;
         r2 = x1 * x1 + x2 * x2;
         used = 8;
         ok = !(r2 >= 1.0 || r2 == 0.0);
     }
-    wl.commit(blkL, e.lpos, e.lpretw, used);
+    mt_advance(e.lpos, e.lpretw, used);
     if (!ok) {
         MtStream sl(blkL, e.lpos, e.lpretw);
         do {
@@ -472,6 +389,15 @@ __device__ __forceinline__ double draw_gauss(Env &e, uint32_t *__restrict__ blkL
     e.gauss = f * x1;
     e.has_gauss = 1;
     return f * x2;
+}
+// wave-level wrapper: makes the lanes' next WL words ready (a chunk twist every ~14 steps, the lanes of a wave consume in step),
+// loads them and draws.  `want`: this lane needs a gaussian.
+__device__ __forceinline__ double next_gauss(Env &e, uint32_t *__restrict__ blkL, bool want) {
+    const bool fresh = want && !e.has_gauss;
+    mt_make_ready(blkL, e.lpos, e.lpretw, WL, fresh);
+    uint32_t lw[WL] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (fresh) mt_load_run<WL>(blkL + e.lpos, lw);
+    return want ? draw_gauss(e, blkL, lw) : 0.0;
 }
 
 // NumPy pairwise sum of 14 / 20 float64 values (loops_utils.h.src): 8 running partials, a balanced
@@ -687,107 +613,16 @@ __device__ __forceinline__ void hash_cont(uint64_t key, uint64_t t, float &b, fl
     s = (float)((double)u1 / 8388608.0 - 1.0);
 }
 
-// step (k_steps == 1, explicit actions, per-step outputs) and rollout (k fused steps) share one body
-template <bool ROLLOUT>
-__global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
-    __shared__ uint32_t tile[64 * ROW];
-    __shared__ uint32_t win[ROLLOUT ? 64 * KROW : 1];
-    const int64_t i0 = (int64_t)blockIdx.x * BLOCK;
-    const int64_t i = i0 + threadIdx.x;
-    const bool live = i < p.n;
-    const int64_t li = live ? i : i0;
-    Env e;
-    e.load(p.scal, p.n, li);
-    uint32_t *wrow = win + (ROLLOUT ? (threadIdx.x & 63u) * KROW : 0u);
-    RollP dp(wrow, p.mtP + li * MT_STRIDE, e.ppos, e.ppretw);
-    RollL dl(wrow + (ROLLOUT ? KW_P : 0), p.mtL + li * MT_STRIDE, e.lpos, e.lpretw);
-    uint64_t key = ROLLOUT ? hash_env_key(p.a_seed, (uint64_t)(p.env0 + li)) : 0;
-    double rsum = 0.0;
-    int32_t dcount = 0;
-    int phase = p.phase;
-    const int ksteps = ROLLOUT ? p.k_steps : 1;
-#pragma unroll 1
-    for (int t = 0; t < ksteps; ++t) {
-        double reward = 0.0;
-        bool term = false, reset_now = false;
-        const int next_phase = phase + 1 == HLEN ? 0 : phase + 1;
-        if (ROLLOUT) { dp.ensure_inline(WP); dl.ensure_inline(WL); }          // wave-convergent top-up: this step's words are parked
-        if (live) {
-            if (p.mode == CGE_AUTORESET_NEXT_STEP && e.needs_reset) {
-                reset_now = true;
-            } else {
-                int32_t a = 0;
-                float ab = 0.0f, as = 0.0f;
-                if (p.cfg.continuous) {
-                    if (p.actions) { const float2 v = reinterpret_cast<const float2 *>(p.actions)[(int64_t)t * p.n + i]; ab = v.x; as = v.y; }
-                    else hash_cont(key, (uint64_t)(p.t0 + t), ab, as);
-                } else {
-                    a = p.actions ? reinterpret_cast<const int32_t *>(p.actions)[(int64_t)t * p.n + i]
-                                  : (int32_t)hash_action_from_key(key, (uint64_t)(p.t0 + t), 5u, 0u);
-                }
-                MtWindow<WP> wp;
-                MtWindow<WL> wl;
-                HistGlobal hist{p.closes, p.ohlv, p.n, i};
-                term = env_step<ROLLOUT ? M_PARKED : M_STEP>(e, p, i, hist, phase, a, ab, as, reward, dp, dl, wp, wl);
-                e.ep_return += reward;
-                if (term) {
-                    e.episodes += 1;
-                    if (p.ep_ret) p.ep_ret[i] = e.ep_return;
-                    if (p.ep_len) p.ep_len[i] = (int32_t)e.step;
-                    if (p.mode == CGE_AUTORESET_SAME_STEP) reset_now = true;
-                    else if (p.mode == CGE_AUTORESET_NEXT_STEP) e.needs_reset = 1;
-                }
-            }
-        }
-        // SAME_STEP: the terminal observation of the lanes that just finished goes to final_obs first
-        const unsigned long long fin_mask = __ballot(live && term && reset_now);
-        float *obs_t = p.obs ? p.obs + (int64_t)t * p.obs_step_stride + i0 * OBS : nullptr;
-#pragma unroll 1
-        for (int pass = (fin_mask && p.final_obs) ? 0 : 1; pass < 2; ++pass) {
-            if (pass == 1 && reset_now) {
-                if (ROLLOUT) { HistGlobal hist{p.closes, p.ohlv, p.n, i}; reset_body(e, p, hist, next_phase, dp, dl); }
-                else do_reset(e, p, i, next_phase, tile + (threadIdx.x & 63u) * ROW);
-            }
-            float *dst = pass == 0 ? p.final_obs + i0 * OBS : obs_t;
-            if (dst) observe(e, p, i0, i, live, next_phase, dst, pass == 0 ? fin_mask : ~0ull, tile);
-        }
-        if (live) {
-            if (ROLLOUT) {
-                rsum += reward;
-                dcount += term ? 1 : 0;
-                if (p.reward) p.reward[(int64_t)t * p.n + i] = (float)reward;
-                if (p.terminated) p.terminated[(int64_t)t * p.n + i] = term ? 1 : 0;
-            } else {
-                p.reward[i] = (float)reward;
-                p.terminated[i] = term ? 1 : 0;
-                if (p.truncated) p.truncated[i] = 0;
-            }
-        }
-        phase = next_phase;
-    }
-    if (live) {
-        if (ROLLOUT) {                                         // consumed words back to the generator blocks, cursors to the record
-            dp.flush(); dl.flush();
-            e.ppos = dp.pos; e.ppretw = dp.pretw; e.lpos = dl.pos; e.lpretw = dl.pretw;
-        }
-        e.store(p.scal, p.n, i);
-        if (ROLLOUT) {
-            if (p.reward_sum) p.reward_sum[i] = rsum;
-            if (p.done_count) p.done_count[i] = dcount;
-        }
-    }
-}
-
 // ------------------------------------------------------------------ resident rollout
 // k fused steps with the 64 envs' 50-candle window resident in LDS (76.8 KB: closes [50][64] f64 + ohlv [50][64] float4): the
 // window is read from HBM once per launch instead of once per step (1,200 of a step's ~2,900 bytes), and every new candle is
 // also written through to the [50][N] arrays, so nothing has to be copied back.  LDS allows two such windows per CU; with one
 // wave per window (measured: 580 us per 1M-env step against 667 streaming) half of the CU's SIMDs idle while each wave issues
 // ~5,500 mostly float64 instructions per step.  So a workgroup is FOUR waves over the same 64 envs and the same window:
-//   A steps the market: trade, volume, regime, P-stream draws (env_step<M_SPLIT>), then — after bar1 — price, candle, termination
+//   A steps the market: trade, volume, regime, P-stream draws (market_step), then — after bar1 — price, candle, termination
 //     (finish_step), rewards, resets;
 //   B (lane = env) streams the 50 closes through the indicators and writes the 11 scalar features (features_resident); it owns
-//     the NumPy stream and draws the next step's gaussian (draw_gauss: polar method, software float64 log);
+//     the NumPy stream and draws the next step's gaussian (next_gauss: polar method, software float64 log);
 //   C (two waves, 32 envs each) writes the 250 ratio columns row by row (ratio_rows_resident: lane = candle, 1,000 contiguous
 //     bytes per env) and never loads from memory: nothing ever waits for its stores.
 // B's observation of step t and C's gaussian for step t+1 overlap A's first half of step t+1.  Hand-over per step, two barriers:
@@ -823,6 +658,9 @@ __device__ unsigned long long g_timing[16384 * 8];
 #define TICK(k)
 #endif
 constexpr int RES_WAVES = 4;
+// the NumPy stream's state as one mailbox word: lpos | ready-mark code << 10 | has_gauss << 15 (waves A and B take turns on the stream)
+__device__ __forceinline__ uint32_t lcur_pack(const Env &e) { return e.lpos | ((e.lpretw > e.lpos ? mt_ready_encode(e.lpretw) : 0u) << 10) | (e.has_gauss << 15); }
+__device__ __forceinline__ void lcur_unpack(Env &e, uint32_t u) { e.lpos = u & 1023u; e.lpretw = mt_ready_decode((u >> 10) & 31u); e.has_gauss = (u >> 15) & 1u; }
 // ONE_STEP: the step() entry (k = 1); a separate instantiation mainly so that profiles tell the two paths apart
 template <bool ONE_STEP>
 __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
@@ -837,7 +675,7 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
     uint32_t *waveflag = reinterpret_cast<uint32_t *>(res_lds + RES_HIST + 8 * 64 * sizeof(double) + 2 * 64 * sizeof(uint32_t));
     uint32_t *slots = reinterpret_cast<uint32_t *>(res_lds + RES_HIST + RES_MAIL);
     double &m_gauss = mail[4 * 64], &m_lcache = mail[5 * 64];
-    uint32_t &m_lcur = mailu[64];                              // lpos | pretw flag << 10 | has_gauss << 11
+    uint32_t &m_lcur = mailu[64];                              // lcur_pack()
     const int64_t i0 = (int64_t)blockIdx.x * BLOCK;
     const int64_t i = i0 + lane;
     const bool live = i < p.n;
@@ -889,7 +727,11 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
         Env v;                                                 // the record: the stream's state (lpos, lpretw, has_gauss, gauss) is this wave's from here on;
         v.load(p.scal, p.n, li);                               // cash, holdings, psych, close, cash_kind are refreshed from the mailbox every step
         // a lane that starts with a pending NEXT_STEP reset does not step first: no gaussian for it
-        if (live && !(p.mode == CGE_AUTORESET_NEXT_STEP && v.needs_reset)) m_gauss = draw_gauss(v, blkL);
+        {
+            const bool w0 = live && !(p.mode == CGE_AUTORESET_NEXT_STEP && v.needs_reset);
+            const double g0 = next_gauss(v, blkL, w0);
+            if (w0) m_gauss = g0;
+        }
 #pragma unroll 1
         for (int t = 0; t < p.k_steps; ++t) {
             const int next_phase = phase + 1 == HLEN ? 0 : phase + 1;
@@ -906,30 +748,32 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
             if (__ballot(want)) features_resident(v, p, hist, next_phase, want ? row : obs_row, want);
             TICK(5);
             if (slow) {
-                m_lcur = v.lpos | (v.lpretw ? 1024u : 0u) | (v.has_gauss << 11); m_lcache = v.gauss;
+                m_lcur = lcur_pack(v); m_lcache = v.gauss;
                 full_barrier();                                 // bar3: the pre-reset rows are out, A may rewrite the window and take the stream
                 full_barrier();                                 // bar4: the fresh windows are in LDS, the stream is back
                 const uint32_t u2 = *mailu;
-                if (u2 & F_RESET) { v.lpos = m_lcur & 1023u; v.lpretw = (m_lcur & 1024u) ? (uint32_t)MT_N : 0u; v.has_gauss = (m_lcur >> 11) & 1u; v.gauss = m_lcache; }
+                if (u2 & F_RESET) { lcur_unpack(v, m_lcur); v.gauss = m_lcache; }
                 const bool again = (u2 & F_RESET) != 0u && obs_row != nullptr;
                 v.cash = mail[0]; v.holdings = mail[64]; v.psych = mail[128]; v.close = mail[192]; v.cash_kind = u2 & 3u;
                 if (__ballot(again)) features_resident(v, p, hist, next_phase, obs_row, again);
             }
-            if (t + 1 < p.k_steps && live && (*mailu & F_DRAW_NEXT)) m_gauss = draw_gauss(v, blkL);   // step t+1's
+            if (t + 1 < p.k_steps) {                           // step t+1's gaussian
+                const bool wn = live && (*mailu & F_DRAW_NEXT);
+                const double gn = next_gauss(v, blkL, wn);
+                if (wn) m_gauss = gn;
+            }
             phase = next_phase;
         }
-        m_lcur = v.lpos | (v.lpretw ? 1024u : 0u) | (v.has_gauss << 11); m_lcache = v.gauss;
+        m_lcur = lcur_pack(v); m_lcache = v.gauss;
         lds_barrier();                                         // closing barrier: A stores the record
         return;
     }
     // ---------------- wave A: the market
     Env e;
     e.load(p.scal, p.n, li);
-    RollP dp(nullptr, nullptr, 0, 0);                          // unused in this mode
-    RollL dl(nullptr, nullptr, 0, 0);
-    MtWindow<WP> wp;
-    MtWindow<WL> wl;                                           // unused (wave B draws the gaussians)
-    wp.load(blkP, e.ppos);
+    uint32_t pw[WP];                                           // the step's CPython-stream words: ready, loaded one step ahead
+    mt_make_ready(blkP, e.ppos, e.ppretw, WP, live);
+    mt_load_run<WP>(blkP + e.ppos, pw);
     const uint64_t key = hash_env_key(p.a_seed, (uint64_t)(p.env0 + li));
     double rsum = 0.0;
     int32_t dcount = 0;
@@ -953,9 +797,13 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
                     a = p.actions ? reinterpret_cast<const int32_t *>(p.actions)[(int64_t)t * p.n + i]
                                   : (int32_t)hash_action_from_key(key, (uint64_t)(p.t0 + t), 5u, 0u);
                 }
-                (void)env_step<M_SPLIT>(e, p, li, pend, phase, a, ab, as, reward, dp, dl, wp, wl, &so);
+                market_step(e, p, li, a, ab, as, reward, pw, so);
                 stepped = true;
             }
+        }
+        if (t + 1 < p.k_steps) {                               // the next step's words (the cursor is final): a chunk twist every ~3 steps,
+            mt_make_ready(blkP, e.ppos, e.ppretw, WP, stepped);   // in wave A's slack before bar1, then a plain load
+            if (stepped) mt_load_run<WP>(blkP + e.ppos, pw);
         }
         TICK(0);
         lds_barrier();                                          // bar1: B is done with window(t-1), C's gaussian for this step is in LDS
@@ -989,18 +837,21 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
 #pragma unroll 1
             for (uint32_t round = 0; round * RES_SLOTS < (uint32_t)__popcll(rm); ++round) {
                 if (reset_now && rank / RES_SLOTS == round) {
-                    e.lpos = m_lcur & 1023u; e.lpretw = (m_lcur & 1024u) ? (uint32_t)MT_N : 0u; e.has_gauss = (m_lcur >> 11) & 1u; e.gauss = m_lcache;
+                    lcur_unpack(e, m_lcur); e.gauss = m_lcache;
                     uint32_t *row = slots + (rank % RES_SLOTS) * RES_SLOT_WORDS;
                     LdsDrawsCall<64> sp(row, blkP, e.ppos, e.ppretw);
                     LdsDrawsCall<32> sl(row + 64, blkL, e.lpos, e.lpretw);
                     reset_body(e, p, hist, next_phase, sp, sl);
                     sp.flush(); sl.flush();
                     e.ppos = sp.pos; e.ppretw = sp.pretw; e.lpos = sl.pos; e.lpretw = sl.pretw;
-                    wp.load(blkP, e.ppos);                     // the prefetched window belonged to the finished episode's cursor
-                    m_lcur = e.lpos | (e.lpretw ? 1024u : 0u) | (e.has_gauss << 11); m_lcache = e.gauss;
+                    m_lcur = lcur_pack(e); m_lcache = e.gauss;
                     mail[0] = e.cash; mail[64] = e.holdings; mail[128] = e.psych; mail[192] = e.close;
                     *mailu = e.cash_kind | F_RESET | F_DRAW_NEXT;
                 }
+            }
+            if (t + 1 < p.k_steps) {                           // the prefetched words belonged to the finished episode's cursor
+                mt_make_ready(blkP, e.ppos, e.ppretw, WP, reset_now);
+                if (reset_now) mt_load_run<WP>(blkP + e.ppos, pw);
             }
             full_barrier();                                      // bar4
         }
@@ -1019,7 +870,7 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
     }
     lds_barrier();                                              // closing barrier: B's last rows are out, C's stream state is in LDS
     if (live) {
-        e.lpos = m_lcur & 1023u; e.lpretw = (m_lcur & 1024u) ? (uint32_t)MT_N : 0u; e.has_gauss = (m_lcur >> 11) & 1u; e.gauss = m_lcache;
+        lcur_unpack(e, m_lcur); e.gauss = m_lcache;
         e.store(p.scal, p.n, i);
         if (p.reward_sum) p.reward_sum[i] = rsum;
         if (p.done_count) p.done_count[i] = dcount;
@@ -1108,11 +959,6 @@ struct cge_crypto : HandleBase {
     }
 };
 
-// CGE_CRYPTO_RESIDENT: 2 (default) the resident kernel serves rollouts and step(); 1 rollouts only; 0 the streaming kernels
-static int resident_mode() {
-    static const int m = [] { const char *v = getenv("CGE_CRYPTO_RESIDENT"); return v ? atoi(v) : 2; }();
-    return m;
-}
 static hipError_t launch_resident(cge_crypto *h, const crypto::Params &p, hipStream_t s, bool one_step) {
     if (!h->resident_ready) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(crypto::resident_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)crypto::RES_LDS);
@@ -1148,7 +994,7 @@ void cge_crypto_default_config(cge_crypto_config *c) {
 int cge_crypto_create(const cge_crypto_config *cfg, int64_t n_envs, int device, int64_t env_index0, cge_crypto **out) {
     if (!cfg || !out || n_envs <= 0 || env_index0 < 0) return CGE_ERR_INVALID_ARG;
     *out = nullptr;
-    if (cfg->autoreset_mode < 0 || cfg->autoreset_mode > 2 || cfg->max_steps <= 0 || cfg->max_steps > 65535 ||
+    if (cfg->autoreset_mode < 0 || cfg->autoreset_mode > 2 || cfg->max_steps <= 0 || cfg->max_steps > crypto::MAX_STEPS_LIMIT ||
         cfg->action_type < 0 || cfg->action_type > 1 || !(cfg->min_price > 0) || !(cfg->max_price >= cfg->min_price))
         return CGE_ERR_INVALID_ARG;
     int ndev = 0;
@@ -1229,9 +1075,7 @@ int cge_crypto_step(cge_crypto *h, const void *actions, float *obs_out, float *r
     p.actions = actions; p.obs = obs_out; p.reward = reward_out; p.terminated = terminated_out; p.truncated = truncated_out;
     p.final_obs = final_obs_out; p.k_steps = 1;
     // the four-wave resident kernel also serves a single step: its waves share the row, feature and market work of the 64 envs
-    if (resident_mode() >= 2) CGE_TRY(h, launch_resident(h, p, as_stream(stream), true));
-    else { hipLaunchKernelGGL(crypto::step_kernel<false>, dim3(h->blocks()), dim3(crypto::BLOCK), 0, as_stream(stream), p); h->last_kernel = "cge::crypto::step_kernel<false>"; }
-    CGE_TRY(h, hipGetLastError());
+    CGE_TRY(h, launch_resident(h, p, as_stream(stream), true));
     h->phase = (h->phase + 1) % crypto::HLEN;
     return CGE_OK;
 }
@@ -1247,9 +1091,7 @@ int cge_crypto_rollout(cge_crypto *h, int32_t k_steps, const void *actions, uint
     crypto::Params p = h->params();
     p.k_steps = k_steps; p.actions = actions; p.a_seed = action_seed; p.t0 = t0; p.obs = obs_out; p.obs_step_stride = obs_step_stride;
     p.reward = reward_traj_out; p.terminated = terminated_traj_out; p.reward_sum = reward_sum_out; p.done_count = done_count_out;
-    if (resident_mode() >= 1 && k_steps >= 2) CGE_TRY(h, launch_resident(h, p, as_stream(stream), false));
-    else { hipLaunchKernelGGL(crypto::step_kernel<true>, dim3(h->blocks()), dim3(crypto::BLOCK), 0, as_stream(stream), p); h->last_kernel = "cge::crypto::step_kernel<true>"; }
-    CGE_TRY(h, hipGetLastError());
+    CGE_TRY(h, launch_resident(h, p, as_stream(stream), false));
     h->phase = (h->phase + k_steps) % crypto::HLEN;
     return CGE_OK;
 }
@@ -1265,11 +1107,32 @@ int cge_crypto_info(cge_crypto *h, int32_t field_id, double *out, void *stream) 
 
 size_t cge_crypto_state_bytes(const cge_crypto *h) { return h ? 12 * 4 + 6 * 8 + 2 * MT_N * 4 + crypto::HLEN * 5 * 8 : 0; }
 
+// device stream (block, cursor, ready mark) -> CPython layout (624 words of ONE generation + index of the next unconsumed word).
+// Words [pos, pretw) are twisted already; the rest of the generation is twisted here.  A ready mark beyond 624 means the first
+// chunk of the NEXT generation has been twisted in place as well (cge_device.hpp: mt_make_ready): those words are taken back
+// to the current generation first — the twist is invertible word by word: new[k] ^ cur[k+397] = g(y) with y = (cur[k] & 0x80000000)
+// | (cur[k+1] & 0x7fffffff), and g(y) = (y >> 1) ^ (y & 1 ? 0x9908b0df : 0) gives y back (bit 31 of g(y) is y's bit 0).  What cannot
+// be recovered, the low 31 bits of cur[0], no future output depends on.
 static void export_mt(const uint32_t *w, uint32_t pos, uint32_t pretw, uint32_t *omt, int32_t *idx) {
     memcpy(omt, w, MT_N * 4);
+    if (pretw > (uint32_t)MT_N) {
+        const uint32_t ahead = pretw - (uint32_t)MT_N;         // words [0, ahead) belong to the next generation
+        std::vector<uint32_t> y(ahead);
+        for (uint32_t k = 0; k < ahead; ++k) {
+            const uint32_t g = omt[k] ^ omt[k + MT_M];          // k + 397 < 624: a word of the current generation
+            const uint32_t odd = g >> 31;
+            y[k] = (((g ^ (odd ? 0x9908b0dfu : 0u)) << 1) | odd);
+        }
+        for (uint32_t k = 0; k < ahead; ++k) {
+            const uint32_t upper = y[k] & 0x80000000u, lower = k ? (y[k - 1] & 0x7fffffffu) : 0u;
+            omt[k] = upper | lower;
+        }
+        omt[ahead] = (omt[ahead] & 0x80000000u) | (y[ahead - 1] & 0x7fffffffu);   // (its low bits were never changed: a consistency no-op)
+        pretw = MT_N;
+    }
     if (pretw >= (uint32_t)MT_N) { *idx = (int32_t)pos; return; }
-    if (pos == 0) { *idx = MT_N; return; }
-    for (uint32_t k = pos; k < (uint32_t)MT_N; ++k) {
+    if (pos == 0 && pretw == 0) { *idx = MT_N; return; }
+    for (uint32_t k = pretw > pos ? pretw : pos; k < (uint32_t)MT_N; ++k) {
         const uint32_t k1 = k + 1 == (uint32_t)MT_N ? 0 : k + 1, km = k + MT_M >= (uint32_t)MT_N ? k + MT_M - MT_N : k + MT_M;
         const uint32_t t = (omt[k] & 0x80000000u) | (omt[k1] & 0x7fffffffu);
         omt[k] = omt[km] ^ (t >> 1) ^ ((t & 1u) ? 0x9908b0dfu : 0u);
@@ -1294,13 +1157,13 @@ int cge_crypto_get_state(cge_crypto *h, void *host_buf, void *stream) {
     const size_t rec = cge_crypto_state_bytes(h);
     for (int64_t i = 0; i < n; ++i) {
         uint8_t *p = (uint8_t *)host_buf + (size_t)i * rec;
-        const uint4 a = sc[i], b = sc[n + i], c = sc[2 * n + i], d = sc[3 * n + i];
-        auto dbl = [](uint32_t lo, uint32_t hi) { uint64_t u = ((uint64_t)hi << 32) | lo; double x; memcpy(&x, &u, 8); return x; };
-        int32_t hd[12] = {(int32_t)((d.x >> 16) & 7u), (int32_t)(d.x & 0xffffu), (int32_t)((d.x >> 22) & 1u), (int32_t)((d.x >> 20) & 3u),
-                          0, 0, (int32_t)((d.x >> 19) & 1u), (int32_t)((d.x >> 23) | ((d.y >> 22) << 9)), 0, 0, 0, 0};
-        double scv[6] = {dbl(a.x, a.y), dbl(a.z, a.w), dbl(b.z, b.w), dbl(c.x, c.y), dbl(c.z, c.w), dbl(d.z, d.w)};   // [5]: episode return so far
-        export_mt(&mp[(size_t)i * MT_STRIDE], d.y & 1023u, (d.y & 1024u) ? MT_N : 0, (uint32_t *)(p + 96), &hd[4]);
-        export_mt(&ml[(size_t)i * MT_STRIDE], (d.y >> 11) & 1023u, (d.y & (1u << 21)) ? MT_N : 0, (uint32_t *)(p + 96 + MT_N * 4), &hd[5]);
+        crypto::Env e;
+        e.unpack(sc[i], sc[n + i], sc[2 * n + i], sc[3 * n + i]);
+        int32_t hd[12] = {(int32_t)e.regime, (int32_t)e.step, (int32_t)e.needs_reset, (int32_t)e.cash_kind,
+                          0, 0, (int32_t)e.has_gauss, (int32_t)e.episodes, 0, 0, 0, 0};
+        double scv[6] = {e.cash, e.holdings, e.psych, e.trend, e.gauss, e.ep_return};   // [5]: episode return so far
+        export_mt(&mp[(size_t)i * MT_STRIDE], e.ppos, e.ppretw, (uint32_t *)(p + 96), &hd[4]);
+        export_mt(&ml[(size_t)i * MT_STRIDE], e.lpos, e.lpretw, (uint32_t *)(p + 96 + MT_N * 4), &hd[5]);
         memcpy(p, hd, 48);
         memcpy(p + 48, scv, 48);
         double *hh = (double *)(p + 96 + 2 * MT_N * 4);
@@ -1328,21 +1191,18 @@ int cge_crypto_set_state(cge_crypto *h, const void *host_buf, void *stream) {
         double scv[6];
         memcpy(hd, p, 48);
         memcpy(scv, p + 48, 48);
-        if (hd[0] < 0 || hd[0] > 4 || hd[1] < 0 || hd[1] > 65535 || hd[4] < 0 || hd[4] > MT_N || hd[5] < 0 || hd[5] > MT_N)
+        if (hd[0] < 0 || hd[0] > 4 || hd[1] < 0 || hd[1] > crypto::MAX_STEPS_LIMIT || hd[4] < 0 || hd[4] > MT_N || hd[5] < 0 || hd[5] > MT_N)
             return h->fail(CGE_ERR_INVALID_ARG, "cge_crypto_set_state: malformed record");
         const double *hh = (const double *)(p + 96 + 2 * MT_N * 4);
-        auto lo = [](double x) { uint64_t u; memcpy(&u, &x, 8); return (uint32_t)u; };
-        auto hi = [](double x) { uint64_t u; memcpy(&u, &x, 8); return (uint32_t)(u >> 32); };
-        const double close = hh[5 * (crypto::HLEN - 1) + 3];
-        const uint32_t ppos = hd[4] >= MT_N ? 0u : (uint32_t)hd[4], ppre = hd[4] >= MT_N ? 0u : 1024u;
-        const uint32_t lpos = hd[5] >= MT_N ? 0u : (uint32_t)hd[5], lpre = hd[5] >= MT_N ? 0u : (1u << 21);
-        sc[i] = make_uint4(lo(scv[0]), hi(scv[0]), lo(scv[1]), hi(scv[1]));
-        sc[n + i] = make_uint4(lo(close), hi(close), lo(scv[2]), hi(scv[2]));
-        sc[2 * n + i] = make_uint4(lo(scv[3]), hi(scv[3]), lo(scv[4]), hi(scv[4]));
-        const uint32_t ep = (uint32_t)hd[7] < 0x7FFFFu ? (uint32_t)hd[7] : 0x7FFFFu;
-        sc[3 * n + i] = make_uint4((uint32_t)hd[1] | ((uint32_t)hd[0] << 16) | ((uint32_t)(hd[6] & 1) << 19) | ((uint32_t)(hd[3] & 3) << 20) |
-                                       ((uint32_t)(hd[2] & 1) << 22) | ((ep & 511u) << 23),
-                                   ppos | ppre | (lpos << 11) | lpre | ((ep >> 9) << 22), lo(scv[5]), hi(scv[5]));
+        crypto::Env e;
+        e.cash = scv[0]; e.holdings = scv[1]; e.psych = scv[2]; e.trend = scv[3]; e.gauss = scv[4]; e.ep_return = scv[5];
+        e.close = hh[5 * (crypto::HLEN - 1) + 3];
+        e.regime = (uint32_t)hd[0]; e.step = (uint32_t)hd[1]; e.needs_reset = (uint32_t)(hd[2] & 1); e.cash_kind = (uint32_t)(hd[3] & 3);
+        e.has_gauss = (uint32_t)(hd[6] & 1); e.episodes = hd[7] < 0 ? 0u : (uint32_t)hd[7];
+        // a CPython state: every word from the index on is generated-but-unconsumed (ready); index 624 = regenerate first
+        e.ppos = hd[4] >= MT_N ? 0u : (uint32_t)hd[4]; e.ppretw = hd[4] >= MT_N ? 0u : (uint32_t)MT_N;
+        e.lpos = hd[5] >= MT_N ? 0u : (uint32_t)hd[5]; e.lpretw = hd[5] >= MT_N ? 0u : (uint32_t)MT_N;
+        e.pack(sc[i], sc[n + i], sc[2 * n + i], sc[3 * n + i]);
         memcpy(&mp[(size_t)i * MT_STRIDE], p + 96, MT_N * 4);
         memcpy(&ml[(size_t)i * MT_STRIDE], p + 96 + MT_N * 4, MT_N * 4);
         memcpy(&mp[(size_t)i * MT_STRIDE + MT_N], &mp[(size_t)i * MT_STRIDE], MT_PAD * 4);       // mirror words (cge_device.hpp)
