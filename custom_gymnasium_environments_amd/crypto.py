@@ -32,8 +32,9 @@ class CryptoVectorEnv(DeviceVectorEnv):
     metadata = {"render_modes": []}
 
     def __init__(self, num_envs, action_type="discrete", device="cuda:0", autoreset_mode="NextStep", env_index0=0,
-                 config=None, max_steps=1000, reuse_buffers=False, info_fields=(), record_episode_statistics=False):
+                 config=None, max_steps=1000, reuse_buffers=False, info_fields=(), record_episode_statistics=False, reference_info=False):
         self._init_common(num_envs, device, autoreset_mode, env_index0, reuse_buffers)
+        self._reference_info = bool(reference_info)
         if action_type not in ("discrete", "continuous"):
             raise ValueError("action_type must be 'discrete' or 'continuous'")
         self.action_type = action_type
@@ -42,7 +43,7 @@ class CryptoVectorEnv(DeviceVectorEnv):
         self._lib.cge_crypto_default_config(C.byref(cfg))
         for k, v in (config or {}).items():    # TradingConfig field names (:28-38)
             if not hasattr(cfg, k):
-                raise ValueError(f"unknown TradingConfig field {k!r}")
+                raise ValueError(f"unknown or unsupported TradingConfig field {k!r} (history_length is fixed at 50 in this build)")
             setattr(cfg, k, v)
         cfg.max_steps = int(max_steps)
         cfg.action_type = int(self.continuous)
@@ -125,7 +126,24 @@ class CryptoVectorEnv(DeviceVectorEnv):
         return out
 
     def _infos(self):
-        return {f: self.info(f) for f in self.info_fields}
+        d = {f: self.info(f) for f in self.info_fields}
+        if self._reference_info:
+            d.update(self.reference_info())
+        return d
+
+    def reference_info(self):
+        """The reference's step() `info` dict under ITS keys (crypto_trading_env.py:390-398): portfolio_value, cash, holdings,
+        current_price, market_psychology as float64 tensors of length N, and market_regime as int32 codes into REGIME_NAMES
+        (the reference puts the enum's string there; `regime_names()` maps a host copy).  `trade_info` (the dict describing
+        the step's trade) is not kept on the device and is not reproduced."""
+        return {"portfolio_value": self.info("portfolio_value"), "cash": self.info("cash"), "holdings": self.info("holdings"),
+                "current_price": self.info("current_price"), "market_regime": self.info("regime").to(torch.int32),
+                "market_psychology": self.info("market_psychology")}
+
+    @staticmethod
+    def regime_names(codes):
+        """MarketRegime values (:20-25) for the int codes in infos["market_regime"] (a host-side convenience)."""
+        return np.asarray(REGIME_NAMES, dtype=object)[np.asarray(torch.as_tensor(codes).cpu(), dtype=np.int64)]
 
     def get_state(self):
         rec = int(self._lib.cge_crypto_state_bytes(self._h))

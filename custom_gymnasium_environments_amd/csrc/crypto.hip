@@ -683,15 +683,15 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
     HistLds hist{lcb, lob, lane, HistGlobal{p.closes, p.ohlv, p.n, li}};
     if (role >= 1u) {   // the window: HBM -> LDS by waves B and C (17 + 17 + 16 slots) while wave A already steps the market
         const int s_lo = role == 1u ? 0 : role == 2u ? 17 : 34, s_hi = role == 1u ? 17 : role == 2u ? 34 : HLEN;
-#pragma unroll 1
-        for (int s0 = s_lo; s0 < s_hi; s0 += 6) {
-            double c[6];
-            float4 o[6];
+        // all of a wave's slots in ONE round trip (34 loads in flight, ~100 VGPRs that nothing else needs yet): in batches of six the
+        // window took three dependent trips, a quarter of a step() workgroup's life
+        constexpr int NB = 17;
+        double c[NB];
+        float4 o[NB];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) { const int sl = s0 + j < s_hi ? s0 + j : s_hi - 1; c[j] = hist.g.close(sl); o[j] = hist.g.rest(sl); }
+        for (int j = 0; j < NB; ++j) { const int sl = s_lo + j < s_hi ? s_lo + j : s_hi - 1; c[j] = hist.g.close(sl); o[j] = hist.g.rest(sl); }
 #pragma unroll
-            for (int j = 0; j < 6; ++j) { const int sl = s0 + j < s_hi ? s0 + j : s_hi - 1; hist.put_lds(sl, c[j], o[j]); }
-        }
+        for (int j = 0; j < NB; ++j) { const int sl = s_lo + j < s_hi ? s_lo + j : s_hi - 1; hist.put_lds(sl, c[j], o[j]); }
     }
     uint32_t *__restrict__ blkP = p.mtP + li * MT_STRIDE;
     uint32_t *__restrict__ blkL = p.mtL + li * MT_STRIDE;
@@ -740,6 +740,15 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
             TICK(4);
             const uint32_t u = *mailu;
             const bool slow = *waveflag != 0u;
+            // step t+1's gaussian: its words are requested BEFORE the features are computed, so the load's latency hides behind them
+            // (a step with resets hands the stream to wave A first: then the words are fetched afterwards)
+            const bool more = t + 1 < p.k_steps;
+            const bool wn_early = more && !slow && live && (u & F_DRAW_NEXT);
+            uint32_t lw[WL] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (more && !slow) {
+                mt_make_ready(blkL, v.lpos, v.lpretw, WL, wn_early && !v.has_gauss);
+                if (wn_early && !v.has_gauss) mt_load_run<WL>(blkL + v.lpos, lw);
+            }
             v.cash = mail[0]; v.holdings = mail[64]; v.psych = mail[128]; v.close = mail[192]; v.cash_kind = u & 3u;
             const uint32_t dest = (u >> 2) & 3u;
             float *obs_row = p.obs ? p.obs + (int64_t)t * p.obs_step_stride + li * OBS : nullptr;
@@ -756,14 +765,17 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
                 const bool again = (u2 & F_RESET) != 0u && obs_row != nullptr;
                 v.cash = mail[0]; v.holdings = mail[64]; v.psych = mail[128]; v.close = mail[192]; v.cash_kind = u2 & 3u;
                 if (__ballot(again)) features_resident(v, p, hist, next_phase, obs_row, again);
-            }
-            if (t + 1 < p.k_steps) {                           // step t+1's gaussian
-                const bool wn = live && (*mailu & F_DRAW_NEXT);
-                const double gn = next_gauss(v, blkL, wn);
-                if (wn) m_gauss = gn;
+                if (more) {
+                    const bool wn = live && (*mailu & F_DRAW_NEXT);
+                    const double gn = next_gauss(v, blkL, wn);
+                    if (wn) m_gauss = gn;
+                }
+            } else if (more) {
+                if (wn_early) m_gauss = draw_gauss(v, blkL, lw);
             }
             phase = next_phase;
         }
+        mt_make_ready(blkL, v.lpos, v.lpretw, WL, live && !v.has_gauss);   // the next launch's first gaussian starts with a plain load
         m_lcur = lcur_pack(v); m_lcache = v.gauss;
         lds_barrier();                                         // closing barrier: A stores the record
         return;
@@ -801,10 +813,10 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
                 stepped = true;
             }
         }
-        if (t + 1 < p.k_steps) {                               // the next step's words (the cursor is final): a chunk twist every ~3 steps,
-            mt_make_ready(blkP, e.ppos, e.ppretw, WP, stepped);   // in wave A's slack before bar1, then a plain load
-            if (stepped) mt_load_run<WP>(blkP + e.ppos, pw);
-        }
+        // the next step's words (the cursor is final): a chunk twist every ~3 steps, in wave A's slack before bar1, then a plain load.
+        // After the launch's last step the twist still happens (the next launch then starts with nothing but the load).
+        mt_make_ready(blkP, e.ppos, e.ppretw, WP, stepped);
+        if (t + 1 < p.k_steps && stepped) mt_load_run<WP>(blkP + e.ppos, pw);
         TICK(0);
         lds_barrier();                                          // bar1: B is done with window(t-1), C's gaussian for this step is in LDS
         TICK(1);
@@ -849,10 +861,8 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
                     *mailu = e.cash_kind | F_RESET | F_DRAW_NEXT;
                 }
             }
-            if (t + 1 < p.k_steps) {                           // the prefetched words belonged to the finished episode's cursor
-                mt_make_ready(blkP, e.ppos, e.ppretw, WP, reset_now);
-                if (reset_now) mt_load_run<WP>(blkP + e.ppos, pw);
-            }
+            mt_make_ready(blkP, e.ppos, e.ppretw, WP, reset_now);   // the prefetched words belonged to the finished episode's cursor
+            if (t + 1 < p.k_steps && reset_now) mt_load_run<WP>(blkP + e.ppos, pw);
             full_barrier();                                      // bar4
         }
         if (live) {

@@ -25,8 +25,9 @@ class ParkingVectorEnv(DeviceVectorEnv):
     metadata = {"render_modes": []}
 
     def __init__(self, num_envs, device="cuda:0", autoreset_mode="NextStep", env_index0=0, max_steps=1440, reuse_buffers=False,
-                 info_fields=(), record_episode_statistics=False):
+                 info_fields=(), record_episode_statistics=False, reference_info=False):
         self._init_common(num_envs, device, autoreset_mode, env_index0, reuse_buffers)
+        self._reference_info = bool(reference_info)
         self.single_action_space = Discrete(8)
         self.single_observation_space = Box(0.0, 1.0, (OBS_DIM,), np.float32)
         self.action_space = batch_space(self.single_action_space, self.num_envs)
@@ -100,4 +101,38 @@ class ParkingVectorEnv(DeviceVectorEnv):
         return out
 
     def _infos(self):
-        return {f: self.info(f) for f in self.info_fields}
+        d = {f: self.info(f) for f in self.info_fields}
+        if self._reference_info:
+            d.update(self.reference_info())
+        return d
+
+    def reference_info(self):
+        """The reference's `info` dict under ITS keys (parking_env.py:371-399 merged with CustomerManager.get_statistics,
+        customer.py:334-354), one tensor of length N per key (zone vectors [N, 3]), computed in float64 from the env's counters
+        with the reference's expressions.  `reference_info=True` in the constructor merges it into every step's / reset's infos
+        (a dozen small kernels per call: for callbacks that read e.g. info["total_revenue"], not for the hot loop)."""
+        f64 = torch.float64
+        tc, rej, sat, tw = (self.info(k) for k in ("total_customers", "rejected", "satisfied", "total_wait_time"))
+        some = tc > 0                                               # customer.py:341-347: all rates are 0.0 before the first customer
+        tcf = tc.to(f64)
+        t = self.info("timestep")
+        occ = torch.stack([self.info("zone_occupied", z) for z in range(3)], 1)
+        lvl = torch.stack([self.info("price_level", z) for z in range(3)], 1).long()
+        spots = torch.tensor([15.0, 20.0, 15.0], dtype=f64, device=self.device)          # config.py:6-10
+        base = torch.tensor([8.0, 5.0, 3.0], dtype=f64, device=self.device)
+        mult = torch.tensor([0.7, 1.0, 1.3], dtype=f64, device=self.device)              # PRICE_LEVELS, config.py:82-86
+        zero = torch.zeros_like(tcf)
+        return {
+            "total_customers": tc,
+            "rejection_rate": torch.where(some, rej.to(f64) / tcf, zero),
+            "satisfaction_rate": torch.where(some, sat.to(f64) / tcf, zero),
+            "avg_wait_time": torch.where(some, tw.to(f64) / torch.clamp(tcf, min=1.0), zero),
+            "hour": t // 60, "minute": t % 60, "timestep": t,                              # :378-379
+            "total_revenue": self.info("episode_revenue"),
+            "rejections": rej,                                                              # episode_rejections: bumped with the manager's counter (:209)
+            "occupancy_rate": occ.sum(1).to(f64) / 50.0,
+            "queue_length": self.info("queue_length"),
+            "zone_occupancy": occ.to(f64) / spots,                                          # parking_lot.py:254-266
+            "zone_prices": base * mult[lvl],                                                # pricing.py:59-64, :87-94
+            "price_changes_this_hour": self.info("price_changes_this_hour"),
+        }

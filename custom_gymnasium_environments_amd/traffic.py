@@ -34,8 +34,10 @@ class TrafficVectorEnv(DeviceVectorEnv):
     metadata = {"render_modes": []}
 
     def __init__(self, num_envs, device="cuda:0", autoreset_mode="NextStep", env_index0=0, grid_size=(5, 5),
-                 num_intersections=9, max_vehicles=50, spawn_rate=0.3, max_steps=1000, reuse_buffers=False, info_fields=(), record_episode_statistics=False):
+                 num_intersections=9, max_vehicles=50, spawn_rate=0.3, max_steps=1000, reuse_buffers=False, info_fields=(), record_episode_statistics=False,
+                 reference_info=False):
         self._init_common(num_envs, device, autoreset_mode, env_index0, reuse_buffers)
+        self._reference_info = bool(reference_info)
         cfg = _native.TrafficConfig()
         self._lib.cge_traffic_default_config(C.byref(cfg))
         cfg.grid_rows, cfg.grid_cols = int(grid_size[0]), int(grid_size[1])
@@ -125,7 +127,28 @@ class TrafficVectorEnv(DeviceVectorEnv):
         return out
 
     def _infos(self):
-        return {f: self.info(f) for f in self.info_fields}
+        d = {f: self.info(f) for f in self.info_fields}
+        if self._reference_info:
+            d.update(self.reference_info())
+        return d
+
+    def reference_info(self):
+        """The reference's `_get_info()` dict under ITS keys (environment.py:365-384): timestep, num_vehicles, total_reward,
+        `metrics` (calculate_traffic_metrics, utils.py:251-267) and `intersection_states` — here one dict of tensors instead of a list
+        of per-intersection dicts: light_phase [N, NI] (index into LIGHT_PHASES), queue_lengths [N, NI, 4] (NORTH, EAST, SOUTH,
+        WEST), vehicles_passed, total_waiting_time [N, NI].  Built from ~7 NI small info kernels: for callbacks, not the hot loop."""
+        ni, f64 = self.num_intersections, torch.float64
+        passed = torch.stack([self.info("vehicles_passed", k) for k in range(ni)], 1)
+        wait = torch.stack([self.info("total_waiting_time", k) for k in range(ni)], 1)
+        qlen = torch.stack([self.info("queue_len", q) for q in range(4 * ni)], 1).reshape(self.num_envs, ni, 4)
+        phase = torch.stack([self.info("light_phase", k) for k in range(ni)], 1)
+        tp, tw, tq = passed.sum(1).to(f64), wait.sum(1).to(f64), qlen.sum((1, 2)).to(f64)
+        metrics = {"total_vehicles_passed": passed.sum(1), "total_waiting_time": wait.sum(1),
+                   "average_waiting_time": tw / torch.clamp(tp, min=1.0), "total_queue_length": qlen.sum((1, 2)),
+                   "average_queue_length": tq / ni, "throughput": tp / ni}
+        return {"timestep": self.info("timestep"), "num_vehicles": self.info("num_vehicles"), "total_reward": self.total_reward(),
+                "metrics": metrics,
+                "intersection_states": {"light_phase": phase, "queue_lengths": qlen, "vehicles_passed": passed, "total_waiting_time": wait}}
 
     def get_state(self):
         rec = int(self._lib.cge_traffic_state_bytes(self._h))

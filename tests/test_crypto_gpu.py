@@ -277,3 +277,22 @@ def test_million_env_config_sampled_parity(cge, oracle):
     assert torch.allclose(obs[:, 252].double(), pv / 10000.0, rtol=1e-6)
     check_slices(obs, T2, T1)
     env.close()
+
+
+def test_reference_info_keys(cge):
+    """`reference_info=True`: the reference's info keys (crypto_trading_env.py:390-398) against the fixture's recorded info rows."""
+    fx = golden("crypto_discrete.npz")
+    A = fx["actions"]
+    n = A.shape[0]
+    env = cge.CryptoVectorEnv(n, autoreset_mode="Disabled", reference_info=True)
+    env.reset(seed=int(fx["seed0"]))
+    A_dev = torch.from_numpy(A).cuda()
+    for t in range(300):
+        _, _, te, _, info = env.step(A_dev[:, t])
+        if t % 60 == 59:
+            ref = fx["info"][:, t]
+            for k, col in [("portfolio_value", 0), ("cash", 1), ("holdings", 2), ("current_price", 3), ("market_psychology", 4)]:
+                assert np.allclose(_np(info[k]), ref[:, col], rtol=1e-9, atol=1e-12), (t, k)
+            assert np.array_equal(_np(info["market_regime"]), ref[:, 5].astype(np.int32))
+            assert list(cge.CryptoVectorEnv.regime_names(info["market_regime"])) == [cge.crypto.REGIME_NAMES[int(r)] for r in ref[:, 5]]
+    env.close()

@@ -102,3 +102,35 @@ def test_rollout_and_config5_size(cge, oracle):
         ob, r, te, _, _ = twin.step(acts[t])
         assert torch.equal(ob, traj[t]) and torch.equal(r, rt[t]) and torch.equal(te, tt[t]), t
     env.close(); half.close(); twin.close()
+
+
+def test_reference_info_keys_match_the_reference_fixture(cge):
+    """`reference_info=True` puts the reference's own info keys (parking_env.py:371-399 + customer.py:334-354) into
+    infos.  Expected values: the reference fixture's recorded counters pushed through the reference's expressions."""
+    fx = golden("parking_busy.npz")
+    A = fx["actions"]
+    n, T = A.shape
+    env = cge.ParkingVectorEnv(n, autoreset_mode="Disabled", reference_info=True)
+    _, info = env.reset(seed=int(fx["seed0"]))
+    assert float(info["rejection_rate"].sum()) == 0.0 and int(info["total_customers"].sum()) == 0
+    A_dev = torch.from_numpy(A).cuda()
+    done = np.zeros(n, bool)
+    for t in range(min(T, 1400)):
+        _, _, te, _, info = env.step(A_dev[:, t])
+        done |= _np(te)
+        if t % 140 != 139:
+            continue
+        S, F, live = fx["stats"][:, t].astype(np.float64), fx["money"][:, t], ~done
+        tc = S[:, 0]
+        some = tc > 0
+        exp = {"total_customers": tc, "rejection_rate": np.where(some, S[:, 1] / np.maximum(tc, 1), 0.0),
+               "satisfaction_rate": np.where(some, S[:, 2] / np.maximum(tc, 1), 0.0),
+               "avg_wait_time": np.where(some, S[:, 3] / np.maximum(tc, 1), 0.0), "hour": S[:, 6] // 60, "minute": S[:, 6] % 60,
+               "timestep": S[:, 6], "total_revenue": F[:, 0], "rejections": S[:, 1], "occupancy_rate": S[:, 7:10].sum(1) / 50,
+               "queue_length": S[:, 4], "price_changes_this_hour": S[:, 5]}
+        for k, v in exp.items():
+            assert np.array_equal(_np(info[k]).astype(np.float64)[live], v[live]), (t, k)
+        assert np.array_equal(_np(info["zone_occupancy"])[live], (S[:, 7:10] / np.array([15.0, 20.0, 15.0]))[live])
+        prices = np.array([8.0, 5.0, 3.0]) * np.array([0.7, 1.0, 1.3])[S[:, 10:13].astype(int)]
+        assert np.array_equal(_np(info["zone_prices"])[live], prices[live])
+    env.close()

@@ -204,3 +204,33 @@ def test_config4_size_properties_and_sampled_parity(cge, oracle):
     oh, rh, dh = half.rollout(T, action_seed=123)
     assert torch.equal(oh, obs[n // 2:]) and torch.equal(rh, rs[n // 2:])
     env.close(); half.close()
+
+
+def test_reference_info_keys(cge):
+    """`reference_info=True`: the reference's `_get_info()` keys (environment.py:365-384, utils.py:251-267) against the fixture's recorded
+    per-intersection state."""
+    fx = golden("traffic_3x3.npz")
+    A = fx["actions"]
+    n, T, ni = A.shape
+    ctor = json.loads(str(fx["ctor"]))
+    env = cge.TrafficVectorEnv(n, autoreset_mode="Disabled", reference_info=True, **ctor)
+    env.reset(seed=int(fx["seed0"]))
+    A_dev = torch.from_numpy(A).cuda()
+    for t in range(400):
+        _, _, te, _, info = env.step(A_dev[:, t])
+        if t % 100 != 99:
+            continue
+        S = fx["internal"][:, t].astype(np.int64)
+        per = S[:, :8 * ni].reshape(n, ni, 8)
+        st = info["intersection_states"]
+        assert np.array_equal(_np(st["light_phase"]), per[:, :, 0]) and np.array_equal(_np(st["vehicles_passed"]), per[:, :, 2])
+        assert np.array_equal(_np(st["total_waiting_time"]), per[:, :, 3]) and np.array_equal(_np(st["queue_lengths"]), per[:, :, 4:8])
+        tp, tw, tq = per[:, :, 2].sum(1), per[:, :, 3].sum(1), per[:, :, 4:8].sum((1, 2))
+        m = info["metrics"]
+        assert np.array_equal(_np(m["total_vehicles_passed"]), tp) and np.array_equal(_np(m["total_queue_length"]), tq)
+        assert np.array_equal(_np(m["average_waiting_time"]), tw / np.maximum(tp, 1)) and np.array_equal(_np(m["throughput"]), tp / ni)
+        assert np.array_equal(_np(m["average_queue_length"]), tq / ni)
+        assert np.array_equal(_np(info["num_vehicles"]), S[:, 8 * ni]) and np.array_equal(_np(info["timestep"]), S[:, 8 * ni + 1])
+        assert np.array_equal(_np(info["total_reward"]), np.cumsum(fx["reward"][:, :t + 1], axis=1)[:, -1]) or \
+            np.allclose(_np(info["total_reward"]), fx["reward"][:, :t + 1].sum(1), rtol=1e-12)
+    env.close()

@@ -10,11 +10,17 @@ env = cge.CryptoVectorEnv(1 << 20, device="cuda:0")
 env.reset(seed=1)
 buf = (ctypes.c_ulonglong * 8)()
 names = ["A: first half of step t+1 (trade, P draws)", "A: waiting at bar1", "A: second half (price, candle) + publish + bar2", "A: per-step outputs", "B: waiting for window(t) (bar1 + bar2)", "B: observation of step t"]
-for chunk in range(2):
-    env.rollout(16, action_seed=7, t0=chunk * 16, trajectory=True)
+import sys
+acts = torch.randint(0, 5, (16, 1 << 20), dtype=torch.int32, device="cuda")
+for chunk in range(4):
+    if chunk < 2:
+        env.rollout(16, action_seed=7, t0=chunk * 16, trajectory=True)
+    else:                                  # the step() entry (resident_kernel<true>, k = 1)
+        for t in range(16):
+            env.step(acts[t])
     torch.cuda.synchronize()
     L.cge_crypto_debug_timing(buf, 1)
     n = max(1, buf[7])
-    print(f"steps {chunk*16}..{chunk*16+15}: workgroup-steps {buf[7]}")
+    print(f"{'rollout' if chunk < 2 else 'step()'} steps {chunk*16}..{chunk*16+15}: workgroup-steps {buf[7]}")
     for k, nm in enumerate(names):
         print(f"   {nm:44s} {buf[k] * 10.0 / n / 1e3:8.2f} us")
