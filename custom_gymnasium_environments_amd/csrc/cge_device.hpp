@@ -90,15 +90,18 @@ __device__ __forceinline__ uint32_t mt_twist(uint32_t a, uint32_t b, uint32_t c)
 // and step (round 2: after a block's first wrap these commits alone cost step() ~150 us per 1M envs, and the generator traffic
 // was the whole gap between obliged and moved bytes).  Twisting a 32-word chunk (one 128-byte line) at a time ahead of the cursor
 // turns that into one full-line write per ~3 steps, and the per-step draw into a plain load of ready words.
-//   pretw codes: a multiple of 32, 624, or 624 + 32; stored in 5 bits as mt_ready_encode(pretw).
+//   pretw codes: a multiple of 32 below 624, 624, or 624 + a multiple of 32 (chunks of the NEXT generation, twisted while the
+//   cursor is still in this one); stored in 5 bits as mt_ready_encode(pretw).
 constexpr int MT_CHUNK = 32;
-__host__ __device__ __forceinline__ uint32_t mt_ready_decode(uint32_t q) { return q <= 19u ? 32u * q : (uint32_t)MT_N + 32u * (q - 20u); }   // q in 0..21
+__host__ __device__ __forceinline__ uint32_t mt_ready_decode(uint32_t q) { return q <= 19u ? 32u * q : (uint32_t)MT_N + 32u * (q - 20u); }   // q in 0..31
 __host__ __device__ __forceinline__ uint32_t mt_ready_encode(uint32_t pretw) { return pretw < (uint32_t)MT_N ? pretw / 32u : 20u + (pretw - (uint32_t)MT_N) / 32u; }
 // Twists, in place, the words from `lo` (unwrapped: >= 624 means word lo - 624 of the next generation) to the end of lo's 32-word
 // chunk, for the lanes with `go`; words of the chunk below lo keep their (already twisted) values.  Returns the new ready mark.
 // One lane = one block: 17 sixteen-byte loads (the chunk + 1 word, and the words 397 ahead — the piece that straddles word 623
 // runs into mirror word 624 = word 0, exactly the word it needs), 8 stores of the whole line (+4 for the mirror of words 0..15).
-__device__ __forceinline__ uint32_t mt_twist_chunk(uint32_t *__restrict__ blk, uint32_t lo, bool go) {
+// old0 (optional): receives the outgoing generation's word 0 when the next generation's first chunk overwrites it — its low 31
+// bits influence no future output, but a byte-exact CPython export (mt_export_cpython) wants them back.
+__device__ __forceinline__ uint32_t mt_twist_chunk(uint32_t *__restrict__ blk, uint32_t lo, bool go, uint32_t *old0 = nullptr) {
     const uint32_t gen = lo >= (uint32_t)MT_N ? (uint32_t)MT_N : 0u, base = lo - gen, c0 = base & ~31u;
     const uint32_t len = (uint32_t)MT_N - c0 < 32u ? (uint32_t)MT_N - c0 : 32u;   // the last chunk holds 16 words
     if (go) {
@@ -115,6 +118,7 @@ __device__ __forceinline__ uint32_t mt_twist_chunk(uint32_t *__restrict__ blk, u
             }
         }
         a[MT_CHUNK] = 0;
+        if (old0 && c0 == 0u) *old0 = a[0];                             // the previous generation's word 0 goes away now
         const uint32_t nxt = blk[c0 + len];                                    // word c0 + len <= 624 (mirror of word 0)
 #pragma unroll
         for (int j = 0; j < MT_CHUNK; ++j) {
@@ -134,13 +138,14 @@ __device__ __forceinline__ uint32_t mt_twist_chunk(uint32_t *__restrict__ blk, u
     }
     return gen + c0 + len;
 }
-// Makes words [pos, pos + need) ready (need <= 32; pos < 624).  Wave-convergent: as long as any lane of the wave is short, the
-// short lanes twist their next chunk (one or two rounds); call it with all lanes of the wave.
-__device__ __forceinline__ void mt_make_ready(uint32_t *__restrict__ blk, uint32_t pos, uint32_t &pretw, uint32_t need, bool active = true) {
+// Makes words [pos, pos + need) ready (pos < 624, need <= 227).  Wave-convergent: as long as any lane of the wave is short, the
+// short lanes twist their next chunk (a round per 32 words); call it with all lanes of the wave.
+__device__ __forceinline__ void mt_make_ready(uint32_t *__restrict__ blk, uint32_t pos, uint32_t &pretw, uint32_t need, bool active = true,
+                                              uint32_t *old0 = nullptr) {
 #pragma unroll 1
     while (__ballot(active && pos + need > pretw)) {
         const bool go = active && pos + need > pretw;
-        const uint32_t t = mt_twist_chunk(blk, pretw > pos ? pretw : pos, go);
+        const uint32_t t = mt_twist_chunk(blk, pretw > pos ? pretw : pos, go, old0);
         if (go) pretw = t;
     }
 }
@@ -307,6 +312,23 @@ struct LdsDraws {
         cur = 0;
         filled = true;
     }
+    // fill() for a stream whose next W words are READY (mt_make_ready): plain loads of the runs — no words 397 ahead, no twist —
+    // and the flush that follows writes nothing back (every consumed word lies below pretw)
+    __device__ __forceinline__ void fill_ready() {
+        static_assert(W % 4 == 0, "whole 16-byte pieces");
+#pragma unroll
+        for (int c0 = 0; c0 < W; c0 += MT_PAD) {
+            constexpr int N = W < MT_PAD ? W : MT_PAD;
+            uint32_t start = pos + (uint32_t)c0;
+            start -= start >= (uint32_t)MT_N ? MT_N : 0;           // words past 623 of a run come from the mirror
+            uint32_t a[N];
+            mt_load_run<N>(blk + start, a);
+#pragma unroll
+            for (int j = 0; j < N; ++j) row[c0 + j] = a[j];
+        }
+        cur = 0;
+        filled = true;
+    }
     __device__ __forceinline__ void flush() {
         if (!filled) return;
         uint32_t j = 0;
@@ -400,6 +422,7 @@ struct LdsDrawsCall {
     uint32_t *row;
     uint32_t *blk;
     uint32_t pos, pretw, cur;
+    uint32_t old0 = 0;                                          // twist-ahead streams: see mt_twist_chunk (kept in the env's record)
     bool filled;
 
     __device__ __forceinline__ LdsDrawsCall(uint32_t *lds_row, uint32_t *block, uint32_t pos_, uint32_t pretw_)
@@ -443,6 +466,21 @@ struct LdsDrawsCall {
             const uint2 r = refill(row, blk, pos, pretw, cur, filled);
             pos = r.x; pretw = r.y; cur = 0; filled = true;
         }
+    }
+    // The same two entry points for streams that twist ahead (the env's record keeps a ready mark, mt_ready_encode): the W words
+    // after the cursor are made ready first — whole 32-word chunks, wave-convergent — so the fill is plain loads and the flush
+    // writes nothing.  `active`: lanes that own a live env.  Call with all lanes of the wave.
+    __device__ __forceinline__ void fill_ahead(bool active) {
+        LdsDraws<W> d(row, blk, pos, pretw);
+        d.cur = cur; d.filled = filled;
+        d.flush();
+        mt_make_ready(blk, d.pos, d.pretw, (uint32_t)W, active, &old0);
+        d.fill_ready();
+        pos = d.pos; pretw = d.pretw; cur = 0; filled = true;
+    }
+    __device__ __forceinline__ void ensure_ahead(uint32_t need, bool active) {
+        const bool shortfall = !filled || (uint32_t)W - cur < need;
+        if (__ballot(shortfall) != 0ull) fill_ahead(active);
     }
     __device__ __forceinline__ void fill_inline() {            // fill() expanded in place (one site per kernel)
         LdsDraws<W> d(row, blk, pos, pretw);

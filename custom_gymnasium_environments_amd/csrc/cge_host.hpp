@@ -94,6 +94,44 @@ int snapshot_set(H *h, const void *host, hipStream_t s) {
     return CGE_OK;
 }
 
+// device stream (block, cursor, ready mark) -> CPython layout (624 words of ONE generation + index of the next unconsumed word).
+// Words [pos, pretw) are twisted already; the rest of the generation is twisted here.  A ready mark beyond 624 means the first
+// chunk of the NEXT generation has been twisted in place as well (cge_device.hpp: mt_make_ready): those words are taken back
+// to the current generation first — the twist is invertible word by word: new[k] ^ cur[k+397] = g(y) with y = (cur[k] & 0x80000000)
+// | (cur[k+1] & 0x7fffffff), and g(y) = (y >> 1) ^ (y & 1 ? 0x9908b0df : 0) gives y back (bit 31 of g(y) is y's bit 0).  What cannot
+// be recovered, the low 31 bits of cur[0], no future output depends on.
+// old0: the saved word 0 of the current generation (its dead low bits), or nullptr: then they read as zero.
+inline void mt_export_cpython(const uint32_t *w, uint32_t pos, uint32_t pretw, uint32_t *omt, int32_t *idx, const uint32_t *old0 = nullptr) {
+    memcpy(omt, w, 624 * 4);
+    // a cursor that has just wrapped (pos 0) with chunks of the new generation already twisted: CPython regenerates lazily, its
+    // state at this point is index 624 over the OLD generation — the same un-twist, seen from the end of that generation
+    if (pos == 0u && pretw > 0u && pretw < 624u) { pos = 624u; pretw += 624u; }
+    if (pretw > 624u) {
+        const uint32_t ahead = pretw - 624u;         // words [0, ahead) belong to the next generation
+        std::vector<uint32_t> y(ahead);
+        for (uint32_t k = 0; k < ahead; ++k) {
+            const uint32_t g = omt[k] ^ omt[k + 397];          // k + 397 < 624: a word of the current generation
+            const uint32_t odd = g >> 31;
+            y[k] = (((g ^ (odd ? 0x9908b0dfu : 0u)) << 1) | odd);
+        }
+        for (uint32_t k = 0; k < ahead; ++k) {
+            const uint32_t upper = y[k] & 0x80000000u, lower = k ? (y[k - 1] & 0x7fffffffu) : (old0 ? *old0 & 0x7fffffffu : 0u);
+            omt[k] = upper | lower;
+        }
+        omt[ahead] = (omt[ahead] & 0x80000000u) | (y[ahead - 1] & 0x7fffffffu);   // (its low bits were never changed: a consistency no-op)
+        pretw = 624;
+    }
+    if (pretw >= 624u) { *idx = (int32_t)pos; return; }
+    if (pos == 0 && pretw == 0) { *idx = 624; return; }
+    for (uint32_t k = pretw > pos ? pretw : pos; k < 624u; ++k) {
+        const uint32_t k1 = k + 1 == 624u ? 0 : k + 1, km = k + 397 >= 624u ? k + 397 - 624 : k + 397;
+        const uint32_t t = (omt[k] & 0x80000000u) | (omt[k1] & 0x7fffffffu);
+        omt[k] = omt[km] ^ (t >> 1) ^ ((t & 1u) ? 0x9908b0dfu : 0u);
+    }
+    *idx = (int32_t)pos;
+}
+
+
 // Seeds n MT19937 stream blocks (cge_device.hpp layout, `stride_words` apart starting at `mt`).
 //   kind 0: CPython random.seed(s)  = init_by_array(32-bit limbs of s)
 //   kind 1: NumPy legacy np.random.seed(s) = init_genrand((uint32)s)

@@ -1117,39 +1117,6 @@ int cge_crypto_info(cge_crypto *h, int32_t field_id, double *out, void *stream) 
 
 size_t cge_crypto_state_bytes(const cge_crypto *h) { return h ? 12 * 4 + 6 * 8 + 2 * MT_N * 4 + crypto::HLEN * 5 * 8 : 0; }
 
-// device stream (block, cursor, ready mark) -> CPython layout (624 words of ONE generation + index of the next unconsumed word).
-// Words [pos, pretw) are twisted already; the rest of the generation is twisted here.  A ready mark beyond 624 means the first
-// chunk of the NEXT generation has been twisted in place as well (cge_device.hpp: mt_make_ready): those words are taken back
-// to the current generation first — the twist is invertible word by word: new[k] ^ cur[k+397] = g(y) with y = (cur[k] & 0x80000000)
-// | (cur[k+1] & 0x7fffffff), and g(y) = (y >> 1) ^ (y & 1 ? 0x9908b0df : 0) gives y back (bit 31 of g(y) is y's bit 0).  What cannot
-// be recovered, the low 31 bits of cur[0], no future output depends on.
-static void export_mt(const uint32_t *w, uint32_t pos, uint32_t pretw, uint32_t *omt, int32_t *idx) {
-    memcpy(omt, w, MT_N * 4);
-    if (pretw > (uint32_t)MT_N) {
-        const uint32_t ahead = pretw - (uint32_t)MT_N;         // words [0, ahead) belong to the next generation
-        std::vector<uint32_t> y(ahead);
-        for (uint32_t k = 0; k < ahead; ++k) {
-            const uint32_t g = omt[k] ^ omt[k + MT_M];          // k + 397 < 624: a word of the current generation
-            const uint32_t odd = g >> 31;
-            y[k] = (((g ^ (odd ? 0x9908b0dfu : 0u)) << 1) | odd);
-        }
-        for (uint32_t k = 0; k < ahead; ++k) {
-            const uint32_t upper = y[k] & 0x80000000u, lower = k ? (y[k - 1] & 0x7fffffffu) : 0u;
-            omt[k] = upper | lower;
-        }
-        omt[ahead] = (omt[ahead] & 0x80000000u) | (y[ahead - 1] & 0x7fffffffu);   // (its low bits were never changed: a consistency no-op)
-        pretw = MT_N;
-    }
-    if (pretw >= (uint32_t)MT_N) { *idx = (int32_t)pos; return; }
-    if (pos == 0 && pretw == 0) { *idx = MT_N; return; }
-    for (uint32_t k = pretw > pos ? pretw : pos; k < (uint32_t)MT_N; ++k) {
-        const uint32_t k1 = k + 1 == (uint32_t)MT_N ? 0 : k + 1, km = k + MT_M >= (uint32_t)MT_N ? k + MT_M - MT_N : k + MT_M;
-        const uint32_t t = (omt[k] & 0x80000000u) | (omt[k1] & 0x7fffffffu);
-        omt[k] = omt[km] ^ (t >> 1) ^ ((t & 1u) ? 0x9908b0dfu : 0u);
-    }
-    *idx = (int32_t)pos;
-}
-
 int cge_crypto_get_state(cge_crypto *h, void *host_buf, void *stream) {
     if (!h || !host_buf) return CGE_ERR_INVALID_ARG;
     DeviceGuard g(h->device);
@@ -1172,8 +1139,8 @@ int cge_crypto_get_state(cge_crypto *h, void *host_buf, void *stream) {
         int32_t hd[12] = {(int32_t)e.regime, (int32_t)e.step, (int32_t)e.needs_reset, (int32_t)e.cash_kind,
                           0, 0, (int32_t)e.has_gauss, (int32_t)e.episodes, 0, 0, 0, 0};
         double scv[6] = {e.cash, e.holdings, e.psych, e.trend, e.gauss, e.ep_return};   // [5]: episode return so far
-        export_mt(&mp[(size_t)i * MT_STRIDE], e.ppos, e.ppretw, (uint32_t *)(p + 96), &hd[4]);
-        export_mt(&ml[(size_t)i * MT_STRIDE], e.lpos, e.lpretw, (uint32_t *)(p + 96 + MT_N * 4), &hd[5]);
+        mt_export_cpython(&mp[(size_t)i * MT_STRIDE], e.ppos, e.ppretw, (uint32_t *)(p + 96), &hd[4]);
+        mt_export_cpython(&ml[(size_t)i * MT_STRIDE], e.lpos, e.lpretw, (uint32_t *)(p + 96 + MT_N * 4), &hd[5]);
         memcpy(p, hd, 48);
         memcpy(p + 48, scv, 48);
         double *hh = (double *)(p + 96 + 2 * MT_N * 4);

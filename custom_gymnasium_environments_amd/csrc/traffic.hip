@@ -38,8 +38,8 @@ struct Lay {
     static constexpr int NI = NI_;
     static constexpr int NQ = 4 * NI;
     static constexpr int OBS = 14 * NI + 4;                    // environment.py:108-121
-    // state words: lights (8 bits each) | queues | passed (16 bits each) | total_wait | m0 m1 episodes total_reward(2)
-    static constexpr int O_Q = (NI + 3) / 4, O_P = O_Q + NQ, O_TW = O_P + (NI + 1) / 2, O_M = O_TW + NI, NW = O_M + 5;
+    // state words: lights (8 bits each) | queues | passed (16 bits each) | total_wait | m0 m1 episodes total_reward(2) mt_old0
+    static constexpr int O_Q = (NI + 3) / 4, O_P = O_Q + NQ, O_TW = O_P + (NI + 1) / 2, O_M = O_TW + NI, NW = O_M + 6;
     static constexpr int COLS = (NW + 3) / 4;                  // uint4 columns per env (15 for NI = 9)
     static constexpr int NCH = NI <= 4 ? 3 : NI <= 9 ? 5 : 6;  // step(): obs chunks staged through LDS
     static constexpr int CW = OBS / NCH;                       // dwords per chunk (20 / 26 / 38)
@@ -92,6 +92,7 @@ struct Env {
     uint32_t q[NQ];         // len:7 | dest:7 << 7 | wait:18 << 14, queue 4*i + dir
     uint32_t passed[NI], tw[NI];
     uint32_t timestep, nveh, needs_reset, episodes, mt_pos, mt_pretw;
+    uint32_t mt_old0;       // word 0 of the generator's current generation once the next one has overwritten it (mt_twist_chunk)
     double total_reward;
 
     __host__ __device__ __forceinline__ void unpack(const uint32_t *raw) {
@@ -105,10 +106,11 @@ struct Env {
         for (int i = 0; i < NI; ++i) tw[i] = raw[L::O_TW + i];
         const uint32_t m0 = raw[L::O_M], m1 = raw[L::O_M + 1];
         timestep = m0 & 0xFFFFu; nveh = (m0 >> 16) & 127u; needs_reset = (m0 >> 23) & 1u;
-        mt_pos = m1 & 1023u; mt_pretw = (m1 & 1024u) ? (uint32_t)MT_N : 0u;
+        mt_pos = m1 & 1023u; mt_pretw = mt_ready_decode((m1 >> 10) & 31u);     // ready mark of the twist-ahead stream (cge_device.hpp)
         episodes = raw[L::O_M + 2];
         const uint64_t u = ((uint64_t)raw[L::O_M + 4] << 32) | raw[L::O_M + 3];
         memcpy(&total_reward, &u, 8);
+        mt_old0 = raw[L::O_M + 5];
     }
     __host__ __device__ __forceinline__ void pack(uint32_t *raw) const {
 #pragma unroll
@@ -124,11 +126,12 @@ struct Env {
 #pragma unroll
         for (int i = 0; i < NI; ++i) raw[L::O_TW + i] = tw[i];
         raw[L::O_M] = timestep | (nveh << 16) | (needs_reset << 23);
-        raw[L::O_M + 1] = mt_pos | (mt_pretw ? 1024u : 0u);
+        raw[L::O_M + 1] = mt_pos | ((mt_pretw > mt_pos ? mt_ready_encode(mt_pretw) : 0u) << 10);
         raw[L::O_M + 2] = episodes;
         uint64_t u;
         memcpy(&u, &total_reward, 8);
         raw[L::O_M + 3] = (uint32_t)u; raw[L::O_M + 4] = (uint32_t)(u >> 32);
+        raw[L::O_M + 5] = mt_old0;
 #pragma unroll
         for (int j = L::NW; j < COLS * 4; ++j) raw[j] = 0;
     }
@@ -210,7 +213,7 @@ __device__ unsigned long long g_timing[4096 * 16];
 template <int NI, class DRAWS>
 __device__ __forceinline__ bool env_step(Env<NI> &e, const Cfg &c, const uint32_t (&a)[NI], DRAWS &d, double &reward TICK_ARG) {
     e.timestep += 1;
-    d.ensure_inline(12);
+    d.ensure_ahead(12, true);
     TICK(1);                                                                      // typical step: 1-2 light timers + a spawn with 1-4 hops
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -399,6 +402,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
     Env<NI> e;
     e.load(p.state, p.n, li);
     LdsDrawsCall<W> d(draws + (threadIdx.x & 63u) * DROW, p.mt + li * MT_STRIDE, e.mt_pos, e.mt_pretw);
+    d.old0 = e.mt_old0;
     const uint64_t key = ROLLOUT ? hash_env_key(p.a_seed, (uint64_t)(p.env0 + li)) : 0;
     double rsum = 0.0;
     int32_t dcount = 0;
@@ -422,7 +426,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
                     for (int j = 0; j < NI; ++j) a[j] = hash_action_from_key(key, (uint64_t)(p.t0 + t), 3u, (uint32_t)j);
                 }
                 TICK(0);
-                if (!ROLLOUT && e.nveh < (uint32_t)p.cfg.max_vehicles) d.fill_inline();      // a spawn attempt always draws: fetch the window now
+                (void)0;
                 term = env_step<NI>(e, p.cfg, a, d, reward TICK_PASS);
                 if (!ROLLOUT) d.flush();                          // a rollout keeps its window across steps
                 if (term) {
@@ -458,7 +462,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
     }
     if (live) {
         if (ROLLOUT) d.flush();                                   // the rollout's window is written back once, here
-        e.mt_pos = d.pos; e.mt_pretw = d.pretw;
+        e.mt_pos = d.pos; e.mt_pretw = d.pretw; e.mt_old0 = d.old0;
         e.store(p.state, p.n, i);
         if (ROLLOUT) {
             if (p.reward_sum) p.reward_sum[i] = rsum;
@@ -536,17 +540,17 @@ struct Ops {
     void (*reset)(const Params &, unsigned, hipStream_t);
     void (*rewind)(uint4 *, int64_t, hipStream_t);
     void (*info)(const uint4 *, int64_t, int, int, int32_t *, double *, hipStream_t);
-    void (*to_record)(const uint32_t *raw, int32_t *hd, double *total_reward, int32_t *w, uint32_t *mt_pos, uint32_t *mt_pretw);
+    void (*to_record)(const uint32_t *raw, int32_t *hd, double *total_reward, int32_t *w, uint32_t *mt_pos, uint32_t *mt_pretw, uint32_t *mt_old0);
     void (*from_record)(const int32_t *hd, double total_reward, const int32_t *w, uint32_t *raw);
 };
 
 // device record <-> the canonical record's fields (w: phase[ni], timer[ni], passed[ni], total_wait[ni], qlen, qdest, qwait [4 ni])
 template <int NI>
-void to_record(const uint32_t *raw, int32_t *hd, double *total_reward, int32_t *w, uint32_t *mt_pos, uint32_t *mt_pretw) {
+void to_record(const uint32_t *raw, int32_t *hd, double *total_reward, int32_t *w, uint32_t *mt_pos, uint32_t *mt_pretw, uint32_t *mt_old0) {
     Env<NI> e;
     e.unpack(raw);
     hd[0] = (int32_t)e.timestep; hd[1] = (int32_t)e.nveh; hd[2] = (int32_t)e.needs_reset; hd[3] = 0; hd[4] = (int32_t)e.episodes; hd[5] = 0;
-    *total_reward = e.total_reward; *mt_pos = e.mt_pos; *mt_pretw = e.mt_pretw;
+    *total_reward = e.total_reward; *mt_pos = e.mt_pos; *mt_pretw = e.mt_pretw; *mt_old0 = e.mt_old0;
     for (int k = 0; k < NI; ++k) { w[k] = (int32_t)(e.light[k] & 3u); w[NI + k] = (int32_t)(e.light[k] >> 2); w[2 * NI + k] = (int32_t)e.passed[k]; w[3 * NI + k] = (int32_t)e.tw[k]; }
     for (int k = 0; k < 4 * NI; ++k) { w[4 * NI + k] = (int32_t)(e.q[k] & QM); w[8 * NI + k] = (int32_t)((e.q[k] >> QS_DEST) & QM); w[12 * NI + k] = (int32_t)(e.q[k] >> QS_WAIT); }
 }
@@ -769,21 +773,9 @@ int cge_traffic_get_state(cge_traffic *h, void *host_buf, void *stream) {
         int32_t hd[6];
         int32_t *w = (int32_t *)(p + 32);
         double total_reward;
-        uint32_t mt_pos, mt_pretw;
-        h->ops.to_record(raw.data(), hd, &total_reward, w, &mt_pos, &mt_pretw);
-        uint32_t *omt = (uint32_t *)(w + 16 * ni);
-        const uint32_t *src = &mt[(size_t)i * MT_STRIDE];
-        memcpy(omt, src, MT_N * 4);
-        if (mt_pretw >= (uint32_t)MT_N) hd[3] = (int32_t)mt_pos;
-        else if (mt_pos == 0) hd[3] = MT_N;
-        else {
-            for (uint32_t k = mt_pos; k < (uint32_t)MT_N; ++k) {
-                const uint32_t k1 = k + 1 == (uint32_t)MT_N ? 0 : k + 1, km = k + MT_M >= (uint32_t)MT_N ? k + MT_M - MT_N : k + MT_M;
-                const uint32_t t = (omt[k] & 0x80000000u) | (omt[k1] & 0x7fffffffu);
-                omt[k] = omt[km] ^ (t >> 1) ^ ((t & 1u) ? 0x9908b0dfu : 0u);
-            }
-            hd[3] = (int32_t)mt_pos;
-        }
+        uint32_t mt_pos, mt_pretw, mt_old0;
+        h->ops.to_record(raw.data(), hd, &total_reward, w, &mt_pos, &mt_pretw, &mt_old0);
+        mt_export_cpython(&mt[(size_t)i * MT_STRIDE], mt_pos, mt_pretw, (uint32_t *)(w + 16 * ni), &hd[3], &mt_old0);
         memcpy(p, hd, 24);
         memcpy(p + 24, &total_reward, 8);
     }

@@ -1,21 +1,23 @@
 import sys, numpy as np, torch
 sys.path.insert(0, '.')
 import custom_gymnasium_environments_amd as cge, oracle
-np.set_printoptions(linewidth=250, precision=2, suppress=True)
-n=70
-for ctor in [dict(), dict(grid_size=(3,3), num_intersections=4), dict(grid_size=(6,6), num_intersections=16, max_vehicles=80)]:
-    env = cge.TrafficVectorEnv(n, autoreset_mode="SameStep", **ctor)
-    o = oracle.TrafficOracle(n, oracle.SAME_STEP, **ctor)
-    o.seed(np.arange(n, dtype=np.uint64)+np.uint64(3)); o.reset()
-    o.rollout(37, 5)
-    env.set_state(o.get_state())
-    od = env.reset(options={"reset_mask": np.zeros(n, np.uint8)})[0].cpu().numpy()
-    oo = o.reset(mask=np.zeros(n, np.uint8))
-    bad = np.argwhere(od != oo)
-    print(ctor, "staged obs mismatches", len(bad), sorted(set(bad[:,1].tolist())))
-    if len(bad):
-        i = bad[0][0]
-        print("dev", od[i]); print("orc", oo[i])
-    ob, rs, dc = env.rollout(1, action_seed=1)
-    oo, ro, do = o.rollout(1, 1)
-    print("own-row obs eq", np.array_equal(ob.cpu().numpy(), oo))
+n = 2048 + 9
+env = cge.TrafficVectorEnv(n, autoreset_mode="SameStep", env_index0=77)
+o = oracle.TrafficOracle(n, oracle.SAME_STEP)
+o.seed(np.arange(n, dtype=np.uint64) + np.uint64(77 + 1))
+env.reset(seed=1); o.reset()
+env.rollout(700, action_seed=9); o.rollout(700, 9, env0=77)
+env.rollout(500, action_seed=9, t0=700); o.rollout(500, 9, t0=700, env0=77)
+a = env.get_state(); b = o.get_state()
+bad = np.argwhere(a != b)
+print("mismatching bytes", len(bad), "envs", len(set(bad[:,0].tolist())))
+ni = 9
+off_mt = 32 + 16*ni*4
+for i in sorted(set(bad[:,0].tolist()))[:6]:
+    cols = bad[bad[:,0]==i][:,1]
+    words = sorted(set(((cols - off_mt)//4).tolist()))
+    hd_a = a[i,:24].view(np.int32); hd_b = b[i,:24].view(np.int32)
+    print("env", i, "idx dev/orc", hd_a[3], hd_b[3], "byte cols", cols.min(), cols.max(), "mt words", words[:12], len(words))
+    wa = a[i, off_mt:off_mt+2496].view(np.uint32); wb = b[i, off_mt:off_mt+2496].view(np.uint32)
+    for w in words[:4]:
+        if 0 <= w < 624: print("   word", w, hex(wa[w]), hex(wb[w]))
