@@ -396,6 +396,16 @@ struct LdsDraws {
         else if (cur == (uint32_t)W) { flush(); fill(); }
         return mt_temper(row[cur++]);
     }
+    // Twist-ahead form of ensure() (the env's record keeps a ready mark, mt_ready_encode): the window is refilled only when a lane
+    // runs low, from words made ready a 32-word chunk at a time — plain loads, and nothing to write back on the way out.
+    __device__ __forceinline__ void ensure_ahead(uint32_t need, bool active) {
+        const bool shortfall = !filled || (uint32_t)W - cur < need;
+        if (__ballot(shortfall) != 0ull) {
+            flush();
+            mt_make_ready(blk, pos, pretw, (uint32_t)W, active);
+            fill_ready();
+        }
+    }
     // Wave-convergent top-up: refill ALL active lanes as soon as ANY of them has fewer than `need` words left.  Without
     // it the lanes' cursors drift apart and every draw site ends up refilling (a ~500-instruction path plus a memory round
     // trip) for some lane; one call at the top of a step bounds that to one refill per wave-step.

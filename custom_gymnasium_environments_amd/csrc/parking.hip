@@ -75,7 +75,7 @@ struct Env {
         const uint32_t m0 = raw[60], m1 = raw[61], m2 = raw[62], m3 = raw[63];
         t = m0 & 0xFFFFu; qlen = (m0 >> 16) & 15u; lv0 = (m0 >> 20) & 3u; lv1 = (m0 >> 22) & 3u; lv2 = (m0 >> 24) & 3u;
         changes = (m0 >> 26) & 3u; needs_reset = (m0 >> 28) & 1u;
-        last_change = (int32_t)(m1 & 0xFFFFu) - 1000; mt_pos = (m1 >> 16) & 1023u; mt_pretw = (m1 & (1u << 26)) ? (uint32_t)MT_N : 0u;
+        last_change = (int32_t)(m1 & 0xFFFFu) - 1000; mt_pos = (m1 >> 16) & 1023u; mt_pretw = mt_ready_decode((m1 >> 26) & 31u);   // ready mark of the twist-ahead stream
         total_customers = m2 & 0xFFFFu; rejected = m2 >> 16; satisfied = m3 & 0xFFFFu; episodes = m3 >> 16;
         total_wait = raw[64];
         uint64_t u = ((uint64_t)raw[66] << 32) | raw[65];
@@ -91,7 +91,7 @@ struct Env {
 #pragma unroll
         for (int k = 0; k < QMAX; ++k) raw[50 + k] = q[k];
         raw[60] = (t & 0xFFFFu) | (qlen << 16) | (lv0 << 20) | (lv1 << 22) | (lv2 << 24) | (changes << 26) | (needs_reset << 28);
-        raw[61] = ((uint32_t)(last_change + 1000) & 0xFFFFu) | (mt_pos << 16) | (mt_pretw ? (1u << 26) : 0u);
+        raw[61] = ((uint32_t)(last_change + 1000) & 0xFFFFu) | (mt_pos << 16) | ((mt_pretw > mt_pos ? mt_ready_encode(mt_pretw) : 0u) << 26);
         raw[62] = (total_customers & 0xFFFFu) | (rejected << 16);
         raw[63] = (satisfied & 0xFFFFu) | (episodes << 16);
         raw[64] = total_wait;
@@ -341,9 +341,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
                 reset_now = true;
             } else {
                 const int32_t a = p.actions ? p.actions[(int64_t)t * p.n + i] : (int32_t)hash_action_from_key(key, (uint64_t)(p.t0 + t), 8u, 0u);
-                d.fill();                                            // the arrival test draws every step
+                d.ensure_ahead(10, true);                            // the arrival test draws every step; the window outlives the step
                 term = env_step(e, p.max_steps, a, d, reward);
-                d.flush();
                 e.ep_return += reward;
                 if (term) {
                     e.episodes += 1;
@@ -372,6 +371,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
         }
     }
     if (live) {
+        d.flush();                                                // advances the cursor; the consumed words were ready: nothing is stored
         e.mt_pos = d.pos; e.mt_pretw = d.pretw;
         e.store(p.state, p.n, i);
         if (ROLLOUT) {
