@@ -608,7 +608,10 @@ struct LdsBulkDraws {
 // where LdsDraws<W> refetches the whole window (and re-reads every 128-byte line it straddles) whenever it runs low.
 // ensure() is the wave-convergent top-up for the top of a step; after it at least W - MT_PAD + 1 words are parked.
 // Same (pos, pretw) cursor contract as the other queues: pos is the stream position of the ring's base.
-template <int W>
+// AHEAD: the stream twists ahead of its cursor in 32-word chunks (the env's record keeps a ready mark, mt_ready_encode): every run the
+// ring fetches is made ready first (mt_make_ready, wave-convergent), so a fetch is plain loads — no words 397 ahead, no twist —
+// and a consumed run is never written back.
+template <int W, bool AHEAD = false>
 struct RingDraws {
     static_assert(W % MT_PAD == 0 && W >= 2 * MT_PAD && W + 2 * MT_PAD <= MT_N - MT_M, "whole runs; the two runs fetched ahead are independent of the parked ones");
     static constexpr int NRUN = W / MT_PAD;
@@ -656,6 +659,25 @@ struct RingDraws {
     // NB runs per round trip: loads of all of them first, then twist and park
     template <int NB>
     __device__ __forceinline__ void fill_runs(uint32_t slot0, uint32_t logical, uint32_t nruns) {
+        if constexpr (AHEAD) {                                 // the runs are ready: plain loads
+            uint32_t a[NB][MT_PAD];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                uint32_t start = logical + (uint32_t)(b * MT_PAD);
+                start -= start >= (uint32_t)MT_N ? MT_N : 0;
+                if ((uint32_t)b < nruns) mt_load_run<MT_PAD>(blk + start, a[b]);
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                if ((uint32_t)b < nruns) {
+                    uint32_t sl = slot0 + (uint32_t)(b * MT_PAD);
+                    sl -= sl >= (uint32_t)W ? W : 0;
+#pragma unroll
+                    for (int j = 0; j < MT_PAD; ++j) row[sl + j] = a[b][j];
+                }
+            }
+            return;
+        }
         MtWindow<MT_PAD> w[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
@@ -675,6 +697,7 @@ struct RingDraws {
     }
     __device__ __forceinline__ void fill_all() {
         constexpr int NB = 3;
+        if constexpr (AHEAD) mt_make_ready(blk, pos, pretw, (uint32_t)(W + 2 * MT_PAD), true);
 #pragma unroll 1
         for (int r = 0; r < NRUN; r += NB)
             fill_runs<NB>((uint32_t)(r * MT_PAD), pos + (uint32_t)(r * MT_PAD), (uint32_t)(NRUN - r < NB ? NRUN - r : NB));
@@ -683,6 +706,7 @@ struct RingDraws {
     // every completely consumed run is written back and replaced by the run W words ahead, two runs per round trip
     __device__ __forceinline__ void top_up() {
         if (!filled) { fill_all(); return; }
+        if constexpr (AHEAD) mt_make_ready(blk, pos, pretw, cur + (uint32_t)(W + 2 * MT_PAD) < 224u ? cur + (uint32_t)(W + 2 * MT_PAD) : 224u, true);
 #pragma unroll 1
         while (cur >= (uint32_t)MT_PAD) {
             const uint32_t n = cur >= 2u * MT_PAD ? 2u : 1u;

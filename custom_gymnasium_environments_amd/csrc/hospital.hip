@@ -42,7 +42,8 @@ constexpr int RING = 3008;
 // flush loop and a memory round trip each) per wave-step.
 constexpr int DW = 112, DROW = DW + 1;
 constexpr uint32_t STEP_WORDS = 88;         // what a step is guaranteed to find parked after the top-up (<= DW - 15)
-using Draws = RingDraws<DW>;
+using Draws = RingDraws<DW>;                // (RingDraws<DW, true>, the twist-ahead form, measured in round 3: rollout 177-181 -> 184-185 us per
+                                            // 131,072-env step, step() unchanged — this kernel is not bound by its generator traffic; not used)
 
 // sub-queues: 0 (E,3) 1 (E,4) 2 (E,5) 3 (ICU,5) 4 (WARD,1) 5 (WARD,2)
 __host__ __device__ constexpr int q_cap(int k) { return k == 0 ? 512 : k == 1 ? 256 : k == 2 ? 64 : k == 3 ? 128 : 1024; }
