@@ -57,6 +57,15 @@ def test_eight_types_coresident_on_eight_streams(oracle):
             oo, ro, do = o.rollout(K // 2, ASEED, t0=K // 2, env0=lo)
             assert _obs_equal(name, _np(obs_co[lo:lo + 512]), oo), (name, lo)
             assert np.array_equal(_np(dc_co[lo:lo + 512]), do), (name, lo)
+            # reward sums against the ORACLE too (they were only compared with the solo run): exact for every type whose
+            # rewards are exact; crypto within its stated reward tolerance summed over the 100 steps, at most one diverged env
+            rs_dev = _np(rs_co[lo:lo + 512]).astype(np.float64)
+            if name == "Crypto":
+                assert int((np.abs(rs_dev - ro) > 1e-2 * (K // 2) * 1e-2 + 1e-6 * np.abs(ro)).sum()) <= 1, (name, lo)
+            elif name == "Climate":                             # float64 dynamics through device libm: tests/test_climate_gpu.py's reward tolerance
+                assert np.allclose(rs_dev, ro, rtol=1e-9, atol=1e-4 * (K // 2)), (name, lo)
+            else:
+                assert np.array_equal(rs_dev, np.asarray(ro, np.float64).astype(_np(rs_co).dtype).astype(np.float64)), (name, lo)
         # (b) the same type alone on the device, default stream
         solo = getattr(cge, name + "VectorEnv")(N, autoreset_mode="SameStep", reuse_buffers=True, **kw)
         solo.reset(seed=SEED)
