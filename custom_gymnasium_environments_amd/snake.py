@@ -52,7 +52,7 @@ class SnakeVectorEnv(DeviceVectorEnv):
         h = C.c_void_p()
         st = self._lib.cge_snake_create(C.byref(cfg), self.num_envs, self._dev_index, self.env_index0, C.byref(h))
         if st == -3:
-            raise ValueError(f"grid_size={grid_size} is not compiled into libcge_amd.so (supported: 6, 8, 10, 12, 16, 20)")
+            raise ValueError(f"grid_size={grid_size} is not compiled into libcge_amd.so (supported: every size from 4 to 30)")
         _native.check(st, what="cge_snake_create")
         self._h = h
         self._obs_shape = (self.num_envs, self.grid_size, self.grid_size)

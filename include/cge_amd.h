@@ -78,7 +78,8 @@ uint32_t cge_hash_action(uint64_t a_seed, uint64_t env, uint64_t t, uint32_t n, 
 typedef struct cge_snake cge_snake;
 
 typedef struct {
-    int32_t grid_size;      /* reference default 20 (snake_env.py:19); BASELINE configs use 10 */
+    int32_t grid_size;      /* reference default 20 (snake_env.py:19); BASELINE configs use 10; any size from 4 to 30 is compiled in
+                             * (other sizes: CGE_ERR_UNSUPPORTED) */
     int32_t max_steps;      /* reference: 1000 (snake_env.py:47); 0 -> 1000; <= 4095 for grid 10, <= 65535 otherwise */
     int32_t autoreset_mode; /* CGE_AUTORESET_* */
     int32_t reserved;

@@ -160,3 +160,5 @@ if __name__ == "__main__":
     make("snake_g20_greedy", 20, 8, 1500, "greedy", seed0=5000, a_seed=9, eps=0.03)
     # short horizon: the time limit (snake_env.py:113-114) fires every 9 steps, often on a step that also eats (:101-104)
     make("snake_g10_short", 10, 64, 300, "greedy", seed0=7000, a_seed=11, eps=0.05, max_steps=9)
+    # an odd grid, the one the reference's own test_visualization.py:17 builds
+    make("snake_g15_greedy", 15, 8, 1200, "greedy", seed0=9000, a_seed=13, eps=0.04)

@@ -21,7 +21,7 @@ def _replay(oracle, fx, mode):
 
 
 # snake_g10_short: max_steps=9, so the time limit (snake_env.py:113-114) often fires on a step that also eats (:101-104, 228 times)
-@pytest.mark.parametrize("name", ["snake_g10_hash.npz", "snake_g10_greedy.npz", "snake_g20_greedy.npz", "snake_g10_short.npz"])
+@pytest.mark.parametrize("name", ["snake_g10_hash.npz", "snake_g10_greedy.npz", "snake_g20_greedy.npz", "snake_g10_short.npz", "snake_g15_greedy.npz"])
 def test_same_step_autoreset_matches_reference(oracle, name):
     fx = golden(name)
     o, A, n, T, reset_at = _replay(oracle, fx, oracle.SAME_STEP)

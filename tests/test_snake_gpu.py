@@ -23,7 +23,7 @@ def _np(t):
 
 
 # snake_g10_short: max_steps=9 — the time limit often fires on a step that also eats (two food placements in one SameStep step)
-@pytest.mark.parametrize("name", ["snake_g10_hash.npz", "snake_g10_greedy.npz", "snake_g20_greedy.npz", "snake_g10_short.npz"])
+@pytest.mark.parametrize("name", ["snake_g10_hash.npz", "snake_g10_greedy.npz", "snake_g20_greedy.npz", "snake_g10_short.npz", "snake_g15_greedy.npz"])
 def test_same_step_matches_reference_fixture(cge, name):
     fx = golden(name)
     grid = int(fx["grid"])
@@ -52,7 +52,9 @@ def test_same_step_matches_reference_fixture(cge, name):
 
 
 @pytest.mark.parametrize("mode", ["NextStep", "SameStep", "Disabled"])
-@pytest.mark.parametrize("grid,n", [(10, 1000), (6, 77), (16, 130), (20, 65)])
+# every grid_size the library compiles (4..30): even and odd, below and above the 144-cell switch to 64-thread workgroups, grids whose
+# obs row is narrower than a digit ring (4, 5), the reference scripts' 15 (test_visualization.py:17) and the largest
+@pytest.mark.parametrize("grid,n", [(10, 1000), (6, 77), (16, 130), (20, 65), (15, 200), (4, 70), (5, 129), (7, 300), (13, 66), (23, 65), (30, 70)])
 def test_step_matches_oracle_all_modes(cge, oracle, mode, grid, n):
     code = {"NextStep": oracle.NEXT_STEP, "SameStep": oracle.SAME_STEP, "Disabled": oracle.DISABLED}[mode]
     env = cge.SnakeVectorEnv(n, grid_size=grid, autoreset_mode=mode, env_index0=5)
@@ -324,3 +326,40 @@ def test_set_state_rejects_malformed_records(cge, oracle):
         with pytest.raises(cge.NativeLibraryError):
             env.set_state(bad)
     env.close()
+
+
+@pytest.mark.parametrize("grid", [15, 5, 9, 27])
+def test_odd_and_unusual_grids_rollout_render_and_state(cge, oracle, grid):
+    """Odd grids keep padded LDS rows and stream them out through a realigning copy: the fused rollout (trajectory and last-obs
+    forms, ragged last wave), rgb_array and the state round trip against the oracle."""
+    n = 64 * 3 + 11
+    env = cge.SnakeVectorEnv(n, grid_size=grid, autoreset_mode="SameStep", env_index0=3)
+    o = oracle.SnakeOracle(n, grid, oracle.SAME_STEP)
+    o.seed(np.arange(n, dtype=np.uint64) + np.uint64(3 + 8))
+    obs, _ = env.reset(seed=8)
+    assert np.array_equal(_np(obs), o.reset())
+    obs, rs, dc = env.rollout(300, action_seed=5, t0=0)
+    oo, ro, do = o.rollout(300, 5, t0=0, env0=3)
+    assert np.array_equal(_np(obs), oo) and np.array_equal(_np(rs), ro) and np.array_equal(_np(dc), do)
+    rgb = _np(env.render_rgb())
+    exp = np.zeros((n, grid, grid, 3), np.uint8)
+    exp[oo == 1] = (0, 255, 0); exp[oo == 2] = (255, 0, 0)                  # snake_env.py:175-188
+    assert np.array_equal(rgb, exp)
+    twin = cge.SnakeVectorEnv(n, grid_size=grid, autoreset_mode="SameStep", env_index0=3)
+    twin.set_state(env.get_state())
+    o2 = oracle.SnakeOracle(n, grid, oracle.SAME_STEP)
+    o2.set_state(env.get_state())
+    acts = torch.randint(0, 4, (40, n), dtype=torch.int32, device="cuda")
+    traj, rt, tt, rs, dc = env.rollout(40, actions=acts, trajectory=True, per_step=True)
+    for t in range(40):
+        ob, r, te, _, info = twin.step(acts[t])
+        oo, ro, teo, _, fo = o2.step(_np(acts[t]), want_final=True)
+        assert torch.equal(ob, traj[t]) and torch.equal(r, rt[t]) and torch.equal(te, tt[t]), t
+        assert np.array_equal(_np(ob), oo) and np.array_equal(_np(info["final_obs"])[teo.astype(bool)], fo[teo.astype(bool)]), t
+    env.close(); twin.close()
+
+
+def test_grid_sizes_outside_4_to_30_are_refused(cge):
+    for g in (3, 31, 64):
+        with pytest.raises(ValueError, match="grid_size"):
+            cge.SnakeVectorEnv(4, grid_size=g)
