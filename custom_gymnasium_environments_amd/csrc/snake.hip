@@ -596,10 +596,16 @@ __device__ __forceinline__ bool finish_deferred(Env<G> &e, const Params &p, int6
 template <int CELLS, int ROW_DW>
 __device__ __forceinline__ void store_rows_realign(const uint32_t *rows, int8_t *dst, uint32_t nrows, uint32_t tid, uint32_t nthreads) {
     const uint8_t *rb = reinterpret_cast<const uint8_t *>(rows);
-    const uint32_t total = nrows * (uint32_t)CELLS, ndw = total >> 2;
-    uint32_t *d1 = reinterpret_cast<uint32_t *>(dst);            // 4-byte aligned: row 0 of a wave / workgroup starts at a multiple of 64 rows
+    auto src = [&](uint32_t b) { const uint32_t r = b / (uint32_t)CELLS; return rb[r * (uint32_t)(ROW_DW * 4) + (b - r * (uint32_t)CELLS)]; };
+    const uint32_t total = nrows * (uint32_t)CELLS;
+    // the destination need not be dword aligned (a [k, N, G, G] trajectory with N*G*G odd): `head` bytes up to the first aligned
+    // dword and the bytes behind the last whole one are written one by one
+    const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u), head0 = mis ? 4u - mis : 0u, head = head0 < total ? head0 : total;
+    const uint32_t ndw = (total - head) >> 2;
+    uint32_t *d1 = reinterpret_cast<uint32_t *>(dst + head);
     for (uint32_t q = tid; q < ndw; q += nthreads) {
-        uint32_t r = (4u * q) / (uint32_t)CELLS, c = 4u * q - r * (uint32_t)CELLS, w = 0;
+        const uint32_t b0 = head + 4u * q;
+        uint32_t r = b0 / (uint32_t)CELLS, c = b0 - r * (uint32_t)CELLS, w = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             w |= (uint32_t)rb[r * (uint32_t)(ROW_DW * 4) + c] << (8 * k);
@@ -607,8 +613,10 @@ __device__ __forceinline__ void store_rows_realign(const uint32_t *rows, int8_t 
         }
         d1[q] = w;
     }
-    if (tid == 0)
-        for (uint32_t b = ndw << 2; b < total; ++b) { const uint32_t r = b / (uint32_t)CELLS; dst[b] = (int8_t)rb[r * (uint32_t)(ROW_DW * 4) + (b - r * (uint32_t)CELLS)]; }
+    if (tid == 0) {
+        for (uint32_t b = 0; b < head; ++b) dst[b] = (int8_t)src(b);
+        for (uint32_t b = head + (ndw << 2); b < total; ++b) dst[b] = (int8_t)src(b);
+    }
 }
 
 // One wave streams its own 64 obs rows (FULL contiguous bytes) from LDS to HBM: (ds_read_b128, global_store_dwordx4) pairs at
@@ -1166,7 +1174,7 @@ int cge_snake_rollout(cge_snake *h, int32_t k_steps, const int32_t *actions, uin
                       float *reward_sum_out, int32_t *done_count_out, void *stream) {
     if (!h) return CGE_ERR_INVALID_ARG;
     if (k_steps < 0 || obs_step_stride < 0 || (obs_step_stride != 0 && obs_step_stride < h->n * h->ops.cells) ||
-        (obs_step_stride & 3))
+        ((obs_step_stride & 3) && h->ops.cells % 4 == 0))          // (odd grids: a step's N*G*G bytes need not be a multiple of 4)
         return h->fail(CGE_ERR_INVALID_ARG, "cge_snake_rollout: bad k_steps / obs_step_stride");
     if (k_steps == 0) return CGE_OK;
     DeviceGuard g(h->device);
