@@ -328,14 +328,16 @@ __device__ __forceinline__ void stage_chunk(const Env<NI> &e, const ObsTotals &t
     ((row[Js] = __float_as_uint(obs_val<NI, BASE + Js>(e, t))), ...);
 }
 
-// OWN rows: chunk C of 32 values (or the last OBS % 32) straight from registers
+// OWN rows: chunk C of OWN_CH values (or the last OBS % OWN_CH) straight from registers.  (Chunks of 16 or 8 values leave the
+// rollout kernel at 195-197 VGPRs, round 3: the register peak is in env_step, not here.)
+constexpr int OWN_CH = 32;
 template <int NI, int C>
 __device__ __forceinline__ void own_chunks(const Env<NI> &e, const ObsTotals &t, float *row, bool mine) {
-    constexpr int OBS = Lay<NI>::OBS, N = OBS - 32 * C < 32 ? OBS - 32 * C : 32;
+    constexpr int OBS = Lay<NI>::OBS, N = OBS - OWN_CH * C < OWN_CH ? OBS - OWN_CH * C : OWN_CH;
     if constexpr (N > 0) {
         float out[N];
-        fill_chunk<NI, C * 32>(e, t, out, std::make_integer_sequence<int, N>{});
-        store_own_row<N>(row, C * 32, out, mine);
+        fill_chunk<NI, C * OWN_CH>(e, t, out, std::make_integer_sequence<int, N>{});
+        store_own_row<N>(row, C * OWN_CH, out, mine);
         own_chunks<NI, C + 1>(e, t, row, mine);
     }
 }
