@@ -140,11 +140,13 @@ __device__ __forceinline__ uint32_t mt_twist_chunk(uint32_t *__restrict__ blk, u
 }
 // Makes words [pos, pos + need) ready (pos < 624, need <= 227).  Wave-convergent: as long as any lane of the wave is short, the
 // short lanes twist their next chunk (a round per 32 words); call it with all lanes of the wave.
+// `slack`: when some lane is short, lanes that would be short within `slack` more words twist their next chunk in the same round —
+// the lanes of a wave consume at similar rates, so this turns "some lane, nearly every step" into "most lanes, every few steps".
 __device__ __forceinline__ void mt_make_ready(uint32_t *__restrict__ blk, uint32_t pos, uint32_t &pretw, uint32_t need, bool active = true,
-                                              uint32_t *old0 = nullptr) {
+                                              uint32_t *old0 = nullptr, uint32_t slack = 0u) {
 #pragma unroll 1
     while (__ballot(active && pos + need > pretw)) {
-        const bool go = active && pos + need > pretw;
+        const bool go = active && pos + need + slack > pretw;
         const uint32_t t = mt_twist_chunk(blk, pretw > pos ? pretw : pos, go, old0);
         if (go) pretw = t;
     }

@@ -585,25 +585,38 @@ __device__ __forceinline__ void ratio_rows_resident(const HistLds &hist, int old
     inv_lds[lane] = 1.0 / closes[lane];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const uint32_t q_end = (uint32_t)env_hi * (uint32_t)HLEN;
-#pragma unroll 1
-    for (uint32_t q0 = (uint32_t)env_lo * (uint32_t)HLEN; q0 < q_end; q0 += 64u) {
-        const uint32_t q = q0 + lane < q_end ? q0 + lane : q_end - 1u;
-        const uint32_t env = q / (uint32_t)HLEN, cand = q - env * (uint32_t)HLEN;
-        const uint32_t f = flagsv[env];
+    // two pairs per iteration (their LDS reads and float64 multiplies interleave: this wave is alone on its SIMD), (env, candle)
+    // carried incrementally: 64 pairs further on is one env and 14 candles further on
+    uint32_t q = (uint32_t)env_lo * (uint32_t)HLEN + lane;
+    uint32_t env = q / (uint32_t)HLEN, cand = q - env * (uint32_t)HLEN;
+    auto one = [&](uint32_t qq, uint32_t ev, uint32_t cd) {
+        const bool in = qq < q_end;
+        const uint32_t e2 = in ? ev : (uint32_t)env_hi - 1u, c2 = in ? cd : 0u;
+        const uint32_t f = flagsv[e2];
         const uint32_t dest = to_obs_only ? DEST_OBS : (f >> 2) & 3u;
         float *base = dest == DEST_FINAL ? base_final : base_obs;
-        const bool want = q0 + lane < q_end && (f & need) == need && dest != DEST_NONE && base != nullptr;
-        int slot = oldest + (int)cand;
+        const bool want = in && (f & need) == need && dest != DEST_NONE && base != nullptr;
+        int slot = oldest + (int)c2;
         slot -= slot >= HLEN ? HLEN : 0;
-        const double x = hist.lcb[HistLds::at(slot, env)];
-        const float4 o = hist.lob[HistLds::at(slot, env)];
-        const double inv = inv_lds[env];
+        const double x = hist.lcb[HistLds::at(slot, e2)];
+        const float4 o = hist.lob[HistLds::at(slot, e2)];
+        const double inv = inv_lds[e2];
         const float v[5] = {(float)((double)o.x * inv), (float)((double)o.y * inv), (float)((double)o.z * inv), (float)(x * inv), (float)((double)o.w * inv)};
         if (want) {
-            float *dstp = base + (int64_t)env * OBS + 5u * cand;
+            float *dstp = base + (int64_t)e2 * OBS + 5u * c2;
             *reinterpret_cast<Piece16 *>(dstp) = Piece16{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
             dstp[4] = v[4];
         }
+    };
+    auto advance = [&](uint32_t &ev, uint32_t &cd) { cd += 64u - (uint32_t)HLEN; ev += 1u; if (cd >= (uint32_t)HLEN) { cd -= (uint32_t)HLEN; ev += 1u; } };
+#pragma unroll 1
+    for (; q - lane < q_end; q += 128u) {
+        uint32_t env1 = env, cand1 = cand;
+        advance(env1, cand1);
+        one(q, env, cand);
+        one(q + 64u, env1, cand1);
+        env = env1; cand = cand1;
+        advance(env, cand);
     }
 }
 
@@ -709,9 +722,15 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
             const int next_phase = phase + 1 == HLEN ? 0 : phase + 1;
             lds_barrier();                                     // bar1
             lds_barrier();                                     // bar2
+#ifdef CGE_CRYPTO_TIMING
+            if (role == 2u) { t_last = wall_clock64(); }
+#endif
             float *base_obs = p.obs ? p.obs + (int64_t)t * p.obs_step_stride + i0 * OBS : nullptr;
             float *base_final = p.final_obs ? p.final_obs + i0 * OBS : nullptr;
             ratio_rows_resident(hist, next_phase, mailu - lane, mail - lane + 192, inv_scratch, 0u, base_obs, base_final, false, env_lo, env_hi);
+#ifdef CGE_CRYPTO_TIMING
+            if (role == 2u) { TICK(6); }
+#endif
             if (*waveflag) {
                 full_barrier();                                 // bar3: the pre-reset rows have been read out of the window
                 full_barrier();                                 // bar4: the fresh windows are in LDS
@@ -815,7 +834,7 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
         }
         // the next step's words (the cursor is final): a chunk twist every ~3 steps, in wave A's slack before bar1, then a plain load.
         // After the launch's last step the twist still happens (the next launch then starts with nothing but the load).
-        mt_make_ready(blkP, e.ppos, e.ppretw, WP, stepped);
+        mt_make_ready(blkP, e.ppos, e.ppretw, WP, stepped, nullptr, 2u * WP);
         if (t + 1 < p.k_steps && stepped) mt_load_run<WP>(blkP + e.ppos, pw);
         TICK(0);
         lds_barrier();                                          // bar1: B is done with window(t-1), C's gaussian for this step is in LDS

@@ -9,7 +9,7 @@ L = ctypes.CDLL(_native.LIB_PATH)
 env = cge.CryptoVectorEnv(1 << 20, device="cuda:0")
 env.reset(seed=1)
 buf = (ctypes.c_ulonglong * 8)()
-names = ["A: first half of step t+1 (trade, P draws)", "A: waiting at bar1", "A: second half (price, candle) + publish + bar2", "A: per-step outputs", "B: waiting for window(t) (bar1 + bar2)", "B: observation of step t"]
+names = ["A: first half of step t+1 (trade, P draws)", "A: waiting at bar1", "A: second half (price, candle) + publish + bar2", "A: per-step outputs", "B: waiting for window(t) (bar1 + bar2)", "B: observation of step t", "C: ratio rows of step t (issue time, stores not awaited)"]
 import sys
 acts = torch.randint(0, 5, (16, 1 << 20), dtype=torch.int32, device="cuda")
 for chunk in range(4):
