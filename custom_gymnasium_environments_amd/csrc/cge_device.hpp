@@ -333,6 +333,12 @@ struct LdsDraws {
     }
     __device__ __forceinline__ void flush() {
         if (!filled) return;
+        if (pos + cur <= pretw) {                              // every consumed word was ready (twist-ahead streams): nothing to write back
+            uint32_t p = pos + cur;
+            if (p >= (uint32_t)MT_N) { p -= MT_N; pretw = mt_wrap_ready(pretw); }
+            pos = p; cur = 0; filled = false;
+            return;
+        }
         uint32_t j = 0;
         if constexpr (W > MT_PAD) {
             // whole runs of MT_PAD consumed words that lie clear of the mirror (words 0..15 <-> 624..639) and of the wrap go
