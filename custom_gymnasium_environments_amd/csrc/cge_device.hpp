@@ -944,6 +944,7 @@ __device__ __forceinline__ void store_tile(const uint32_t *tile, int8_t *dst, ui
 // transposition, no index arithmetic.  (Round 1 staged column chunks in LDS and wrote them dword by dword: for crypto 261 store
 // instructions and ~3,000 VALU of index arithmetic per wave and step.)
 struct __attribute__((packed, aligned(4))) Piece16 { uint32_t a, b, c, d; };
+struct __attribute__((packed, aligned(4))) Piece8 { uint32_t a, b; };
 
 template <int NF>
 __device__ __forceinline__ void store_own_row(float *row, int col0, const float (&v)[NF], bool mine) {

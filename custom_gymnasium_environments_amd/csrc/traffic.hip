@@ -41,14 +41,11 @@ struct Lay {
     // state words: lights (8 bits each) | queues | passed (16 bits each) | total_wait | m0 m1 episodes total_reward(2) mt_old0
     static constexpr int O_Q = (NI + 3) / 4, O_P = O_Q + NQ, O_TW = O_P + (NI + 1) / 2, O_M = O_TW + NI, NW = O_M + 6;
     static constexpr int COLS = (NW + 3) / 4;                  // uint4 columns per env (15 for NI = 9)
-    static constexpr int NCH = NI <= 4 ? 3 : NI <= 9 ? 5 : 6;  // step(): obs chunks staged through LDS
-    static constexpr int CW = OBS / NCH;                       // dwords per chunk (20 / 26 / 38)
-    static constexpr int ROW = CW | 1;                         // LDS row stride, odd
+    static constexpr int CW = 32, ROW = 33;                    // step(): obs staged through LDS 32 dwords at a time, odd row stride
     static constexpr int START_BITS = bitlen(NI);              // random.randint(0, NI-1): _randbelow(NI), k = NI.bit_length()
     static constexpr int HOPS = (NI < 5 ? NI : 5) - 1;         // route_length = randint(2, min(5, NI)) -> 1..HOPS hops (utils.py:181)
     static constexpr int HOP_BITS = bitlen(HOPS);
     static_assert(NI >= 2 && NI <= 16, "randint(2, min(5, NI)) needs NI >= 2; 16 intersections fill the register file");
-    static_assert(OBS % NCH == 0 && ROW > CW, "whole chunks, padded rows");
 };
 constexpr int DW = 16;             // MT words per draw-queue fill: one step() call
 constexpr int DWR = 48;            // fused rollout: a window lasts several steps, refilled wave-convergently (ensure)
@@ -341,24 +338,35 @@ __device__ __forceinline__ void own_chunks(const Env<NI> &e, const ObsTotals &t,
         own_chunks<NI, C + 1>(e, t, row, mine);
     }
 }
-// staged rows: chunk C of CW values through the wave's LDS tile, then coalesced dword stores
+// staged rows: 32 values at a time through the wave's LDS tile (row stride 33: the row writes and the reads below are both
+// conflict-free), then 16-byte stores — 8 lanes cover one row's 128 contiguous bytes, one instruction 8 rows — and the last
+// OBS % 32 values (always even) in 8-byte stores.  Rows start 8-byte aligned (OBS * 4 = 8 (7 NI + 2)).
 template <int NI, int C>
 __device__ __forceinline__ void staged_chunks(const Env<NI> &e, const ObsTotals &t, int64_t nrows, float *__restrict__ dst,
                                               unsigned long long rowmask, uint32_t *__restrict__ tile) {
     using L = Lay<NI>;
-    if constexpr (C < L::NCH) {
+    constexpr int N = L::OBS - L::CW * C < L::CW ? L::OBS - L::CW * C : L::CW;
+    if constexpr (N > 0) {
         const uint32_t lane = threadIdx.x & 63u;
-        uint32_t *row = tile + lane * L::ROW;
-        stage_chunk<NI, C * L::CW>(e, t, row, std::make_integer_sequence<int, L::CW>{});
+        stage_chunk<NI, C * L::CW>(e, t, tile + lane * L::ROW, std::make_integer_sequence<int, N>{});
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        {
-            uint32_t r = lane / (uint32_t)L::CW, col = lane - r * (uint32_t)L::CW;
-#pragma unroll 1
-            for (int m = 0; m < L::CW; ++m) {
-                if ((int64_t)r < nrows && ((rowmask >> r) & 1ull))
-                    reinterpret_cast<uint32_t *>(dst)[(int64_t)r * L::OBS + C * L::CW + col] = tile[r * L::ROW + col];
-                col += 64u % L::CW; r += 64u / L::CW;
-                if (col >= (uint32_t)L::CW) { col -= L::CW; r += 1u; }
+        uint32_t *out = reinterpret_cast<uint32_t *>(dst) + C * L::CW;
+        if constexpr (N == L::CW) {
+            const uint32_t seg = lane & 7u;
+#pragma unroll 2
+            for (uint32_t r = lane >> 3; r < 64u; r += 8u) {
+                const uint32_t *src = tile + r * L::ROW + seg * 4u;
+                const Piece16 v{src[0], src[1], src[2], src[3]};
+                if ((int64_t)r < nrows && ((rowmask >> r) & 1ull)) *reinterpret_cast<Piece16 *>(out + (int64_t)r * L::OBS + seg * 4u) = v;
+            }
+        } else {
+            constexpr uint32_t PAIRS = N / 2;
+            static_assert(N % 2 == 0, "14 NI + 4 is even");
+#pragma unroll 2
+            for (uint32_t k = lane; k < 64u * PAIRS; k += 64u) {
+                const uint32_t r = k / PAIRS, c2 = (k - r * PAIRS) * 2u;
+                const Piece8 v{tile[r * L::ROW + c2], tile[r * L::ROW + c2 + 1u]};
+                if ((int64_t)r < nrows && ((rowmask >> r) & 1ull)) *reinterpret_cast<Piece8 *>(out + (int64_t)r * L::OBS + c2) = v;
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -369,8 +377,8 @@ __device__ __forceinline__ void staged_chunks(const Env<NI> &e, const ObsTotals 
 // writes the wave's 64 obs rows (rows with their bit in rowmask) to dst (+ row*130 floats).
 // OWN (the fused rollout): every lane streams its own row in 16-byte stores straight from registers (cge_device.hpp:
 // store_own_row), 32 values at a time + the last two — 96 -> 77 us per 262,144-env rollout step (A/B on one box, round 2).
-// !OWN (step()): five 26-value chunks staged in LDS (row stride 27) and written with coalesced dword stores; the own-row form
-// was 5 % slower there (99 vs 95 us), where all waves of the launch reach their stores together.
+// !OWN (step()): staged in LDS 32 values at a time and written 8 rows per 16-byte store instruction (staged_chunks); the own-row
+// form is slower there (90.6 vs 81.3 us, round 3), where all waves of the launch reach their stores together.
 template <int NI, bool OWN>
 __device__ __forceinline__ void observe(const Env<NI> &e, int64_t nrows, float *__restrict__ dst, unsigned long long rowmask,
                                         uint32_t *__restrict__ tile) {
