@@ -5,17 +5,22 @@
 //   _update_production :381-425, _update_machine_status :427-462, _quality_control :464-480, _complete_product :482-500
 //   (its return value is discarded at :418), _calculate_timestep_rewards :502-531, _update_metrics :533-553,
 //   _check_termination :555-578, _update_supply_chain :580-595.
-// Fixed state per env: 84 dwords in 21 uint4 columns (PCG64, 5 stations incl. a cached copy of the product each is
-// working on, counters, thresholds, cached recent-quality means).  Variable state lives in per-env TABLES laid out
-// [slot][env] so that a wave walking slot s touches 64 consecutive values:
-//   pq/pm/pnext[320][N]  one row per product started in the episode (slot = product id; an episode can start at most
-//                        (250 + 29*99)/10 = 312): quality f64, {type, station+1, alive, remaining} u16, queue link u16
+// Fixed state per env: 88 dwords in 22 uint4 columns (PCG64, 5 stations incl. a cached copy of the product each is
+// working on, counters, thresholds, cached recent-quality means).  Variable state lives in per-env TABLES:
+//   pq/pm/pnext/pts[320][N]  one row per product started in the episode (row = product id; an episode can start at most
+//                        (250 + 29*99)/10 = 312), laid out [row][env]: quality f64 as of the product's last station exit,
+//                        {type, station+1, alive, remaining} u16, queue link u16, the product's place in its type list u16
+//   tq/tid[N][6][320]    per env and product type, the DENSE list of the qualities (f64) and ids (u16) of the products of
+//                        that type in the system, in list order, occupying places [head, head + count)
 //   comp[20][N]          ring of the last 20 completed qualities (:525, :552)
 //   hist[100][N]         ring of the last 100 quality_rate_history entries (:573-576)
 // The per-type quality means of the observation (:220-228) are np.mean over ALL products in the system in list order,
-// i.e. NumPy's pairwise summation: they are recomputed every step by a wave-uniform walk over the live slot range with
-// the 8 running accumulators of each type parked in LDS (bit-identical to the reference; a second pass handles a type
-// with more than 128 products, where NumPy's recursion splits the list).  Rewards are integers -> exact.
+// i.e. NumPy's pairwise summation, and the qualities of the products at the stations change every step: the means are
+// recomputed every step (bit-identical to the reference), which is why each type's qualities are kept dense — the sum is
+// then 8 register accumulators over 64-byte runs of one lane's own list, the next run loaded while the last is added.
+// A product leaves its list from (or near) the front: same-type products overtake nobody (FIFO queues, equal station times),
+// only products that were started while station 0 was down stay behind forever; the few older entries move up one place.
+// Rewards are integers -> exact.
 #include <cstring>
 #include <vector>
 
@@ -28,10 +33,10 @@ namespace mfg {
 
 constexpr int OBS = 73;
 constexpr int BLOCK = 64;
-constexpr int COLS = 21;
+constexpr int COLS = 22;
 constexpr int CAP = 320;
 constexpr uint32_t NONE = 1023u;
-constexpr int ACCROW = 55;          // f64 per lane in LDS: 6 types x (8 accumulators + running result) + pad
+constexpr int TROW = 6 * CAP;        // places per env in tq / tid
 constexpr uint32_t M_ALIVE = 1u << 6;
 enum : uint32_t { OPERATIONAL = 0, BROKEN = 1, MAINTENANCE = 2 };
 enum : uint32_t { BALANCED = 0, RUSH = 1, QUALITY = 2 };
@@ -39,7 +44,9 @@ enum : uint32_t { BALANCED = 0, RUSH = 1, QUALITY = 2 };
 struct Params {
     uint4 *state;
     double *pq;
-    uint16_t *pm, *pnext;
+    uint16_t *pm, *pnext, *pts;
+    double *tq;
+    uint16_t *tid;
     double *comp, *hist;
     int64_t n, env0;
     int32_t mode, max_steps, k_steps;
@@ -73,6 +80,7 @@ struct Env {
     uint32_t mode, emergency, disruption, disruption_cd, timestep, needs_reset, overflow, raw, energy, targets;
     uint32_t nprod, lo, ncomp, ngood, nscrap, nhist, cnt_lt, cnt_gt, episodes;
     uint64_t completed, qlen, cnt[5], nT, curm;
+    uint64_t th, curs;             // 9-bit fields: head place of each type's list; list place of the product at each station
     int32_t total_reward;
     double util[5], degr[5], curq[5], mean20, mean10, thr[3];
     uint32_t status[5], ops[5], cur[5], qhead[5], qtail[5];
@@ -104,6 +112,8 @@ struct Env {
         qlen = ((uint64_t)r[69] << 32) | r[68];
         nT = ((uint64_t)r[81] << 32) | r[80];
         curm = ((uint64_t)r[83] << 32) | r[82];
+        th = ((uint64_t)r[85] << 32) | r[84];
+        curs = ((uint64_t)r[87] << 32) | r[86];
     }
     __device__ __forceinline__ void pack(uint32_t (&r)[COLS * 4]) const {
         const uint64_t sl = (uint64_t)g.state, sh = (uint64_t)(g.state >> 64), il = (uint64_t)g.inc, ih = (uint64_t)(g.inc >> 64);
@@ -133,6 +143,8 @@ struct Env {
         r[68] = (uint32_t)qlen; r[69] = (uint32_t)(qlen >> 32);
         r[80] = (uint32_t)nT; r[81] = (uint32_t)(nT >> 32);
         r[82] = (uint32_t)curm; r[83] = (uint32_t)(curm >> 32);
+        r[84] = (uint32_t)th; r[85] = (uint32_t)(th >> 32);
+        r[86] = (uint32_t)curs; r[87] = (uint32_t)(curs >> 32);
     }
     __device__ __forceinline__ void load(const uint4 *__restrict__ s, int64_t n, int64_t i) {
         uint32_t r[COLS * 4];
@@ -151,13 +163,44 @@ struct Env {
     }
 };
 
-struct Tab {       // this env's column of every table
+struct Tab {       // this env's column of every [row][env] table, and its own block of the type lists
     double *pq;
-    uint16_t *pm, *pnext;
+    uint16_t *pm, *pnext, *pts;
+    double *tq;
+    uint16_t *tid;
     double *comp, *hist;
     int64_t n;
-    __device__ __forceinline__ Tab(const Params &p, int64_t i) : pq(p.pq + i), pm(p.pm + i), pnext(p.pnext + i), comp(p.comp + i), hist(p.hist + i), n(p.n) {}
+    __device__ __forceinline__ Tab(const Params &p, int64_t i)
+        : pq(p.pq + i), pm(p.pm + i), pnext(p.pnext + i), pts(p.pts + i), tq(p.tq + i * TROW), tid(p.tid + i * TROW), comp(p.comp + i), hist(p.hist + i), n(p.n) {}
 };
+
+// A product of `type` at place r of its list leaves the system (completed :482-500, scrapped :468-478): the older entries
+// [head, r) move up one place (none, when it is the oldest), the head advances.  `curs` follows for the products at the stations.
+__device__ __forceinline__ void list_remove(Env &e, const Tab &tb, uint32_t type, uint32_t r) {
+    const uint32_t head = fld9(e.th, type);
+    if (r != head) {
+        double *q = tb.tq + type * CAP;
+        uint16_t *id = tb.tid + type * CAP;
+#pragma unroll 1
+        for (uint32_t s = r; s > head;) {
+            const uint32_t m = s - head < 4u ? s - head : 4u;
+            double qv[4];
+            uint32_t iv[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) if (j < m) { qv[j] = q[s - 1u - j]; iv[j] = id[s - 1u - j]; }
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) if (j < m) { q[s - j] = qv[j]; id[s - j] = (uint16_t)iv[j]; tb.pts[(int64_t)iv[j] * tb.n] = (uint16_t)(s - j); }
+            s -= m;
+        }
+#pragma unroll
+        for (int S = 0; S < 5; ++S) {
+            const uint32_t cs = fld9(e.curs, S);
+            if (e.cur[S] != NONE && ((uint32_t)(e.curm >> (12 * S)) & 7u) == type && cs >= head && cs < r) e.curs += 1ull << (9 * S);
+        }
+    }
+    e.th += 1ull << (9u * type);
+    e.nT -= 1ull << (9u * type);
+}
 
 __device__ __forceinline__ double combine8(const double *a) { return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7])); }
 
@@ -227,7 +270,7 @@ __device__ __forceinline__ void do_reset(Env &e) {                              
         e.mcount[s] = (int32_t)e.g.integers(100, 200);
         e.cur[s] = NONE; e.qhead[s] = 0; e.qtail[s] = 0; e.degr[s] = 0.0; e.curq[s] = 0.0; e.cnt[s] = 0;
     }
-    e.qlen = 0; e.nT = 0; e.curm = 0; e.nprod = 0; e.lo = 0; e.ncomp = 0; e.ngood = 0; e.nscrap = 0; e.nhist = 0; e.cnt_lt = 0; e.cnt_gt = 0;
+    e.qlen = 0; e.nT = 0; e.curm = 0; e.th = 0; e.curs = 0; e.nprod = 0; e.lo = 0; e.ncomp = 0; e.ngood = 0; e.nscrap = 0; e.nhist = 0; e.cnt_lt = 0; e.cnt_gt = 0;
     e.thr[0] = 0.70; e.thr[1] = 0.80; e.thr[2] = 0.85;
     e.raw = 250;
     uint32_t tg = 0;
@@ -261,6 +304,7 @@ __device__ __forceinline__ void station_update(Env &e, const Tab &tb, bool &comp
             const uint32_t req = type == 5u ? 3u : type + 1u;                       // stations_required :35-40
             if (next < req) {
                 tb.pq[(int64_t)id * tb.n] = q;
+                tb.tq[type * CAP + fld9(e.curs, S)] = q;
                 tb.pm[(int64_t)id * tb.n] = (uint16_t)mk_meta(type, next + 1u, 1u, 0u);
                 if (S == 0 && csp1 == 0) {                                          // first visit ends: queued at station 0 again (:367, :410-415)
                     queue_push<0>(e, tb, id);
@@ -274,13 +318,13 @@ __device__ __forceinline__ void station_update(Env &e, const Tab &tb, bool &comp
                 tb.comp[(int64_t)(e.ncomp % 20u) * tb.n] = q;
                 e.ncomp += 1; e.ngood += q > 0.7 ? 1u : 0u;
                 tb.pm[(int64_t)id * tb.n] = (uint16_t)mk_meta(type, csp1, 0u, 0u);
-                e.nT -= 1ull << (9u * type);
+                list_remove(e, tb, type, fld9(e.curs, S));
                 e.cnt[S] -= 1ull << (9u * type);
                 completed_any = true;
             }
         } else {
             e.curq[S] = q;
-            tb.pq[(int64_t)id * tb.n] = q;                                          // the observation's per-type mean reads the table
+            tb.tq[type * CAP + fld9(e.curs, S)] = q;                                // the observation's per-type mean reads the list
             cm = (cm & 63u) | ((uint32_t)rem2 << 6);
             e.curm = (e.curm & ~(4095ull << (12 * S))) | ((uint64_t)cm << (12 * S));
         }
@@ -292,6 +336,7 @@ __device__ __forceinline__ void station_update(Env &e, const Tab &tb, bool &comp
         const uint32_t m = tb.pm[(int64_t)id * tb.n];
         const uint32_t cm = (m & 63u) | (((m >> 7) & 63u) << 6);
         e.curm = (e.curm & ~(4095ull << (12 * S))) | ((uint64_t)cm << (12 * S));
+        e.curs = (e.curs & ~(511ull << (9 * S))) | ((uint64_t)tb.pts[(int64_t)id * tb.n] << (9 * S));
         e.qlen -= 1ull << (9 * S);
         if (fld9(e.qlen, S) > 0) e.qhead[S] = tb.pnext[(int64_t)id * tb.n];
         e.util[S] = 0.8;
@@ -321,7 +366,7 @@ __device__ __forceinline__ void quality_check(Env &e, const Tab &tb, int32_t &re
     if (e.cur[S] != NONE && e.curq[S] < e.thr[C]) {
         const uint32_t cm = (uint32_t)(e.curm >> (12 * S)) & 4095u, type = cm & 7u;
         tb.pm[(int64_t)e.cur[S] * tb.n] = (uint16_t)mk_meta(type, (cm >> 3) & 7u, 0u, 0u);
-        e.nT -= 1ull << (9u * type);
+        list_remove(e, tb, type, fld9(e.curs, S));
         e.cnt[S] -= 1ull << (9u * type);
         e.cur[S] = NONE; e.nscrap += 1;
         reward -= 100;
@@ -337,8 +382,12 @@ __device__ __forceinline__ uint32_t env_step(Env &e, const Tab &tb, int32_t max_
             if (e.nprod < (uint32_t)CAP) {                                                            // _start_production :361-379
                 const uint32_t id = e.nprod, type = (uint32_t)action;
                 const double q = 0.85 + e.g.uniform(-0.1, 0.1);
+                const uint32_t place = fld9(e.th, type) + fld9(e.nT, type);             // < CAP: places are never reused within an episode
                 tb.pq[(int64_t)id * tb.n] = q;
                 tb.pm[(int64_t)id * tb.n] = (uint16_t)mk_meta(type, 0u, 1u, timesteps2(type));
+                tb.pts[(int64_t)id * tb.n] = (uint16_t)place;
+                tb.tq[type * CAP + place] = q;
+                tb.tid[type * CAP + place] = (uint16_t)id;
                 e.nT += 1ull << (9u * type);
                 if (e.status[0] == OPERATIONAL) queue_push<0>(e, tb, id);
                 e.nprod += 1;
@@ -427,108 +476,112 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
     return v;
 }
 
-// NumPy pairwise sum of the qualities of the `nt` products of `type` (nt > 128, rare): the recursion of
-// pairwise_sum splits the list into at most four leaves of <= 128 for nt <= 320; one more walk over the slots.
-__device__ __forceinline__ double big_type_sum(const Env &e, const Tab &tb, bool mine, uint32_t type, uint32_t nt, double *a, uint32_t smin, uint32_t smax) {
-    uint32_t b[5] = {0, 0, 0, 0, 0};          // leaf boundaries in the type's own index space, nleaf leaves
-    uint32_t nleaf = 0;
-    bool split_left = false, split_right = false;
-    if (mine) {
-        uint32_t n2 = nt / 2u; n2 -= n2 % 8u;
-        const uint32_t nr = nt - n2;
-        split_left = n2 > 128u; split_right = nr > 128u;
-        uint32_t k = 0;
-        b[k++] = 0;
-        if (split_left) { uint32_t h = n2 / 2u; h -= h % 8u; b[k++] = h; }
-        b[k++] = n2;
-        if (split_right) { uint32_t h = nr / 2u; h -= h % 8u; b[k++] = n2 + h; }
-        b[k] = nt;
-        nleaf = k;
-    }
-    double leafsum[4] = {0.0, 0.0, 0.0, 0.0};
-    uint32_t j = 0, leaf = 0;
-#pragma unroll 1
-    for (uint32_t s = smin; s < smax; ++s) {
-        const bool in = mine && s >= e.lo && s < e.nprod;
-        const uint32_t m = in ? tb.pm[(int64_t)s * tb.n] : 0u;
-        if (in && (m & M_ALIVE) && (m & 7u) == type) {
-            const double q = tb.pq[(int64_t)s * tb.n];
-            const uint32_t lo = sel(b, leaf), hi = sel(b, leaf + 1u);
-            const uint32_t n = hi - lo, jj = j - lo, nfull = n & ~7u;
-            if (jj < nfull) { if (jj < 8u) a[jj] = q; else a[jj & 7u] += q; }
-            else { const double res = jj == nfull ? (nfull ? combine8(a) : 0.0) : a[8]; a[8] = res + q; }
-            ++j;
-            if (j == hi) {                                                          // leaf finished
-                const double tot = (n & 7u) == 0u ? combine8(a) : a[8];
+// NumPy's pairwise_sum of n <= 128 values: fewer than 8 -> in order from 0.0; else 8 accumulators over the whole runs of 8,
+// combined, then the remainder in order (numpy/core/src/umath/loops_utils.h.src)
+__device__ __forceinline__ double leaf_sum(const double *a, uint32_t n) {
+    double res = 0.0;
+    uint32_t i = 0;
+    if (n >= 8u) {
+        double r[8];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) leafsum[k] = leaf == (uint32_t)k ? tot : leafsum[k];
-                ++leaf;
-            }
+        for (int k = 0; k < 8; ++k) r[k] = a[k];
+#pragma unroll 1
+        for (i = 8u; i < (n & ~7u); i += 8u) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) r[k] += a[i + k];
+        }
+        res = combine8(r);
+    }
+#pragma unroll 1
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+
+// ... of 128 < n <= 320 values (rare): the recursion halves the list (left half rounded down to a multiple of 8) until every
+// leaf has <= 128 — at most four leaves, two levels
+__device__ __forceinline__ double big_sum(const double *a, uint32_t n) {
+    uint32_t n2 = n / 2u; n2 -= n2 % 8u;
+    const uint32_t nr = n - n2;
+    double side[2];
+#pragma unroll 1
+    for (uint32_t h = 0; h < 2u; ++h) {
+        const double *x = h ? a + n2 : a;
+        const uint32_t m = h ? nr : n2;
+        if (m <= 128u) side[h] = leaf_sum(x, m);
+        else {
+            uint32_t m2 = m / 2u; m2 -= m2 % 8u;
+            const double l = leaf_sum(x, m2);
+            side[h] = l + leaf_sum(x + m2, m - m2);
         }
     }
-    (void)nleaf;
-    // tree: S(left) + S(right), each side one leaf or the sum of two
-    double left, right;
-    if (split_left) { left = leafsum[0] + leafsum[1]; right = split_right ? leafsum[2] + leafsum[3] : leafsum[2]; }
-    else { left = leafsum[0]; right = split_right ? leafsum[1] + leafsum[2] : leafsum[1]; }
-    return left + right;
+    return side[0] + side[1];
+}
+
+struct __attribute__((packed, aligned(8))) Pair { double a, b; };
+__device__ __forceinline__ void load_run(const double *p, double (&v)[8]) {       // one 64-byte run of a lane's own list
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const Pair x = *reinterpret_cast<const Pair *>(p + 2 * k); v[2 * k] = x.a; v[2 * k + 1] = x.b; }
 }
 
 // obs[50..55]: np.mean of quality_score per product type over products_in_system (:220-228), NumPy pairwise order.
-// Wave-uniform walk over the union of the lanes' live slot ranges; per lane 6 x (8 accumulators + result) in LDS.
-constexpr int WALK = 16;            // slots per round trip of the type_means walk
-__device__ __forceinline__ void type_means(Env &e, const Tab &tb, bool live, double *acc_lane, double (&mean)[6]) {
-    const uint32_t smin = wave_min(live ? e.lo : (uint32_t)CAP), smax = wave_max(live ? e.nprod : 0u);
-    uint64_t jc = 0;
-    uint32_t first_alive = e.nprod;
-    // 16 slots per round trip (8: 40 dependent trips per step once ~300 products have been started): the loads are unconditional (every slot row exists) and issued before the first use
-#pragma unroll 1
-    for (uint32_t s0 = smin; s0 < smax; s0 += (uint32_t)WALK) {
-        uint32_t mm[WALK];
-        double qq[WALK];
-#pragma unroll
-        for (int u = 0; u < WALK; ++u) {
-            const uint32_t sl = s0 + u < (uint32_t)CAP ? s0 + u : (uint32_t)CAP - 1u;
-            mm[u] = tb.pm[(int64_t)sl * tb.n];
-            qq[u] = tb.pq[(int64_t)sl * tb.n];
-        }
-#pragma unroll
-        for (int u = 0; u < WALK; ++u) {
-            const uint32_t s = s0 + u, m = mm[u];
-            const double q = qq[u];
-            if (live && s >= e.lo && s < e.nprod && (m & M_ALIVE)) {
-                first_alive = s < first_alive ? s : first_alive;
-                const uint32_t t = m & 7u, nt = fld9(e.nT, t), j = fld9(jc, t);
-                jc += 1ull << (9u * t);
-                if (nt <= 128u) {
-                    const uint32_t nfull = nt & ~7u;
-                    double *a = acc_lane + t * 9u;
-                    if (j < nfull) { if (j < 8u) a[j] = q; else a[j & 7u] += q; }
-                    else { const double res = j == nfull ? (nfull ? combine8(a) : 0.0) : a[8]; a[8] = res + q; }
-                }
-            }
-        }
-    }
-    if (live) e.lo = first_alive;
-    unsigned long long big = 0;
+// One pass over (type, run of 8 places) items whose count per type is the wave's longest list; the next item's run is loaded
+// before the current one is added, so the whole pass costs about one memory round trip plus the adds.
+__device__ __forceinline__ void type_means(const Env &e, const Tab &tb, bool live, double (&mean)[6]) {
+    uint64_t nruns = 0;                    // 6 bits per type, wave-uniform
+    unsigned big = 0;
 #pragma unroll
     for (int t = 0; t < 6; ++t) {
         const uint32_t nt = live ? fld9(e.nT, t) : 0u;
-        const double *a = acc_lane + t * 9;
-        double res = 0.0;
-        if (nt != 0u && nt <= 128u) res = (nt & 7u) == 0u ? combine8(a) : a[8];
-        mean[t] = nt ? res / (double)nt : 0.0;
-        big |= __ballot(nt > 128u) ? (1ull << t) : 0ull;
+        const bool isbig = nt > 128u;
+        if (__ballot(isbig) != 0ull) big |= 1u << t;
+        const uint32_t longest = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max(isbig ? 0u : nt));
+        nruns |= (uint64_t)((longest + 7u) / 8u) << (6 * t);
+        mean[t] = 0.0;
+    }
+    uint32_t t = 0;
+    while (t < 6u && ((nruns >> (6u * t)) & 63u) == 0u) ++t;
+    uint32_t c = 0;
+    double A[8], B[8], r[8], res = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { B[k] = 0.0; r[k] = 0.0; }
+    if (t < 6u) load_run(tb.tq + t * CAP + fld9(e.th, t), A);
+#pragma unroll 1
+    while (t < 6u) {
+        uint32_t t2 = t, c2 = c + 1u;
+        if (c2 == (uint32_t)((nruns >> (6u * t)) & 63u)) {
+            c2 = 0; ++t2;
+            while (t2 < 6u && ((nruns >> (6u * t2)) & 63u) == 0u) ++t2;
+        }
+        if (t2 < 6u) load_run(tb.tq + t2 * CAP + fld9(e.th, t2) + 8u * c2, B);
+        const uint32_t nt = live ? fld9(e.nT, t) : 0u, n = nt > 128u ? 0u : nt, nb = n >> 3, rem = n & 7u;
+        if (c < nb) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) r[k] = c == 0u ? A[k] : r[k] + A[k];
+        } else if (c == nb && rem != 0u) {
+            res = nb ? combine8(r) : 0.0;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) res = (uint32_t)k < rem ? res + A[k] : res;
+        }
+        if (c2 == 0u) {                                         // the type's last run: its mean
+            if (rem == 0u) res = nb ? combine8(r) : 0.0;
+            const double m = n ? res / (double)n : 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) mean[k] = t == (uint32_t)k ? m : mean[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) A[k] = B[k];
+        t = t2; c = c2;
     }
     if (big) {
 #pragma unroll 1
-        for (uint32_t t = 0; t < 6u; ++t) {
-            if (!((big >> t) & 1ull)) continue;
-            const uint32_t nt = live ? fld9(e.nT, t) : 0u;
-            const bool mine = nt > 128u;
-            const double tot = big_type_sum(e, tb, mine, t, nt, acc_lane, smin, smax);
+        for (uint32_t tt = 0; tt < 6u; ++tt) {
+            if (!((big >> tt) & 1u)) continue;
+            const uint32_t nt = live ? fld9(e.nT, tt) : 0u;
+            if (nt > 128u) {
+                const double m = big_sum(tb.tq + tt * CAP + fld9(e.th, tt), nt) / (double)nt;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) mean[k] = (mine && t == (uint32_t)k) ? tot / (double)nt : mean[k];
+                for (int k = 0; k < 6; ++k) mean[k] = tt == (uint32_t)k ? m : mean[k];
+            }
         }
     }
 }
@@ -556,12 +609,18 @@ __device__ __forceinline__ void stage_row(const Env &e, const double (&mean)[6],
 __device__ __forceinline__ void store_rows(int64_t nrows, float *__restrict__ dst, unsigned long long rowmask, const uint32_t *__restrict__ tile) {
     const uint32_t lane = threadIdx.x & 63u;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    uint32_t r = 0, col = lane;                                 // OBS = 73 > 64: lane walks the tile linearly
+    if (nrows == 64 && rowmask == ~0ull && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0u) {
+        // the wave's 64 rows are one contiguous 18,688-byte image, in LDS as in the destination: 1168 16-byte pieces
+#pragma unroll 5
+        for (uint32_t k = lane; k < (uint32_t)(64 * OBS / 4); k += 64u) reinterpret_cast<uint4 *>(dst)[k] = reinterpret_cast<const uint4 *>(tile)[k];
+    } else {
+        uint32_t r = 0, col = lane;                             // OBS = 73 > 64: lane walks the tile linearly
 #pragma unroll 1
-    for (int m = 0; m < OBS; ++m) {
-        if ((int64_t)r < nrows && ((rowmask >> r) & 1ull)) reinterpret_cast<uint32_t *>(dst)[(int64_t)r * OBS + col] = tile[r * OBS + col];
-        col += 64u;
-        if (col >= (uint32_t)OBS) { col -= OBS; r += 1u; }
+        for (int m = 0; m < OBS; ++m) {
+            if ((int64_t)r < nrows && ((rowmask >> r) & 1ull)) reinterpret_cast<uint32_t *>(dst)[(int64_t)r * OBS + col] = tile[r * OBS + col];
+            col += 64u;
+            if (col >= (uint32_t)OBS) { col -= OBS; r += 1u; }
+        }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
@@ -575,8 +634,7 @@ __device__ unsigned long long g_timing[2048 * 8];
 #endif
 template <bool ROLLOUT>
 __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
-    __shared__ double lds[64 * ACCROW];                        // accumulators during the slot walk, then the obs tile
-    uint32_t *tile = reinterpret_cast<uint32_t *>(lds);
+    __shared__ __attribute__((aligned(16))) uint32_t tile[64 * OBS];   // the wave's obs rows, staged for coalesced stores
     const int64_t i0 = (int64_t)blockIdx.x * BLOCK;
     const int64_t i = i0 + threadIdx.x;
     const bool live = i < p.n;
@@ -619,8 +677,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
         const unsigned long long fin_mask = __ballot(reset_now);
         if (want_obs || (fin_mask && p.final_obs)) {
             double mean[6];
-            type_means(e, tb, live, lds + lane * ACCROW, mean);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            type_means(e, tb, live, mean);
             TICK(2);
             if (fin_mask && p.final_obs) {
                 stage_row(e, mean, reinterpret_cast<float *>(tile) + lane * OBS);
@@ -662,8 +719,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
 
 // what: 0 = reset(mask) + obs, 1 = reseed the generators, 2 = fresh-handle state (generators seeded, nothing in the system)
 __global__ __launch_bounds__(BLOCK) void reset_kernel(Params p, int what) {
-    __shared__ double lds[64 * ACCROW];
-    uint32_t *tile = reinterpret_cast<uint32_t *>(lds);
+    __shared__ __attribute__((aligned(16))) uint32_t tile[64 * OBS];
     const int64_t i0 = (int64_t)blockIdx.x * BLOCK;
     const int64_t i = i0 + threadIdx.x;
     const bool live = i < p.n;
@@ -689,8 +745,7 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(Params p, int what) {
     }
     if (what == 0 && p.obs) {
         double mean[6];
-        type_means(e, tb, live, lds + lane * ACCROW, mean);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        type_means(e, tb, live, mean);
         stage_row(e, mean, reinterpret_cast<float *>(tile) + lane * OBS);
         store_rows(nrows, p.obs + i0 * OBS, ~0ull, tile);
     }
@@ -740,20 +795,21 @@ struct cge_manufacturing : HandleBase {
     cge_manufacturing_config cfg{};
     uint4 *state = nullptr;
     double *pq = nullptr, *comp = nullptr, *hist = nullptr;
-    uint16_t *pm = nullptr, *pnext = nullptr;
+    uint16_t *pm = nullptr, *pnext = nullptr, *pts = nullptr, *tid = nullptr;
+    double *tq = nullptr;
     static constexpr uint32_t snap_tag = 4u;
-    std::vector<std::pair<void *, size_t>> blobs() const { return {{state, (size_t)mfg::COLS * n * sizeof(uint4)}, {pq, (size_t)mfg::CAP * n * 8}, {pm, (size_t)mfg::CAP * n * 2}, {pnext, (size_t)mfg::CAP * n * 2}, {comp, (size_t)20 * n * 8}, {hist, (size_t)100 * n * 8}}; }
+    std::vector<std::pair<void *, size_t>> blobs() const { return {{state, (size_t)mfg::COLS * n * sizeof(uint4)}, {pq, (size_t)mfg::CAP * n * 8}, {pm, (size_t)mfg::CAP * n * 2}, {pnext, (size_t)mfg::CAP * n * 2}, {pts, (size_t)mfg::CAP * n * 2}, {tq, (size_t)mfg::TROW * n * 8}, {tid, (size_t)mfg::TROW * n * 2}, {comp, (size_t)20 * n * 8}, {hist, (size_t)100 * n * 8}}; }
     uint32_t snap_extra() const { return 0u; }
     void set_snap_extra(uint32_t v) { (void)v; }
     mfg::Params params() const {
         mfg::Params p{};
-        p.state = state; p.pq = pq; p.pm = pm; p.pnext = pnext; p.comp = comp; p.hist = hist;
+        p.state = state; p.pq = pq; p.pm = pm; p.pnext = pnext; p.pts = pts; p.tq = tq; p.tid = tid; p.comp = comp; p.hist = hist;
         p.n = n; p.env0 = env0; p.mode = cfg.autoreset_mode; p.max_steps = cfg.max_steps;
         p.ep_ret = ep_ret; p.ep_len = ep_len;
         return p;
     }
     unsigned blocks() const { return (unsigned)((n + mfg::BLOCK - 1) / mfg::BLOCK); }
-    void free_all() { (void)hipFree(state); (void)hipFree(pq); (void)hipFree(pm); (void)hipFree(pnext); (void)hipFree(comp); (void)hipFree(hist); }
+    void free_all() { (void)hipFree(state); (void)hipFree(pq); (void)hipFree(pm); (void)hipFree(pnext); (void)hipFree(pts); (void)hipFree(tq); (void)hipFree(tid); (void)hipFree(comp); (void)hipFree(hist); }
 };
 
 extern "C" {
@@ -783,15 +839,18 @@ int cge_manufacturing_create(const cge_manufacturing_config *cfg, int64_t n_envs
     DeviceGuard g(device);
     const size_t N = (size_t)n_envs;
     const size_t sb = (size_t)mfg::COLS * N * sizeof(uint4), qb = (size_t)mfg::CAP * N * 8, mb = (size_t)mfg::CAP * N * 2, cb = 20 * N * 8, hb = 100 * N * 8;
+    const size_t tqb = (size_t)mfg::TROW * N * 8 + 2048;       // + 2 KB: type_means reads whole runs, up to 128 places past a short list's end
     hipError_t e;
     if ((e = hipMalloc(&h->state, sb)) != hipSuccess || (e = hipMalloc(&h->pq, qb)) != hipSuccess || (e = hipMalloc(&h->pm, mb)) != hipSuccess ||
-        (e = hipMalloc(&h->pnext, mb)) != hipSuccess || (e = hipMalloc(&h->comp, cb)) != hipSuccess || (e = hipMalloc(&h->hist, hb)) != hipSuccess ||
+        (e = hipMalloc(&h->pnext, mb)) != hipSuccess || (e = hipMalloc(&h->pts, mb)) != hipSuccess ||
+        (e = hipMalloc(&h->tq, tqb)) != hipSuccess || (e = hipMalloc(&h->tid, (size_t)mfg::TROW * N * 2)) != hipSuccess ||
+        (e = hipMalloc(&h->comp, cb)) != hipSuccess || (e = hipMalloc(&h->hist, hb)) != hipSuccess ||
         (e = hipMemset(h->state, 0, sb)) != hipSuccess) {
         h->free_all();
         delete h;
         return CGE_ERR_HIP;
     }
-    h->device_bytes = sb + qb + 2 * mb + cb + hb;
+    h->device_bytes = sb + qb + 3 * mb + tqb + (size_t)mfg::TROW * N * 2 + cb + hb;
     mfg::Params p = h->params();                               // default generators: PCG64(SeedSequence(env_index0 + i)); no reset
     hipLaunchKernelGGL(mfg::reset_kernel, dim3(h->blocks()), dim3(mfg::BLOCK), 0, nullptr, p, 2);
     e = hipGetLastError();
