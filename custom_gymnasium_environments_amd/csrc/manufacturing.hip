@@ -10,14 +10,16 @@
 //   pq/pm/pnext/pts[320][N]  one row per product started in the episode (row = product id; an episode can start at most
 //                        (250 + 29*99)/10 = 312), laid out [row][env]: quality f64 as of the product's last station exit,
 //                        {type, station+1, alive, remaining} u16, queue link u16, the product's place in its type list u16
-//   tq/tid[N][6][320]    per env and product type, the DENSE list of the qualities (f64) and ids (u16) of the products of
-//                        that type in the system, in list order, occupying places [head, head + count)
+//   tq/tid[6][320][N]    per product type, the DENSE list of the qualities (f64) and ids (u16) of the products of that type
+//                        in the system, in list order, occupying places [head, head + count) — laid out [place][env] like the
+//                        other tables: lanes whose lists stand at the same places read one line (per-env contiguous lists,
+//                        64 scattered 64-byte runs per load, cost 1.3-1.8 us of latency per run, round 3)
 //   comp[20][N]          ring of the last 20 completed qualities (:525, :552)
 //   hist[100][N]         ring of the last 100 quality_rate_history entries (:573-576)
 // The per-type quality means of the observation (:220-228) are np.mean over ALL products in the system in list order,
 // i.e. NumPy's pairwise summation, and the qualities of the products at the stations change every step: the means are
 // recomputed every step (bit-identical to the reference), which is why each type's qualities are kept dense — the sum is
-// then 8 register accumulators over 64-byte runs of one lane's own list, the next run loaded while the last is added.
+// then 8 register accumulators over runs of 8 places, the next run loaded while the last is added.
 // A product leaves its list from (or near) the front: same-type products overtake nobody (FIFO queues, equal station times),
 // only products that were started while station 0 was down stay behind forever; the few older entries move up one place.
 // Rewards are integers -> exact.
@@ -163,7 +165,7 @@ struct Env {
     }
 };
 
-struct Tab {       // this env's column of every [row][env] table, and its own block of the type lists
+struct Tab {       // this env's column of every [row][env] table
     double *pq;
     uint16_t *pm, *pnext, *pts;
     double *tq;
@@ -171,7 +173,7 @@ struct Tab {       // this env's column of every [row][env] table, and its own b
     double *comp, *hist;
     int64_t n;
     __device__ __forceinline__ Tab(const Params &p, int64_t i)
-        : pq(p.pq + i), pm(p.pm + i), pnext(p.pnext + i), pts(p.pts + i), tq(p.tq + i * TROW), tid(p.tid + i * TROW), comp(p.comp + i), hist(p.hist + i), n(p.n) {}
+        : pq(p.pq + i), pm(p.pm + i), pnext(p.pnext + i), pts(p.pts + i), tq(p.tq + i), tid(p.tid + i), comp(p.comp + i), hist(p.hist + i), n(p.n) {}
 };
 
 // A product of `type` at place r of its list leaves the system (completed :482-500, scrapped :468-478): the older entries
@@ -179,17 +181,17 @@ struct Tab {       // this env's column of every [row][env] table, and its own b
 __device__ __forceinline__ void list_remove(Env &e, const Tab &tb, uint32_t type, uint32_t r) {
     const uint32_t head = fld9(e.th, type);
     if (r != head) {
-        double *q = tb.tq + type * CAP;
-        uint16_t *id = tb.tid + type * CAP;
+        double *q = tb.tq + (int64_t)(type * CAP) * tb.n;
+        uint16_t *id = tb.tid + (int64_t)(type * CAP) * tb.n;
 #pragma unroll 1
         for (uint32_t s = r; s > head;) {
             const uint32_t m = s - head < 4u ? s - head : 4u;
             double qv[4];
             uint32_t iv[4];
 #pragma unroll
-            for (uint32_t j = 0; j < 4u; ++j) if (j < m) { qv[j] = q[s - 1u - j]; iv[j] = id[s - 1u - j]; }
+            for (uint32_t j = 0; j < 4u; ++j) if (j < m) { qv[j] = q[(int64_t)(s - 1u - j) * tb.n]; iv[j] = id[(int64_t)(s - 1u - j) * tb.n]; }
 #pragma unroll
-            for (uint32_t j = 0; j < 4u; ++j) if (j < m) { q[s - j] = qv[j]; id[s - j] = (uint16_t)iv[j]; tb.pts[(int64_t)iv[j] * tb.n] = (uint16_t)(s - j); }
+            for (uint32_t j = 0; j < 4u; ++j) if (j < m) { q[(int64_t)(s - j) * tb.n] = qv[j]; id[(int64_t)(s - j) * tb.n] = (uint16_t)iv[j]; tb.pts[(int64_t)iv[j] * tb.n] = (uint16_t)(s - j); }
             s -= m;
         }
 #pragma unroll
@@ -304,7 +306,7 @@ __device__ __forceinline__ void station_update(Env &e, const Tab &tb, bool &comp
             const uint32_t req = type == 5u ? 3u : type + 1u;                       // stations_required :35-40
             if (next < req) {
                 tb.pq[(int64_t)id * tb.n] = q;
-                tb.tq[type * CAP + fld9(e.curs, S)] = q;
+                tb.tq[(int64_t)(type * CAP + fld9(e.curs, S)) * tb.n] = q;
                 tb.pm[(int64_t)id * tb.n] = (uint16_t)mk_meta(type, next + 1u, 1u, 0u);
                 if (S == 0 && csp1 == 0) {                                          // first visit ends: queued at station 0 again (:367, :410-415)
                     queue_push<0>(e, tb, id);
@@ -324,7 +326,7 @@ __device__ __forceinline__ void station_update(Env &e, const Tab &tb, bool &comp
             }
         } else {
             e.curq[S] = q;
-            tb.tq[type * CAP + fld9(e.curs, S)] = q;                                // the observation's per-type mean reads the list
+            tb.tq[(int64_t)(type * CAP + fld9(e.curs, S)) * tb.n] = q;                                // the observation's per-type mean reads the list
             cm = (cm & 63u) | ((uint32_t)rem2 << 6);
             e.curm = (e.curm & ~(4095ull << (12 * S))) | ((uint64_t)cm << (12 * S));
         }
@@ -386,8 +388,8 @@ __device__ __forceinline__ uint32_t env_step(Env &e, const Tab &tb, int32_t max_
                 tb.pq[(int64_t)id * tb.n] = q;
                 tb.pm[(int64_t)id * tb.n] = (uint16_t)mk_meta(type, 0u, 1u, timesteps2(type));
                 tb.pts[(int64_t)id * tb.n] = (uint16_t)place;
-                tb.tq[type * CAP + place] = q;
-                tb.tid[type * CAP + place] = (uint16_t)id;
+                tb.tq[(int64_t)(type * CAP + place) * tb.n] = q;
+                tb.tid[(int64_t)(type * CAP + place) * tb.n] = (uint16_t)id;
                 e.nT += 1ull << (9u * type);
                 if (e.status[0] == OPERATIONAL) queue_push<0>(e, tb, id);
                 e.nprod += 1;
@@ -476,109 +478,122 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
     return v;
 }
 
-// NumPy's pairwise_sum of n <= 128 values: fewer than 8 -> in order from 0.0; else 8 accumulators over the whole runs of 8,
-// combined, then the remainder in order (numpy/core/src/umath/loops_utils.h.src)
-__device__ __forceinline__ double leaf_sum(const double *a, uint32_t n) {
+// NumPy's pairwise_sum of n <= 128 values (stride `st` apart): fewer than 8 -> in order from 0.0; else 8 accumulators over the
+// whole runs of 8, combined, then the remainder in order (numpy/core/src/umath/loops_utils.h.src)
+__device__ __forceinline__ double leaf_sum(const double *a, int64_t st, uint32_t n) {
     double res = 0.0;
     uint32_t i = 0;
     if (n >= 8u) {
         double r[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) r[k] = a[k];
+        for (int k = 0; k < 8; ++k) r[k] = a[k * st];
 #pragma unroll 1
         for (i = 8u; i < (n & ~7u); i += 8u) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) r[k] += a[i + k];
+            for (int k = 0; k < 8; ++k) r[k] += a[(int64_t)(i + k) * st];
         }
         res = combine8(r);
     }
 #pragma unroll 1
-    for (; i < n; ++i) res += a[i];
+    for (; i < n; ++i) res += a[(int64_t)i * st];
     return res;
 }
 
 // ... of 128 < n <= 320 values (rare): the recursion halves the list (left half rounded down to a multiple of 8) until every
 // leaf has <= 128 — at most four leaves, two levels
-__device__ __forceinline__ double big_sum(const double *a, uint32_t n) {
+__device__ __forceinline__ double big_sum(const double *a, int64_t st, uint32_t n) {
     uint32_t n2 = n / 2u; n2 -= n2 % 8u;
     const uint32_t nr = n - n2;
     double side[2];
 #pragma unroll 1
     for (uint32_t h = 0; h < 2u; ++h) {
-        const double *x = h ? a + n2 : a;
+        const double *x = h ? a + (int64_t)n2 * st : a;
         const uint32_t m = h ? nr : n2;
-        if (m <= 128u) side[h] = leaf_sum(x, m);
+        if (m <= 128u) side[h] = leaf_sum(x, st, m);
         else {
             uint32_t m2 = m / 2u; m2 -= m2 % 8u;
-            const double l = leaf_sum(x, m2);
-            side[h] = l + leaf_sum(x + m2, m - m2);
+            const double l = leaf_sum(x, st, m2);
+            side[h] = l + leaf_sum(x + (int64_t)m2 * st, st, m - m2);
         }
     }
     return side[0] + side[1];
 }
 
-struct __attribute__((packed, aligned(8))) Pair { double a, b; };
-__device__ __forceinline__ void load_run(const double *p, double (&v)[8]) {       // one 64-byte run of a lane's own list
+// one run of 8 places of a lane's list from place `p0` of type block `tbase` (places past the table's end re-read its last row)
+__device__ __forceinline__ void load_run(const Tab &tb, uint32_t tbase, uint32_t p0, double (&v)[8]) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { const Pair x = *reinterpret_cast<const Pair *>(p + 2 * k); v[2 * k] = x.a; v[2 * k + 1] = x.b; }
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t pl = p0 + k < (uint32_t)CAP ? p0 + k : (uint32_t)CAP - 1u;
+        v[k] = tb.tq[(int64_t)(tbase + pl) * tb.n];
+    }
 }
 
-// obs[50..55]: np.mean of quality_score per product type over products_in_system (:220-228), NumPy pairwise order.
-// One pass over (type, run of 8 places) items whose count per type is the wave's longest list; the next item's run is loaded
-// before the current one is added, so the whole pass costs about one memory round trip plus the adds.
+// np.mean of the qualities of the products of type T (<= 128 of them; longer lists take big_sum): `nrun` = the wave's longest
+// such list in runs of 8.  F holds the list's first run (loaded by the previous type's call); this call loads type T + 1's
+// first run into N before anything else, and its own next run while the last one is added: the loads are unconditional (past
+// the last run they re-read run 0) so that the compiler's wait counters stay exact and never drain a prefetch.
+template <int T>
+__device__ __forceinline__ double type_mean(const Env &e, const Tab &tb, bool live, uint32_t nrun, double (&F)[8], double (&N)[8]) {
+    if constexpr (T < 5) load_run(tb, (T + 1) * CAP, fld9(e.th, T + 1), N);
+    const uint32_t nt = live ? fld9(e.nT, T) : 0u, n = nt > 128u ? 0u : nt, nb = n >> 3, rem = n & 7u;
+    if (nrun == 0u) return 0.0;
+    const uint32_t head = fld9(e.th, T);
+    double Y[8], r[8], res = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = 0.0;
+    const auto add_run = [&](const double (&V)[8], uint32_t c) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) asm volatile("" ::"v"(V[k]));   // the run counts as used on every path: a load the compiler thinks may still be pending makes it drain everything at the loop head
+        if (c < nb) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) r[k] += V[k];           // (0.0 + a == a exactly: qualities are positive)
+        } else if (c == nb && rem != 0u) {
+            res = nb ? combine8(r) : 0.0;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) res = (uint32_t)k < rem ? res + V[k] : res;
+        }
+    };
+    uint32_t c = 0;
+#pragma unroll 1
+    for (;;) {
+        load_run(tb, T * CAP, head + (c + 1u < nrun ? 8u * (c + 1u) : 0u), Y);
+        add_run(F, c);
+        if (++c >= nrun) break;
+        load_run(tb, T * CAP, head + (c + 1u < nrun ? 8u * (c + 1u) : 0u), F);
+        add_run(Y, c);
+        if (++c >= nrun) break;
+    }
+    if (rem == 0u) res = nb ? combine8(r) : 0.0;
+    return n ? res / (double)n : 0.0;
+}
+
+// obs[50..55]: np.mean of quality_score per product type over products_in_system (:220-228), NumPy pairwise order
 __device__ __forceinline__ void type_means(const Env &e, const Tab &tb, bool live, double (&mean)[6]) {
-    uint64_t nruns = 0;                    // 6 bits per type, wave-uniform
+    uint32_t nrun[6];                      // wave-uniform
     unsigned big = 0;
 #pragma unroll
     for (int t = 0; t < 6; ++t) {
         const uint32_t nt = live ? fld9(e.nT, t) : 0u;
         const bool isbig = nt > 128u;
         if (__ballot(isbig) != 0ull) big |= 1u << t;
-        const uint32_t longest = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max(isbig ? 0u : nt));
-        nruns |= (uint64_t)((longest + 7u) / 8u) << (6 * t);
-        mean[t] = 0.0;
+        nrun[t] = ((uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max(isbig ? 0u : nt)) + 7u) / 8u;
     }
-    uint32_t t = 0;
-    while (t < 6u && ((nruns >> (6u * t)) & 63u) == 0u) ++t;
-    uint32_t c = 0;
-    double A[8], B[8], r[8], res = 0.0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { B[k] = 0.0; r[k] = 0.0; }
-    if (t < 6u) load_run(tb.tq + t * CAP + fld9(e.th, t), A);
-#pragma unroll 1
-    while (t < 6u) {
-        uint32_t t2 = t, c2 = c + 1u;
-        if (c2 == (uint32_t)((nruns >> (6u * t)) & 63u)) {
-            c2 = 0; ++t2;
-            while (t2 < 6u && ((nruns >> (6u * t2)) & 63u) == 0u) ++t2;
-        }
-        if (t2 < 6u) load_run(tb.tq + t2 * CAP + fld9(e.th, t2) + 8u * c2, B);
-        const uint32_t nt = live ? fld9(e.nT, t) : 0u, n = nt > 128u ? 0u : nt, nb = n >> 3, rem = n & 7u;
-        if (c < nb) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) r[k] = c == 0u ? A[k] : r[k] + A[k];
-        } else if (c == nb && rem != 0u) {
-            res = nb ? combine8(r) : 0.0;
-#pragma unroll
-            for (int k = 0; k < 7; ++k) res = (uint32_t)k < rem ? res + A[k] : res;
-        }
-        if (c2 == 0u) {                                         // the type's last run: its mean
-            if (rem == 0u) res = nb ? combine8(r) : 0.0;
-            const double m = n ? res / (double)n : 0.0;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) mean[k] = t == (uint32_t)k ? m : mean[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) A[k] = B[k];
-        t = t2; c = c2;
-    }
+    double F[8], N[8];
+    __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0): with older loads still counted the loops below would wait for them at every trip
+    load_run(tb, 0, fld9(e.th, 0), F);
+    mean[0] = type_mean<0>(e, tb, live, nrun[0], F, N);
+    mean[1] = type_mean<1>(e, tb, live, nrun[1], N, F);
+    mean[2] = type_mean<2>(e, tb, live, nrun[2], F, N);
+    mean[3] = type_mean<3>(e, tb, live, nrun[3], N, F);
+    mean[4] = type_mean<4>(e, tb, live, nrun[4], F, N);
+    mean[5] = type_mean<5>(e, tb, live, nrun[5], N, F);
     if (big) {
 #pragma unroll 1
         for (uint32_t tt = 0; tt < 6u; ++tt) {
             if (!((big >> tt) & 1u)) continue;
             const uint32_t nt = live ? fld9(e.nT, tt) : 0u;
             if (nt > 128u) {
-                const double m = big_sum(tb.tq + tt * CAP + fld9(e.th, tt), nt) / (double)nt;
+                const double m = big_sum(tb.tq + (int64_t)(tt * CAP + fld9(e.th, tt)) * tb.n, tb.n, nt) / (double)nt;
 #pragma unroll
                 for (int k = 0; k < 6; ++k) mean[k] = tt == (uint32_t)k ? m : mean[k];
             }
@@ -633,7 +648,7 @@ __device__ unsigned long long g_timing[2048 * 8];
 #define TICK(k)
 #endif
 template <bool ROLLOUT>
-__global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void step_kernel(Params p) {   // 131,072 envs are 2 waves per SIMD: both must be resident (a few spilled registers cost less, round 3)
     __shared__ __attribute__((aligned(16))) uint32_t tile[64 * OBS];   // the wave's obs rows, staged for coalesced stores
     const int64_t i0 = (int64_t)blockIdx.x * BLOCK;
     const int64_t i = i0 + threadIdx.x;
@@ -839,7 +854,7 @@ int cge_manufacturing_create(const cge_manufacturing_config *cfg, int64_t n_envs
     DeviceGuard g(device);
     const size_t N = (size_t)n_envs;
     const size_t sb = (size_t)mfg::COLS * N * sizeof(uint4), qb = (size_t)mfg::CAP * N * 8, mb = (size_t)mfg::CAP * N * 2, cb = 20 * N * 8, hb = 100 * N * 8;
-    const size_t tqb = (size_t)mfg::TROW * N * 8 + 2048;       // + 2 KB: type_means reads whole runs, up to 128 places past a short list's end
+    const size_t tqb = (size_t)mfg::TROW * N * 8;
     hipError_t e;
     if ((e = hipMalloc(&h->state, sb)) != hipSuccess || (e = hipMalloc(&h->pq, qb)) != hipSuccess || (e = hipMalloc(&h->pm, mb)) != hipSuccess ||
         (e = hipMalloc(&h->pnext, mb)) != hipSuccess || (e = hipMalloc(&h->pts, mb)) != hipSuccess ||
