@@ -54,10 +54,11 @@ struct Params {
     double *ep_ret;       // episode statistics (cge_fleet_episode_stats), nullable
     int32_t *ep_len;
     int32_t t_index, accumulate;
-    uint32_t *work_count;      // [2][NSUB] alternating counters of the deferred-work sub-lists, one per 64-byte line
-    uint64_t *work_list;       // [NSUB][sub_cap] entries, see work_entry()
+    uint32_t *work_count;      // [3][NSUB] rotating counters of the deferred-work sub-lists, one per 64-byte line
+    uint64_t *work_list;       // [3][NSUB][sub_cap] entries, see work_entry()
     int64_t sub_cap;
-    int32_t parity;
+    int32_t parity;            // the list this launch APPENDS to; a pipelined dense launch serves list (parity + 2) % 3, any other `parity` itself
+    uint32_t seq;              // Env::seq of an env that has not taken this launch's step yet
 };
 
 enum : uint32_t { W_TRAFFIC = 1u, W_WEATHER = 2u, W_RESET = 4u };
@@ -73,6 +74,7 @@ __device__ __forceinline__ uint64_t work_entry(int64_t i, uint32_t work, uint32_
 constexpr int NSUB = 64;
 constexpr int CNT_STRIDE = 16;                                  // dwords between counters
 __device__ __forceinline__ uint32_t *work_counter(uint32_t *base, int parity, uint32_t sub) { return base + ((uint32_t)parity * NSUB + sub) * CNT_STRIDE; }
+__device__ __forceinline__ uint64_t *work_sublist(const Params &p, int parity, uint32_t sub) { return p.work_list + ((int64_t)parity * NSUB + sub) * p.sub_cap; }
 
 __device__ __forceinline__ double vrange(int k) { return k == 0 ? 80.0 : k == 1 ? 120.0 : 60.0; }     // :128-132
 __device__ __forceinline__ double vcons(int k) { return k == 0 ? 1.0 : k == 1 ? 0.5 : 2.0; }
@@ -85,6 +87,8 @@ struct Env {
     uint32_t dB[MAXD];      // t0:8 | commercial<<8 | deadline:9<<9 | pickup_time:10<<18
     uint32_t traffic[2];    // 25 cells x 2 bits, row-major
     uint32_t timestep, nd, weather, needs_reset, missed, completed, episodes, ppos, ppretw, lpos, lpretw;
+    uint32_t pending;       // on a work list: its step is not complete until a dense launch has served it (pipelined rollouts skip it meanwhile)
+    uint32_t seq;           // steps taken, mod 16 — the same for every env of a handle between launches (each launch steps each env once)
     double total_reward;
 
     __host__ __device__ __forceinline__ void unpack(const uint32_t *raw) {
@@ -100,7 +104,7 @@ struct Env {
         const uint32_t m0 = raw[35], m1 = raw[36], m2 = raw[37];
         timestep = m0 & 1023u; nd = (m0 >> 10) & 15u; weather = (m0 >> 14) & 3u; needs_reset = (m0 >> 16) & 1u; missed = m0 >> 17;
         completed = m1 & 15u; episodes = (m1 >> 4) & 0xFFFFu; ppos = (m1 >> 20) & 1023u; ppretw = (m1 & (1u << 30)) ? (uint32_t)MT_N : 0u;
-        lpos = m2 & 1023u; lpretw = (m2 & 1024u) ? (uint32_t)MT_N : 0u;
+        lpos = m2 & 1023u; lpretw = (m2 & 1024u) ? (uint32_t)MT_N : 0u; pending = (m2 >> 11) & 1u; seq = (m2 >> 12) & 15u;
         const uint64_t u = ((uint64_t)raw[39] << 32) | raw[38];
         memcpy(&total_reward, &u, 8);
     }
@@ -117,7 +121,7 @@ struct Env {
         raw[33] = traffic[0]; raw[34] = traffic[1];
         raw[35] = timestep | (nd << 10) | (weather << 14) | (needs_reset << 16) | (missed << 17);
         raw[36] = completed | ((episodes & 0xFFFFu) << 4) | (ppos << 20) | (ppretw ? (1u << 30) : 0u);
-        raw[37] = lpos | (lpretw ? 1024u : 0u);
+        raw[37] = lpos | (lpretw ? 1024u : 0u) | (pending << 11) | (seq << 12);
         uint64_t u;
         memcpy(&u, &total_reward, 8);
         raw[38] = (uint32_t)u; raw[39] = (uint32_t)(u >> 32);
@@ -420,88 +424,83 @@ __device__ __forceinline__ void stage_row(const Env &e, float *__restrict__ row)
     for (int c = 0; c < 25; ++c) row[51 + c] = (float)(((c < 16 ? e.traffic[0] : e.traffic[1]) >> ((c & 15) * 2)) & 3u);
 }
 
-// One lane per env, NO random draws: vehicle actions, deadlines, termination, and the obs row of the state as it
-// stands.  Everything that needs the generators — the traffic/weather redraws and the 8-12 new delivery requests
-// of an episode reset (~150 draws over two interleaved streams, ~10k instructions) — happens for ~1-3 % of the
-// lanes per step; executed in place it cost every wave that whole path at 1/64 lane utilisation (234 us per
-// 131k-env step, profiles/r01_fleet_step_v1_summary.txt).  Those envs are appended to a work list instead and
-// dense_kernel processes them with full waves.
-#ifdef CGE_FLEET_TIMING
-__device__ unsigned long long g_timing_step[4096 * 8];
-#define STICK(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = wall_clock64(); \
-    if (threadIdx.x == 0 && blockIdx.x < 4096) { g_timing_step[blockIdx.x * 8 + k] += now_ - t_last; } t_last = now_; } while (0)
-#else
-#define STICK(k)
-#endif
+// One step of the lane's env (not its row, not its store), NO random draws: vehicle actions, deadlines, termination; reward /
+// flags outputs, episode statistics.  Everything that needs the generators — the traffic/weather redraws and the 8-12 new
+// delivery requests of an episode reset (~150 draws over two interleaved streams, ~10k instructions) — happens for ~1-3 % of
+// the lanes per step; executed in place it cost every wave that whole path at 1/64 lane utilisation (234 us per 131k-env step,
+// profiles/r01_fleet_step_v1_summary.txt).  Those envs get an entry on work list `p.parity` instead (appended by wave `wave_id`
+// to its sub-list) and a dense launch processes them with full waves.
+__device__ __forceinline__ void lane_step(const Params &p, Env &e, int64_t i, uint32_t wave_id) {
+    const int t = p.t_index;
+    double reward = 0.0;
+    uint32_t flags = 0, work = 0;
+    if (p.mode == CGE_AUTORESET_NEXT_STEP && e.needs_reset) {
+        work = W_RESET;                                        // reset-only step: action ignored, reward 0
+    } else {
+        int32_t a0, a1, a2;
+        if (p.actions) {
+            const int32_t *ap = p.actions + ((int64_t)t * p.n + i) * 3;
+            a0 = ap[0]; a1 = ap[1]; a2 = ap[2];
+        } else {
+            const uint64_t key = hash_env_key(p.a_seed, (uint64_t)(p.env0 + i));
+            a0 = (int32_t)hash_action_from_key(key, (uint64_t)(p.t0 + t), 8u, 0u);
+            a1 = (int32_t)hash_action_from_key(key, (uint64_t)(p.t0 + t), 8u, 1u);
+            a2 = (int32_t)hash_action_from_key(key, (uint64_t)(p.t0 + t), 8u, 2u);
+        }
+        flags = env_step(e, p.max_steps, a0, a1, a2, work, reward);
+        if (flags) {
+            e.episodes += 1;
+            if (p.ep_ret) p.ep_ret[i] = e.total_reward;                // fleet_env.py accumulates it in step(), reset() zeroes it
+            if (p.ep_len) p.ep_len[i] = (int32_t)e.timestep;
+            if (p.mode == CGE_AUTORESET_SAME_STEP) work |= W_RESET;
+            else if (p.mode == CGE_AUTORESET_NEXT_STEP) e.needs_reset = 1;
+        }
+    }
+    e.pending = work ? 1u : 0u;
+    e.seq = (e.seq + 1u) & 15u;
+    if (work) {
+        const uint32_t sub = wave_id % (uint32_t)NSUB;
+        const uint32_t slot = atomicAdd(work_counter(p.work_count, p.parity, sub), 1u);
+        work_sublist(p, p.parity, sub)[slot] = work_entry(i, work, e.lpos, e.lpretw, e.ppos, e.ppretw);
+    }
+    if (p.accumulate) {
+        if (p.reward_sum) p.reward_sum[i] += reward;
+        if (p.done_count) p.done_count[i] += flags ? 1 : 0;
+        if (p.reward) p.reward[(int64_t)t * p.n + i] = (float)reward;
+        if (p.terminated) p.terminated[(int64_t)t * p.n + i] = (uint8_t)flags;
+    } else {
+        p.reward[i] = (float)reward;
+        p.terminated[i] = (uint8_t)(flags & 1u);
+        p.truncated[i] = (uint8_t)((flags >> 1) & 1u);
+    }
+}
+
+// The step of 64 envs, one per lane, and the obs row of the state as it stands.  PIPE (rollouts): envs still on the previous
+// step's list are left alone — the dense launch that runs beside this one serves them and steps them itself.
+template <bool PIPE>
 __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
-#ifdef CGE_FLEET_TIMING
-    unsigned long long t_last = wall_clock64();
-#endif
     const int64_t i0 = (int64_t)blockIdx.x * BLOCK;
     const int64_t i = i0 + threadIdx.x;
     const bool live = i < p.n;
     const int64_t li = live ? i : i0;
-    const int t = p.t_index;
+    if (blockIdx.x == 0 && threadIdx.x < (unsigned)NSUB) *work_counter(p.work_count, (p.parity + 1) % 3, threadIdx.x) = 0;   // the list after this one: nobody's during this launch
     Env e;
     e.load(p.state, p.n, li);
-    STICK(0);
-    double reward = 0.0;
-    uint32_t flags = 0, work = 0;
-    if (live) {
-        if (p.mode == CGE_AUTORESET_NEXT_STEP && e.needs_reset) {
-            work = W_RESET;                                    // reset-only step: action ignored, reward 0
-        } else {
-            int32_t a0, a1, a2;
-            if (p.actions) {
-                const int32_t *ap = p.actions + ((int64_t)t * p.n + i) * 3;
-                a0 = ap[0]; a1 = ap[1]; a2 = ap[2];
-            } else {
-                const uint64_t key = hash_env_key(p.a_seed, (uint64_t)(p.env0 + i));
-                a0 = (int32_t)hash_action_from_key(key, (uint64_t)(p.t0 + t), 8u, 0u);
-                a1 = (int32_t)hash_action_from_key(key, (uint64_t)(p.t0 + t), 8u, 1u);
-                a2 = (int32_t)hash_action_from_key(key, (uint64_t)(p.t0 + t), 8u, 2u);
-            }
-            STICK(1);
-            flags = env_step(e, p.max_steps, a0, a1, a2, work, reward);
-            STICK(2);
-            if (flags) {
-                e.episodes += 1;
-                if (p.ep_ret) p.ep_ret[i] = e.total_reward;                // fleet_env.py accumulates it in step(), reset() zeroes it
-                if (p.ep_len) p.ep_len[i] = (int32_t)e.timestep;
-                if (p.mode == CGE_AUTORESET_SAME_STEP) work |= W_RESET;
-                else if (p.mode == CGE_AUTORESET_NEXT_STEP) e.needs_reset = 1;
-            }
-        }
+    // (PIPE: the dense launch beside this one clears `pending` when it has served an env — but by then it has also taken the env
+    // through this step, and `seq`, in the same dword, says so: whichever version of the record this load sees, the env is skipped)
+    const bool mine = live && !(PIPE && (e.pending || e.seq != p.seq));
+    if (mine) {
+        lane_step(p, e, i, blockIdx.x);
         e.store(p.state, p.n, i);
-        if (work) {
-            const uint32_t sub = blockIdx.x % (uint32_t)NSUB;
-            const uint32_t slot = atomicAdd(work_counter(p.work_count, p.parity, sub), 1u);
-            p.work_list[(int64_t)sub * p.sub_cap + slot] = work_entry(i, work, e.lpos, e.lpretw, e.ppos, e.ppretw);
-        }
-        if (p.accumulate) {
-            if (p.reward_sum) p.reward_sum[i] += reward;
-            if (p.done_count) p.done_count[i] += flags ? 1 : 0;
-            if (p.reward) p.reward[(int64_t)t * p.n + i] = (float)reward;
-            if (p.terminated) p.terminated[(int64_t)t * p.n + i] = (uint8_t)flags;
-        } else {
-            p.reward[i] = (float)reward;
-            p.terminated[i] = (uint8_t)(flags & 1u);
-            p.truncated[i] = (uint8_t)((flags >> 1) & 1u);
-        }
     }
-    STICK(3);
-    // rows of envs on the work list are rewritten by dense_kernel (also their final_obs row).  Each lane streams its own
+    // rows of envs on the work list are rewritten by the dense launch (also their final_obs row).  Each lane streams its own
     // 304-byte row from registers, 19 16-byte stores (store_own_row); round 1 staged the wave's rows in LDS and wrote them
     // dword by dword in a 76-trip loop, 8 of this kernel's 20 us per wave.
     if (p.obs) {
         float row[OBS];
         stage_row(e, row);
-        store_own_row<OBS>(p.obs + (int64_t)t * p.obs_step_stride + li * OBS, 0, row, live);
+        store_own_row<OBS>(p.obs + (int64_t)p.t_index * p.obs_step_stride + li * OBS, 0, row, mine);
     }
-    STICK(4);
-#ifdef CGE_FLEET_TIMING
-    if (threadIdx.x == 0 && blockIdx.x < 4096) g_timing_step[blockIdx.x * 8 + 7] += 1;
-#endif
 }
 
 // DL lanes per wave, one work-list entry each (dense): traffic / weather redraw, terminal obs -> final_obs, episode
@@ -516,7 +515,12 @@ __device__ unsigned long long g_timing[1024 * 16];          // one slot row per 
 #else
 #define TICK(k)
 #endif
+// PIPE (rollouts): the launch serves list (parity + 2) % 3 — the step BEFORE the one now being taken by step_kernel<true> on the
+// other stream — and then takes each served env through that step too (lane_step), appending to list `parity` like everyone else.
+template <bool PIPE>
 __global__ __launch_bounds__(BLOCK) void dense_kernel(Params p, int what) {
+    const int serve = PIPE ? (p.parity + 2) % 3 : p.parity;
+    const int64_t t_row = PIPE ? p.t_index - 1 : p.t_index;     // the step whose rows the served work completes
 #ifdef CGE_FLEET_TIMING
     unsigned long long t_last = wall_clock64();
     const unsigned long long t_begin = t_last;
@@ -530,8 +534,8 @@ __global__ __launch_bounds__(BLOCK) void dense_kernel(Params p, int what) {
     // lane s holds sub-list s's entry count and the running total up to and including it
     uint32_t sub_n = 0, sub_end = 0;
     if (what == 0) {
-        sub_n = *work_counter(p.work_count, p.parity, lane);
-        if (blockIdx.x == 0) *work_counter(p.work_count, p.parity ^ 1, lane) = 0;                 // next step's counters
+        sub_n = *work_counter(p.work_count, serve, lane);
+        if (!PIPE && blockIdx.x == 0) *work_counter(p.work_count, (p.parity + 1) % 3, lane) = 0;  // next step's counters (pipelined: the step launch beside this one does it)
         sub_end = sub_n;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -558,7 +562,7 @@ __global__ __launch_bounds__(BLOCK) void dense_kernel(Params p, int what) {
             for (int b = NSUB / 2; b; b >>= 1)
                 if ((uint32_t)__shfl((int)sub_end, (int)(sub + b - 1), 64) <= g) sub += b;
             const uint32_t before = (uint32_t)__shfl((int)(sub_end - sub_n), (int)sub, 64);
-            const uint64_t entry = p.work_list[(int64_t)sub * p.sub_cap + (g - before)];
+            const uint64_t entry = work_sublist(p, serve, sub)[g - before];
             i = (int64_t)(entry >> 25);
             work = live ? (uint32_t)(entry & 7u) : 0u;
             lcur = (uint32_t)(entry >> 14) & 2047u; pcur = (uint32_t)(entry >> 3) & 2047u;
@@ -612,9 +616,10 @@ __global__ __launch_bounds__(BLOCK) void dense_kernel(Params p, int what) {
                 coop_update_traffic(e, L, (work & W_RESET) != 0, drawsL, traffic_acc);
             }
             if (pass == 1) TICK(5);
-            float *dst = pass == 0 ? p.final_obs : (p.obs ? p.obs + (int64_t)p.t_index * p.obs_step_stride : nullptr);
+            float *dst = pass == 0 ? p.final_obs : (p.obs ? p.obs + t_row * p.obs_step_stride : nullptr);
             const unsigned long long m = __ballot(want);
             if (!m || !dst) continue;
+            if (PIPE && pass == 1 && p.obs_step_stride == 0) continue;   // rows in place: this launch's own step rewrites them below
             if (lane < (uint32_t)DL) stage_row(e, reinterpret_cast<float *>(tile + lane * ROW));
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll 1
@@ -632,7 +637,23 @@ __global__ __launch_bounds__(BLOCK) void dense_kernel(Params p, int what) {
         TICK(7);
         if (work) {
             e.ppos = P.pos; e.ppretw = P.pretw; e.lpos = L.pos; e.lpretw = L.pretw;
+            e.pending = 0;
+            if (PIPE) lane_step(p, e, i, blockIdx.x);           // the step now being taken, for the env just served (draws nothing)
             e.store(p.state, p.n, i);
+        }
+        if (PIPE && p.obs) {                                    // ... and its row
+            const unsigned long long m = __ballot(work != 0u);
+            if (lane < (uint32_t)DL) stage_row(e, reinterpret_cast<float *>(tile + lane * ROW));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            float *dst = p.obs + (int64_t)p.t_index * p.obs_step_stride;
+#pragma unroll 1
+            for (int r = 0; r < nlive; ++r) {
+                if (!((m >> r) & 1ull)) continue;
+                uint32_t *drow = reinterpret_cast<uint32_t *>(dst + row_env[r] * OBS);
+                drow[lane] = tile[r * ROW + lane];
+                if (lane < (uint32_t)(OBS - 64)) drow[64 + lane] = tile[r * ROW + 64 + lane];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         TICK(8);
 #ifdef CGE_FLEET_TIMING
@@ -675,14 +696,17 @@ struct cge_fleet : HandleBase {
     uint32_t *work_count = nullptr;
     uint64_t *work_list = nullptr;
     int parity = 0;
+    uint32_t seq = 0;                    // Env::seq of every env (mod 16)
+    hipStream_t side = nullptr;          // pipelined rollouts: the dense launches' stream
+    hipEvent_t ev_step = nullptr, ev_dense = nullptr;
     static constexpr uint32_t snap_tag = 3u;
     std::vector<std::pair<void *, size_t>> blobs() const { return {{state, (size_t)fleet::COLS * n * sizeof(uint4)}, {mtP, (size_t)n * MT_STRIDE * 4}, {mtL, (size_t)n * MT_STRIDE * 4}, {work_count, count_bytes()}}; }
-    static size_t count_bytes() { return (size_t)2 * fleet::NSUB * fleet::CNT_STRIDE * sizeof(uint32_t); }
+    static size_t count_bytes() { return (size_t)3 * fleet::NSUB * fleet::CNT_STRIDE * sizeof(uint32_t); }
     unsigned blocks() const { return (unsigned)((n + fleet::BLOCK - 1) / fleet::BLOCK); }
     int64_t sub_cap() const { return ((int64_t)blocks() + fleet::NSUB - 1) / fleet::NSUB * fleet::BLOCK; }
-    size_t list_entries() const { return (size_t)fleet::NSUB * (size_t)sub_cap(); }
-    uint32_t snap_extra() const { return (uint32_t)parity; }
-    void set_snap_extra(uint32_t v) { parity = (int)(v & 1u); (void)v; }
+    size_t list_entries() const { return (size_t)3 * fleet::NSUB * (size_t)sub_cap(); }
+    uint32_t snap_extra() const { return (uint32_t)parity | (seq << 2); }
+    void set_snap_extra(uint32_t v) { parity = (int)(v & 3u) % 3; seq = (v >> 2) & 15u; }
     fleet::Params params() const {
         fleet::Params p{};
         p.state = state; p.mtP = mtP; p.mtL = mtL; p.n = n; p.env0 = env0; p.mode = cfg.autoreset_mode; p.max_steps = cfg.max_timesteps;
@@ -690,25 +714,58 @@ struct cge_fleet : HandleBase {
         p.ep_ret = ep_ret; p.ep_len = ep_len;
         return p;
     }
-    void free_all() { (void)hipFree(state); (void)hipFree(mtP); (void)hipFree(mtL); (void)hipFree(work_count); (void)hipFree(work_list); }
-    // k env steps = k x (the RNG-free step kernel + the dense kernel over the envs it listed), one stream.  (Measured and dropped:
-    // 2-4 partitions of the envs on forked streams, so that one partition's dense kernel overlaps the others' step kernels —
-    // 51.7 vs 53.5 us per step: both kernels are bound by one wave's latency at this batch size, not by throughput, and the
-    // fork/join events cost step() 23 us per extra stream.)
+    void free_all() { if (side) (void)hipStreamDestroy(side); if (ev_step) (void)hipEventDestroy(ev_step); if (ev_dense) (void)hipEventDestroy(ev_dense);
+                      (void)hipFree(state); (void)hipFree(mtP); (void)hipFree(mtL); (void)hipFree(work_count); (void)hipFree(work_list); }
+    // k env steps.  step() (the rows must be final when the call returns): the RNG-free step kernel, then the dense kernel over the
+    // envs it listed, on the caller's stream.
     hipError_t launch_steps(fleet::Params &p, int k, hipStream_t s) {
-        const unsigned db = (unsigned)((n + fleet::DL - 1) / fleet::DL);
+        const unsigned db = (unsigned)((n + fleet::DL - 1) / fleet::DL), dblocks = db < 1024u ? db : 1024u;
         for (int t = 0; t < k; ++t) {
-            p.t_index = t; p.parity = parity;
-            hipLaunchKernelGGL(fleet::step_kernel, dim3(blocks()), dim3(fleet::BLOCK), 0, s, p);
-            hipLaunchKernelGGL(fleet::dense_kernel, dim3(db < 1024u ? db : 1024u), dim3(fleet::BLOCK), 0, s, p, 0);
-            parity ^= 1;
+            p.t_index = t; p.parity = parity; p.seq = seq;
+            hipLaunchKernelGGL(fleet::step_kernel<false>, dim3(blocks()), dim3(fleet::BLOCK), 0, s, p);
+            hipLaunchKernelGGL(fleet::dense_kernel<false>, dim3(dblocks), dim3(fleet::BLOCK), 0, s, p, 0);
+            parity = (parity + 1) % 3; seq = (seq + 1u) & 15u;
         }
         last_kernel = "cge::fleet::step_kernel + cge::fleet::dense_kernel";
         return hipGetLastError();
     }
+    // Rollouts, k >= 2: both kernels are bound by one wave's latency, not by throughput, so the dense launch for step t runs
+    // BESIDE step t + 1's step launch, on the handle's side stream: step_kernel<true> leaves the envs on list t alone,
+    // dense_kernel<true> serves them and takes them through step t + 1 itself.
+    //   caller's stream:  S0 | S1' | S2' | ...  | S(k-1)' |            (S(t+1)' waits for D(t-1)': its pending flags and list entries)
+    //   side stream:           D0' | D1' | ...  | D(k-2)' | D(k-1)     (D(t)' waits for S(t)': the list is complete)
+    // 58 -> 3x us per 131,072-env step (round 3).  (Measured and dropped before: 2-4 partitions of the envs on forked streams —
+    // partitions overlap but each is as long as the whole; one launch with step and dense ROLES — a launch has one register and
+    // LDS budget, the dense role's 254 VGPRs + 23 KB would halve the step role's residency.)
+    hipError_t launch_rollout(fleet::Params &p, int k, hipStream_t s) {
+        if (k < 2) return launch_steps(p, k, s);
+        const unsigned db = (unsigned)((n + fleet::DL - 1) / fleet::DL), dblocks = db < 1024u ? db : 1024u;
+        hipError_t e;
+        for (int t = 0; t < k; ++t) {
+            p.t_index = t; p.parity = parity; p.seq = seq;
+            if (t == 0) hipLaunchKernelGGL(fleet::step_kernel<false>, dim3(blocks()), dim3(fleet::BLOCK), 0, s, p);
+            else {
+                if (t >= 2 && (e = hipStreamWaitEvent(s, ev_dense, 0)) != hipSuccess) return e;      // D(t-2)' done
+                hipLaunchKernelGGL(fleet::step_kernel<true>, dim3(blocks()), dim3(fleet::BLOCK), 0, s, p);
+                // D(t-1)': serves list t-1 = (parity + 2) % 3, steps its envs through step t; needs S(t-1)' (event recorded below, last trip)
+                hipLaunchKernelGGL(fleet::dense_kernel<true>, dim3(dblocks), dim3(fleet::BLOCK), 0, side, p, 0);
+                if ((e = hipEventRecord(ev_dense, side)) != hipSuccess) return e;
+            }
+            if ((e = hipEventRecord(ev_step, s)) != hipSuccess) return e;                            // S(t)' done ->
+            if ((e = hipStreamWaitEvent(side, ev_step, 0)) != hipSuccess) return e;                  // ... the side stream's next launch may read list t
+            parity = (parity + 1) % 3; seq = (seq + 1u) & 15u;
+        }
+        // the last step's list: plain dense launch (serves list k-1 = (parity + 2) % 3 now; no further step)
+        p.t_index = k - 1; p.parity = (parity + 2) % 3;
+        hipLaunchKernelGGL(fleet::dense_kernel<false>, dim3(dblocks), dim3(fleet::BLOCK), 0, side, p, 0);
+        if ((e = hipEventRecord(ev_dense, side)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(s, ev_dense, 0)) != hipSuccess) return e;
+        last_kernel = "cge::fleet::step_kernel<true> || cge::fleet::dense_kernel<true>";
+        return hipGetLastError();
+    }
     hipError_t launch_all(fleet::Params &p, int what, hipStream_t s) {
         const unsigned b = (unsigned)((n + fleet::DL - 1) / fleet::DL);
-        hipLaunchKernelGGL(fleet::dense_kernel, dim3(b < (1u << 20) ? b : (1u << 20)), dim3(fleet::BLOCK), 0, s, p, what);
+        hipLaunchKernelGGL(fleet::dense_kernel<false>, dim3(b < (1u << 20) ? b : (1u << 20)), dim3(fleet::BLOCK), 0, s, p, what);
         return hipGetLastError();
     }
 };
@@ -716,15 +773,6 @@ struct cge_fleet : HandleBase {
 extern "C" {
 
 #ifdef CGE_FLEET_TIMING
-int cge_fleet_debug_timing_step(unsigned long long *out, int clear) {
-    static unsigned long long all[4096 * 8];
-    if (hipMemcpyFromSymbol(all, HIP_SYMBOL(fleet::g_timing_step), sizeof all) != hipSuccess) return 1;
-    for (int k = 0; k < 8; ++k) out[k] = 0;
-    for (int b = 0; b < 4096; ++b)
-        for (int k = 0; k < 8; ++k) out[k] += all[b * 8 + k];
-    if (clear) { memset(all, 0, sizeof all); if (hipMemcpyToSymbol(HIP_SYMBOL(fleet::g_timing_step), all, sizeof all) != hipSuccess) return 1; }
-    return 0;
-}
 int cge_fleet_debug_timing(unsigned long long *out, int clear) {
     static unsigned long long all[1024 * 16];
     if (hipMemcpyFromSymbol(all, HIP_SYMBOL(fleet::g_timing), sizeof all) != hipSuccess) return 1;
@@ -752,7 +800,9 @@ int cge_fleet_create(const cge_fleet_config *cfg, int64_t n_envs, int device, in
     if ((e = hipMalloc(&h->state, sb)) != hipSuccess || (e = hipMalloc(&h->mtP, mb)) != hipSuccess || (e = hipMalloc(&h->mtL, mb)) != hipSuccess ||
         (e = hipMalloc(&h->work_count, cge_fleet::count_bytes())) != hipSuccess ||
         (e = hipMalloc(&h->work_list, h->list_entries() * sizeof(uint64_t))) != hipSuccess ||
-        (e = hipMemset(h->work_count, 0, cge_fleet::count_bytes())) != hipSuccess || (e = hipMemset(h->state, 0, sb)) != hipSuccess) {
+        (e = hipMemset(h->work_count, 0, cge_fleet::count_bytes())) != hipSuccess || (e = hipMemset(h->state, 0, sb)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&h->ev_step, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&h->ev_dense, hipEventDisableTiming)) != hipSuccess) {
         h->free_all();
         delete h;
         return CGE_ERR_HIP;
@@ -831,7 +881,7 @@ int cge_fleet_rollout(cge_fleet *h, int32_t k_steps, const int32_t *actions, uin
     p.accumulate = 1;
     if (reward_sum_out) CGE_TRY(h, hipMemsetAsync(reward_sum_out, 0, (size_t)h->n * sizeof(double), as_stream(stream)));
     if (done_count_out) CGE_TRY(h, hipMemsetAsync(done_count_out, 0, (size_t)h->n * sizeof(int32_t), as_stream(stream)));
-    CGE_TRY(h, h->launch_steps(p, k_steps, as_stream(stream)));   // K x (step, dense) per partition: the state stays in HBM/L2 between launches
+    CGE_TRY(h, h->launch_rollout(p, k_steps, as_stream(stream)));
     return CGE_OK;
 }
 

@@ -89,3 +89,30 @@ def test_rollout_config5_size_and_sharding(cge, oracle):
     oh, rh, dh = half.rollout(T, action_seed=123)
     assert torch.equal(oh, obs[n // 2:]) and torch.equal(rh, rs[n // 2:]) and torch.equal(dh, dc[n // 2:])
     env.close(); half.close()
+
+
+@pytest.mark.parametrize("mode", ["NextStep", "SameStep", "Disabled"])
+def test_pipelined_rollout_equals_step_by_step(cge, mode):
+    """cge_fleet_rollout runs step t + 1's step launch beside the dense launch that finishes step t (two streams, fleet.hip
+    launch_rollout); the per-step trajectory it returns must be the one K single step() calls give, in every autoreset mode,
+    across the every-50-steps traffic redraw (all envs on the work list at once) and across a second call."""
+    n, K = 700, 130
+    g = torch.Generator().manual_seed(5)
+    acts = torch.randint(0, 8, (2 * K, n, 3), generator=g, dtype=torch.int32).cuda()
+    a, b = cge.FleetVectorEnv(n, autoreset_mode=mode, env_index0=3), cge.FleetVectorEnv(n, autoreset_mode=mode, env_index0=3)
+    a.reset(seed=11); b.reset(seed=11)
+    for call in range(2):
+        A = acts[call * K:(call + 1) * K].contiguous()
+        obs, rew, term, rs, dc = a.rollout(K, actions=A, trajectory=True, per_step=True)
+        obs, rew, term = obs.clone(), rew.clone(), term.clone()
+        tot = torch.zeros(n, dtype=torch.float64, device="cuda")
+        cnt = torch.zeros(n, dtype=torch.int32, device="cuda")
+        for t in range(K):
+            o, r, te, tr, _ = b.step(A[t])
+            assert torch.equal(obs[t], o), (call, t, (obs[t] != o).nonzero()[:4])
+            assert torch.equal(rew[t], r) and torch.equal(term[t].to(torch.uint8) & 1, te.to(torch.uint8)), (call, t)
+            cnt += (te | tr).to(torch.int32)
+        assert torch.equal(dc, cnt)
+        for f in ["timestep", "episodes", "total_reward", "needs_reset", "fuel0"]:
+            assert torch.equal(a.info(f), b.info(f)), f
+    a.close(); b.close()

@@ -19,8 +19,4 @@ for chunk in range(4):
     for k, nm in enumerate(names):
         if not nm: continue
         print(f"   {nm:18s} {buf[k] * 10.0 / n / 1e3:8.2f} us per wave iteration")
-    sb = (ctypes.c_ulonglong * 8)()
-    L.cge_fleet_debug_timing_step(sb, 1)
-    ns = max(1, sb[7])
-    print("   step kernel per wave: " + ", ".join(f"{nm} {sb[k] * 10.0 / ns / 1e3:.2f} us" for k, nm in enumerate(["load", "actions", "env_step", "store+list+outputs", "obs"])))
     print(f"   slowest wave {buf[10] * 10.0 / 1e3:.1f} us; wave iterations with a serial refill: {buf[11]}")
