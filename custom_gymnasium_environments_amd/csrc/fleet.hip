@@ -515,10 +515,12 @@ __device__ unsigned long long g_timing[1024 * 16];          // one slot row per 
 #else
 #define TICK(k)
 #endif
-// PIPE (rollouts): the launch serves list (parity + 2) % 3 — the step BEFORE the one now being taken by step_kernel<true> on the
+// Pipelined (rollouts): the launch serves list (parity + 2) % 3 — the step BEFORE the one now being taken by step_kernel<true> on the
 // other stream — and then takes each served env through that step too (lane_step), appending to list `parity` like everyone else.
-template <bool PIPE>
+// MODE: 0 plain, 1 pipelined, 2 = 0 under its own name (the launch that ends a rollout: the profiles keep the two paths' bytes apart)
+template <int MODE>
 __global__ __launch_bounds__(BLOCK) void dense_kernel(Params p, int what) {
+    constexpr bool PIPE = MODE == 1;
     const int serve = PIPE ? (p.parity + 2) % 3 : p.parity;
     const int64_t t_row = PIPE ? p.t_index - 1 : p.t_index;     // the step whose rows the served work completes
 #ifdef CGE_FLEET_TIMING
@@ -723,15 +725,15 @@ struct cge_fleet : HandleBase {
         for (int t = 0; t < k; ++t) {
             p.t_index = t; p.parity = parity; p.seq = seq;
             hipLaunchKernelGGL(fleet::step_kernel<false>, dim3(blocks()), dim3(fleet::BLOCK), 0, s, p);
-            hipLaunchKernelGGL(fleet::dense_kernel<false>, dim3(dblocks), dim3(fleet::BLOCK), 0, s, p, 0);
+            hipLaunchKernelGGL(fleet::dense_kernel<0>, dim3(dblocks), dim3(fleet::BLOCK), 0, s, p, 0);
             parity = (parity + 1) % 3; seq = (seq + 1u) & 15u;
         }
-        last_kernel = "cge::fleet::step_kernel + cge::fleet::dense_kernel";
+        last_kernel = "cge::fleet::step_kernel<false> + cge::fleet::dense_kernel<0>";
         return hipGetLastError();
     }
     // Rollouts, k >= 2: both kernels are bound by one wave's latency, not by throughput, so the dense launch for step t runs
     // BESIDE step t + 1's step launch, on the handle's side stream: step_kernel<true> leaves the envs on list t alone,
-    // dense_kernel<true> serves them and takes them through step t + 1 itself.
+    // dense_kernel<1> serves them and takes them through step t + 1 itself.
     //   caller's stream:  S0 | S1' | S2' | ...  | S(k-1)' |            (S(t+1)' waits for D(t-1)': its pending flags and list entries)
     //   side stream:           D0' | D1' | ...  | D(k-2)' | D(k-1)     (D(t)' waits for S(t)': the list is complete)
     // 58 -> 3x us per 131,072-env step (round 3).  (Measured and dropped before: 2-4 partitions of the envs on forked streams —
@@ -743,12 +745,12 @@ struct cge_fleet : HandleBase {
         hipError_t e;
         for (int t = 0; t < k; ++t) {
             p.t_index = t; p.parity = parity; p.seq = seq;
-            if (t == 0) hipLaunchKernelGGL(fleet::step_kernel<false>, dim3(blocks()), dim3(fleet::BLOCK), 0, s, p);
+            if (t == 0) hipLaunchKernelGGL(fleet::step_kernel<true>, dim3(blocks()), dim3(fleet::BLOCK), 0, s, p);   // (nothing is pending: skips nobody)
             else {
                 if (t >= 2 && (e = hipStreamWaitEvent(s, ev_dense, 0)) != hipSuccess) return e;      // D(t-2)' done
                 hipLaunchKernelGGL(fleet::step_kernel<true>, dim3(blocks()), dim3(fleet::BLOCK), 0, s, p);
                 // D(t-1)': serves list t-1 = (parity + 2) % 3, steps its envs through step t; needs S(t-1)' (event recorded below, last trip)
-                hipLaunchKernelGGL(fleet::dense_kernel<true>, dim3(dblocks), dim3(fleet::BLOCK), 0, side, p, 0);
+                hipLaunchKernelGGL(fleet::dense_kernel<1>, dim3(dblocks), dim3(fleet::BLOCK), 0, side, p, 0);
                 if ((e = hipEventRecord(ev_dense, side)) != hipSuccess) return e;
             }
             if ((e = hipEventRecord(ev_step, s)) != hipSuccess) return e;                            // S(t)' done ->
@@ -757,15 +759,15 @@ struct cge_fleet : HandleBase {
         }
         // the last step's list: plain dense launch (serves list k-1 = (parity + 2) % 3 now; no further step)
         p.t_index = k - 1; p.parity = (parity + 2) % 3;
-        hipLaunchKernelGGL(fleet::dense_kernel<false>, dim3(dblocks), dim3(fleet::BLOCK), 0, side, p, 0);
+        hipLaunchKernelGGL(fleet::dense_kernel<2>, dim3(dblocks), dim3(fleet::BLOCK), 0, side, p, 0);
         if ((e = hipEventRecord(ev_dense, side)) != hipSuccess) return e;
         if ((e = hipStreamWaitEvent(s, ev_dense, 0)) != hipSuccess) return e;
-        last_kernel = "cge::fleet::step_kernel<true> || cge::fleet::dense_kernel<true>";
+        last_kernel = "cge::fleet::step_kernel<true> + cge::fleet::dense_kernel<1> + cge::fleet::dense_kernel<2>";
         return hipGetLastError();
     }
     hipError_t launch_all(fleet::Params &p, int what, hipStream_t s) {
         const unsigned b = (unsigned)((n + fleet::DL - 1) / fleet::DL);
-        hipLaunchKernelGGL(fleet::dense_kernel<false>, dim3(b < (1u << 20) ? b : (1u << 20)), dim3(fleet::BLOCK), 0, s, p, what);
+        hipLaunchKernelGGL(fleet::dense_kernel<0>, dim3(b < (1u << 20) ? b : (1u << 20)), dim3(fleet::BLOCK), 0, s, p, what);
         return hipGetLastError();
     }
 };
