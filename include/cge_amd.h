@@ -411,7 +411,10 @@ int cge_fleet_reset(cge_fleet *h, const uint8_t *mask, float *obs_out, void *str
 /* actions int32 [n_envs, 3]; a value outside 0..7 costs -10 (:326-327).  truncated_out is REQUIRED here. */
 int cge_fleet_step(cge_fleet *h, const int32_t *actions, float *obs_out, float *reward_out, uint8_t *terminated_out,
                    uint8_t *truncated_out, float *final_obs_out, void *stream);
-/* done_count counts terminated-or-truncated steps; terminated_traj_out gets terminated | truncated << 1 */
+/* done_count counts terminated-or-truncated steps; terminated_traj_out gets terminated | truncated << 1.
+ * k_steps >= 2: the launches that finish step t (redraws, resets, their rows) run on a stream the handle owns, beside step t + 1's
+ * step launch on `stream`; the call orders them with events and joins the side stream into `stream` before it returns, so to the
+ * caller everything is ordered on `stream` as usual (buffers must stay valid until `stream` reaches that point). */
 int cge_fleet_rollout(cge_fleet *h, int32_t k_steps, const int32_t *actions, uint64_t action_seed, int64_t t0,
                       float *obs_out, int64_t obs_step_stride, float *reward_traj_out, uint8_t *terminated_traj_out,
                       double *reward_sum_out, int32_t *done_count_out, void *stream);
