@@ -115,4 +115,12 @@ def test_pipelined_rollout_equals_step_by_step(cge, mode):
         assert torch.equal(dc, cnt)
         for f in ["timestep", "episodes", "total_reward", "needs_reset", "fuel0"]:
             assert torch.equal(a.info(f), b.info(f)), f
+    # rows in place (obs_step_stride 0: the dense launch skips the row its own step rewrites), hash actions replaced by explicit ones
+    A = acts[:57].contiguous()
+    obs, rs, dc = a.rollout(57, actions=A)
+    tot = torch.zeros(n, dtype=torch.float64, device="cuda")
+    for t in range(57):
+        o, r, te, tr, _ = b.step(A[t])
+        tot += r.to(torch.float64)
+    assert torch.equal(obs, o) and torch.equal(rs, tot)
     a.close(); b.close()
