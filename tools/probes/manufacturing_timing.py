@@ -9,10 +9,15 @@ env = cge.ManufacturingVectorEnv(131072, device="cuda:0")
 env.reset(seed=1)
 buf = (ctypes.c_ulonglong * 8)()
 names = ["action (hash) + outputs of the previous step", "env_step", "type_means", "stage + store rows"]
+import sys as _s
+SKIP = int(_s.argv[1]) if len(_s.argv) > 1 else 0      # steps to run before the timed chunks (the bench's steady state: 1000+)
+if SKIP:
+    env.rollout(SKIP, action_seed=7, t0=0)
+    torch.cuda.synchronize(); L.cge_manufacturing_debug_timing(buf, 1)
 for chunk in range(5):
-    env.rollout(50, action_seed=7, t0=chunk * 50, trajectory=True)
+    env.rollout(50, action_seed=7, t0=SKIP + chunk * 50, trajectory=True)
     torch.cuda.synchronize()
     L.cge_manufacturing_debug_timing(buf, 1)
     n = max(1, buf[7])
-    print(f"steps {chunk*50}..{chunk*50+49}: wave-steps {buf[7]}, total {sum(buf[k] for k in range(4)) * 10.0 / n / 1e3:.1f} us per wave-step: " +
+    print(f"steps {SKIP+chunk*50}..{SKIP+chunk*50+49}: wave-steps {buf[7]}, total {sum(buf[k] for k in range(4)) * 10.0 / n / 1e3:.1f} us per wave-step: " +
           ", ".join(f"{nm} {buf[k] * 10.0 / n / 1e3:.2f}" for k, nm in enumerate(names)))
