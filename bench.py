@@ -64,7 +64,7 @@ ENVS = {
     "hospital": dict(algo=3078, obs=972, state=768, resident=96, stream=560, n_act=35, act_shape=(), dtype="f64", ref_py="not in BASELINE.md"),
     # 292 obs + 2 x 336 state + action/reward/flags; plus 10 bytes (quality f64 + meta u16) per product in the system, which the
     # per-type np.mean of the observation has to read every step: added from the measured mean occupancy (algo_per_product)
-    "manufacturing": dict(algo=996, algo_per_product=8, obs=292, state=352, resident=352, stream=0, n_act=25, act_shape=(), dtype="f64", ref_py="not in BASELINE.md"),
+    "manufacturing": dict(algo=1028, algo_per_product=8, obs=292, state=368, resident=368, stream=0, n_act=25, act_shape=(), dtype="f64", ref_py="not in BASELINE.md"),
 }
 WORKLOADS = {
     "snake_1m": dict(env="snake", n=1 << 20, desc="SnakeEnv 10x10, 1,048,576 parallel envs per GPU, random actions, fused auto-reset"),

@@ -120,7 +120,7 @@ def test_manufacturing_overflow_flag_is_raised_not_silent():
     n, victim = 70, 33
     env = cge.ManufacturingVectorEnv(n, autoreset_mode="Disabled")
     env.reset(seed=4)
-    buf, w = _state_words(env, 22)
+    buf, w = _state_words(env, 23)
     assert int(w[3, victim, 3]) == 0                               # nprod | lo << 10 | ncomp << 20 after a reset
     w[3, victim, 3] = np.uint32(319 | (319 << 10))
     env.restore(buf)
