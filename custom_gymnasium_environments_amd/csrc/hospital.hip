@@ -56,7 +56,6 @@ struct Params {
     uint4 *state;
     uint32_t *mt;
     uint32_t *ring;
-    uint8_t *ringtt;
     int64_t n, env0;
     int32_t mode, max_steps, k_steps;
     const int32_t *actions;
@@ -134,8 +133,7 @@ struct Misc {
 };
 
 struct Ring {
-    uint32_t *rec;
-    uint8_t *tt;
+    uint2 *rec;               // .x the record below, .y the patient's treatment time: one 8-byte entry, so that the pop that needs both waits once
 };
 // record: seq (12) | arrival (11) << 12 | insurance_delay (5) << 23
 __device__ __forceinline__ uint32_t rec_seq(uint32_t r) { return r & 4095u; }
@@ -146,8 +144,7 @@ template <int K>
 __device__ __forceinline__ void q_push(Misc &m, const Ring &rg, uint32_t arrival, uint32_t ins, uint32_t ttime) {
     if (m.qc[K] >= (uint32_t)q_cap(K) || m.next_id >= 4095u) { m.overflow = 1; return; }     // beyond any episode the dynamics can produce
     const uint32_t p = q_off(K) + ((m.qh[K] + m.qc[K]) & (uint32_t)(q_cap(K) - 1));
-    rg.rec[p] = m.next_id | (arrival << 12) | (ins << 23);
-    rg.tt[p] = (uint8_t)ttime;
+    rg.rec[p] = make_uint2(m.next_id | (arrival << 12) | (ins << 23), ttime);
     m.qc[K] += 1; m.sumarr[q_dept3(K)] += arrival; m.next_id += 1;
 }
 template <int K>
@@ -157,14 +154,16 @@ __device__ __forceinline__ void q_pop(Misc &m, uint32_t arrival) {
 }
 // front of a department's deque: the head with the smallest sequence number.  Returns the sub-queue (or -1).
 template <int K0, int K1>
-__device__ __forceinline__ int q_front(const Misc &m, const Ring &rg, uint32_t &rec, uint32_t &slot) {
+__device__ __forceinline__ int q_front(const Misc &m, const Ring &rg, uint32_t &rec, uint32_t &slot, uint32_t &tt) {
     int best = -1;
     uint32_t bseq = 0xFFFFFFFFu;
 #pragma unroll
     for (int k = K0; k <= K1; ++k) {
         if (m.qc[k] > 0) {
-            const uint32_t p = q_off(k) + m.qh[k], r = rg.rec[p];
-            if (rec_seq(r) < bseq) { bseq = rec_seq(r); best = k; rec = r; slot = p; }
+            const uint32_t p = q_off(k) + m.qh[k];
+            const uint2 r2 = rg.rec[p];
+            const uint32_t r = r2.x;
+            if (rec_seq(r) < bseq) { bseq = rec_seq(r); best = k; rec = r; slot = p; tt = r2.y; }
         }
     }
     return best;
@@ -244,10 +243,10 @@ struct Equip {
 
 
 template <int G>
-__device__ __forceinline__ int dept_front(const Misc &m, const Ring &rg, uint32_t &rec, uint32_t &slot) {
-    if (G == 0) return q_front<0, 2>(m, rg, rec, slot);
-    if (G == 1) return q_front<3, 3>(m, rg, rec, slot);
-    return q_front<4, 5>(m, rg, rec, slot);
+__device__ __forceinline__ int dept_front(const Misc &m, const Ring &rg, uint32_t &rec, uint32_t &slot, uint32_t &tt) {
+    if (G == 0) return q_front<0, 2>(m, rg, rec, slot, tt);
+    if (G == 1) return q_front<3, 3>(m, rg, rec, slot, tt);
+    return q_front<4, 5>(m, rg, rec, slot, tt);
 }
 
 template <int G>
@@ -255,8 +254,8 @@ __device__ __forceinline__ void transfer_dept(Misc &m, const Ring &rg, int32_t &
     if (m.qlen(G) > 10u) {
 #pragma unroll 1
         for (int r = 0; r < 3; ++r) {
-            uint32_t rec = 0, slot = 0;
-            const int k = dept_front<G>(m, rg, rec, slot);
+            uint32_t rec = 0, slot = 0, tt = 0;
+            const int k = dept_front<G>(m, rg, rec, slot, tt);
             q_pop_dyn(m, k, rec_arr(rec));
             reward -= 200;
         }
@@ -276,12 +275,12 @@ __device__ __forceinline__ void assign_dept(Misc &m, const Ring &rg, Doctors &dc
     for (int k = 0; k < NDOC; ++k) fd |= (doc_dept(dc.meta[k]) == dept && doc_busy(dc.meta[k]) <= now ? 1u : 0u) << k;
 #pragma unroll 1
     while (fb && fd && m.qlen(G) > 0u) {
-        uint32_t rec = 0, slot = 0;
-        const int k = dept_front<G>(m, rg, rec, slot);
+        uint32_t rec = 0, slot = 0, tt = 0;
+        const int k = dept_front<G>(m, rg, rec, slot, tt);
         const uint32_t b = (uint32_t)__ffs((int)fb) - 1u, di = (uint32_t)__ffs((int)fd) - 1u;
         fb &= fb - 1u; fd &= fd - 1u;
-        if (rec_ins(rec) > 0u) { rg.rec[slot] = rec - (1u << 23); continue; }
-        const uint32_t sev = (uint32_t)(k == 0 ? 3 : k == 1 ? 4 : k == 2 ? 5 : k == 3 ? 5 : k == 4 ? 1 : 2), tt = rg.tt[slot];
+        if (rec_ins(rec) > 0u) { rg.rec[slot].x = rec - (1u << 23); continue; }
+        const uint32_t sev = (uint32_t)(k == 0 ? 3 : k == 1 ? 4 : k == 2 ? 5 : k == 3 ? 5 : k == 4 ? 1 : 2);
         const uint32_t word = 1u | (sev << 1) | (rec_arr(rec) << 4) | (tt << 15);
 #pragma unroll
         for (int j = 0; j < nb; ++j) if (b == (uint32_t)j) bd.b[b0 + j] = word;
@@ -300,14 +299,14 @@ __device__ __forceinline__ void death_rolls(Misc &m, const Ring &rg, Draws &D, u
     uint32_t j = 0;
 #pragma unroll 1
     while (j < m.qc[K]) {
-        const uint32_t r = rg.rec[off + ((m.qh[K] + j) & msk)];
+        const uint32_t r = rg.rec[off + ((m.qh[K] + j) & msk)].x;
         if (!(rec_arr(r) + 60u < now)) break;                                   // sorted by arrival: nobody behind has waited longer
         if (D.random53() < 0.1) {
             m.deaths += 1; reward -= 2000;
 #pragma unroll 1
             for (uint32_t q = j; q + 1u < m.qc[K]; ++q) {                       // close the gap (a handful of entries)
                 const uint32_t src = off + ((m.qh[K] + q + 1u) & msk), dst = off + ((m.qh[K] + q) & msk);
-                rg.rec[dst] = rg.rec[src]; rg.tt[dst] = rg.tt[src];
+                rg.rec[dst] = rg.rec[src];
             }
             m.qc[K] -= 1; m.sumarr[q_dept3(K)] -= rec_arr(r);
         } else { reward -= 500; ++j; }
@@ -319,7 +318,7 @@ __device__ __forceinline__ void late_penalty(Misc &m, const Ring &rg, uint32_t n
     constexpr uint32_t thr = K == 0 ? 30u : 90u;
 #pragma unroll 1
     while (m.ql[K] < m.qc[K]) {
-        const uint32_t r = rg.rec[q_off(K) + ((m.qh[K] + m.ql[K]) & (uint32_t)(q_cap(K) - 1))];
+        const uint32_t r = rg.rec[q_off(K) + ((m.qh[K] + m.ql[K]) & (uint32_t)(q_cap(K) - 1))].x;
         if (rec_arr(r) + thr < now) m.ql[K] += 1; else break;
     }
     reward -= (int32_t)m.ql[K] * (K == 0 ? 50 : 100);
@@ -498,7 +497,7 @@ struct StepOut {
 
 // obs_row: this env's row of the obs output (null: no observation wanted)
 __device__ __forceinline__ void wave_step(const Params &p, int64_t i, bool live, int32_t action, Misc &m, Draws &D, float *obs_row, StepOut &out) {
-    const Ring rg{p.ring + i * RING, p.ringtt + i * RING};
+    const Ring rg{reinterpret_cast<uint2 *>(p.ring) + i * RING};
     const bool reset_only = live && p.mode == CGE_AUTORESET_NEXT_STEP && m.needs_reset;
     const bool run = live && !reset_only;
     int32_t reward = 0;
@@ -940,19 +939,18 @@ struct cge_hospital : HandleBase {
     cge_hospital_config cfg{};
     uint4 *state = nullptr;
     uint32_t *mt = nullptr, *ring = nullptr;
-    uint8_t *ringtt = nullptr;
     static constexpr uint32_t snap_tag = 5u;
-    std::vector<std::pair<void *, size_t>> blobs() const { return {{state, (size_t)hosp::COLS * n * sizeof(uint4)}, {mt, (size_t)n * MT_STRIDE * 4}, {ring, (size_t)n * hosp::RING * 4}, {ringtt, (size_t)n * hosp::RING}}; }
+    std::vector<std::pair<void *, size_t>> blobs() const { return {{state, (size_t)hosp::COLS * n * sizeof(uint4)}, {mt, (size_t)n * MT_STRIDE * 4}, {ring, (size_t)n * hosp::RING * 8}}; }
     uint32_t snap_extra() const { return 0u; }
     void set_snap_extra(uint32_t v) { (void)v; }
     hosp::Params params() const {
         hosp::Params p{};
-        p.state = state; p.mt = mt; p.ring = ring; p.ringtt = ringtt; p.n = n; p.env0 = env0; p.mode = cfg.autoreset_mode; p.max_steps = cfg.max_episode_length;
+        p.state = state; p.mt = mt; p.ring = ring; p.n = n; p.env0 = env0; p.mode = cfg.autoreset_mode; p.max_steps = cfg.max_episode_length;
         p.ep_ret = ep_ret; p.ep_len = ep_len;
         return p;
     }
     unsigned blocks() const { return (unsigned)((n + hosp::BLOCK - 1) / hosp::BLOCK); }
-    void free_all() { (void)hipFree(state); (void)hipFree(mt); (void)hipFree(ring); (void)hipFree(ringtt); }
+    void free_all() { (void)hipFree(state); (void)hipFree(mt); (void)hipFree(ring); }
 };
 
 extern "C" {
@@ -981,15 +979,15 @@ int cge_hospital_create(const cge_hospital_config *cfg, int64_t n_envs, int devi
     h->n = n_envs; h->env0 = env_index0; h->device = device;
     DeviceGuard g(device);
     const size_t N = (size_t)n_envs;
-    const size_t sb = (size_t)hosp::COLS * N * sizeof(uint4), mb = N * MT_STRIDE * sizeof(uint32_t), rb = N * hosp::RING * 4, tb = N * hosp::RING;
+    const size_t sb = (size_t)hosp::COLS * N * sizeof(uint4), mb = N * MT_STRIDE * sizeof(uint32_t), rb = N * hosp::RING * 8;
     hipError_t e;
     if ((e = hipMalloc(&h->state, sb)) != hipSuccess || (e = hipMalloc(&h->mt, mb)) != hipSuccess || (e = hipMalloc(&h->ring, rb)) != hipSuccess ||
-        (e = hipMalloc(&h->ringtt, tb)) != hipSuccess || (e = hipMemset(h->state, 0, sb)) != hipSuccess) {
+        (e = hipMemset(h->state, 0, sb)) != hipSuccess) {
         h->free_all();
         delete h;
         return CGE_ERR_HIP;
     }
-    h->device_bytes = sb + mb + rb + tb;
+    h->device_bytes = sb + mb + rb;
     e = launch_mt_seed(h->mt, MT_STRIDE, n_envs, nullptr, 0, env_index0, 0, nullptr);
     if (e == hipSuccess) {
         hosp::Params p = h->params();
