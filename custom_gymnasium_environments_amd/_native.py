@@ -151,6 +151,7 @@ SIGNATURES = {
     "cge_fleet_snapshot_set": (C.c_int, [_vp, _vp, _vp]),
     "cge_fleet_device_bytes": (_sz, [_vp]),
     "cge_fleet_episode_stats": (C.c_int, [_vp, _vp, _vp]),
+    "cge_fleet_done_mask": (C.c_int, [_vp, _vp]),
     "cge_fleet_last_error": (C.c_char_p, [_vp]),
     "cge_fleet_last_kernel": (C.c_char_p, [_vp]),
     "cge_manufacturing_create": (C.c_int, [C.POINTER(ManufacturingConfig), _i64, C.c_int, _i64, C.POINTER(_vp)]),
@@ -165,6 +166,7 @@ SIGNATURES = {
     "cge_manufacturing_snapshot_set": (C.c_int, [_vp, _vp, _vp]),
     "cge_manufacturing_device_bytes": (_sz, [_vp]),
     "cge_manufacturing_episode_stats": (C.c_int, [_vp, _vp, _vp]),
+    "cge_manufacturing_done_mask": (C.c_int, [_vp, _vp]),
     "cge_manufacturing_last_error": (C.c_char_p, [_vp]),
     "cge_manufacturing_last_kernel": (C.c_char_p, [_vp]),
     "cge_hospital_create": (C.c_int, [C.POINTER(HospitalConfig), _i64, C.c_int, _i64, C.POINTER(_vp)]),
@@ -179,6 +181,7 @@ SIGNATURES = {
     "cge_hospital_snapshot_set": (C.c_int, [_vp, _vp, _vp]),
     "cge_hospital_device_bytes": (_sz, [_vp]),
     "cge_hospital_episode_stats": (C.c_int, [_vp, _vp, _vp]),
+    "cge_hospital_done_mask": (C.c_int, [_vp, _vp]),
     "cge_hospital_last_error": (C.c_char_p, [_vp]),
     "cge_hospital_last_kernel": (C.c_char_p, [_vp]),
 }

@@ -22,6 +22,7 @@ struct HandleBase {
     size_t device_bytes = 0;
     double *ep_ret = nullptr;      // episode-statistics outputs registered by <env>_episode_stats (caller-owned device buffers)
     int32_t *ep_len = nullptr;
+    uint8_t *done_out = nullptr;   // step(): terminated | truncated per env, registered by <env>_done_mask (caller-owned device buffer, nullable)
 
     int fail(int status, const char *what, hipError_t e = hipSuccess) {
         char buf[512];

@@ -53,6 +53,7 @@ struct Params {
     int32_t *done_count;
     double *ep_ret;       // episode statistics (cge_fleet_episode_stats), nullable
     int32_t *ep_len;
+    uint8_t *done;        // step(): terminated | truncated (cge_fleet_done_mask), nullable
     int32_t t_index, accumulate;
     uint32_t *work_count;      // [3][NSUB] rotating counters of the deferred-work sub-lists, one per 64-byte line
     uint64_t *work_list;       // [3][NSUB][sub_cap] entries, see work_entry()
@@ -472,6 +473,7 @@ __device__ __forceinline__ void lane_step(const Params &p, Env &e, int64_t i, ui
         p.reward[i] = (float)reward;
         p.terminated[i] = (uint8_t)(flags & 1u);
         p.truncated[i] = (uint8_t)((flags >> 1) & 1u);
+        if (p.done) p.done[i] = flags ? 1 : 0;
     }
 }
 
@@ -713,7 +715,7 @@ struct cge_fleet : HandleBase {
         fleet::Params p{};
         p.state = state; p.mtP = mtP; p.mtL = mtL; p.n = n; p.env0 = env0; p.mode = cfg.autoreset_mode; p.max_steps = cfg.max_timesteps;
         p.work_count = work_count; p.work_list = work_list; p.sub_cap = sub_cap(); p.parity = parity;
-        p.ep_ret = ep_ret; p.ep_len = ep_len;
+        p.ep_ret = ep_ret; p.ep_len = ep_len; p.done = done_out;
         return p;
     }
     void free_all() { if (side) (void)hipStreamDestroy(side); if (ev_step) (void)hipEventDestroy(ev_step); if (ev_dense) (void)hipEventDestroy(ev_dense);
@@ -902,6 +904,12 @@ size_t cge_fleet_device_bytes(const cge_fleet *h) { return h ? h->device_bytes :
 int cge_fleet_episode_stats(cge_fleet *h, double *return_out, int32_t *length_out) {
     if (!h) return CGE_ERR_INVALID_ARG;
     h->ep_ret = return_out; h->ep_len = length_out;
+    return CGE_OK;
+}
+
+int cge_fleet_done_mask(cge_fleet *h, uint8_t *done_out) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    h->done_out = done_out;
     return CGE_OK;
 }
 

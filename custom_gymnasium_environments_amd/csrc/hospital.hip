@@ -71,6 +71,7 @@ struct Params {
     int32_t *done_count;
     double *ep_ret;       // episode statistics (cge_hospital_episode_stats), nullable
     int32_t *ep_len;
+    uint8_t *done;        // step(): terminated | truncated (cge_hospital_done_mask), nullable
 };
 
 __device__ __forceinline__ double mk_double(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
@@ -812,6 +813,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
                 p.reward[i] = (float)o.reward;
                 p.terminated[i] = (uint8_t)(o.flags & 1u);
                 p.truncated[i] = (uint8_t)((o.flags >> 1) & 1u);
+                if (p.done) p.done[i] = o.flags ? 1 : 0;
             }
         }
     }
@@ -946,7 +948,7 @@ struct cge_hospital : HandleBase {
     hosp::Params params() const {
         hosp::Params p{};
         p.state = state; p.mt = mt; p.ring = ring; p.n = n; p.env0 = env0; p.mode = cfg.autoreset_mode; p.max_steps = cfg.max_episode_length;
-        p.ep_ret = ep_ret; p.ep_len = ep_len;
+        p.ep_ret = ep_ret; p.ep_len = ep_len; p.done = done_out;
         return p;
     }
     unsigned blocks() const { return (unsigned)((n + hosp::BLOCK - 1) / hosp::BLOCK); }
@@ -1080,6 +1082,12 @@ size_t cge_hospital_device_bytes(const cge_hospital *h) { return h ? h->device_b
 int cge_hospital_episode_stats(cge_hospital *h, double *return_out, int32_t *length_out) {
     if (!h) return CGE_ERR_INVALID_ARG;
     h->ep_ret = return_out; h->ep_len = length_out;
+    return CGE_OK;
+}
+
+int cge_hospital_done_mask(cge_hospital *h, uint8_t *done_out) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    h->done_out = done_out;
     return CGE_OK;
 }
 

@@ -67,6 +67,7 @@ struct Params {
     int32_t *done_count;
     double *ep_ret;       // episode statistics (cge_manufacturing_episode_stats), nullable
     int32_t *ep_len;
+    uint8_t *done;        // step(): terminated | truncated (cge_manufacturing_done_mask), nullable
 };
 
 __device__ __forceinline__ double mk_double(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
@@ -731,6 +732,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 p.reward[i] = (float)reward;
                 p.terminated[i] = (uint8_t)(flags & 1u);
                 p.truncated[i] = (uint8_t)((flags >> 1) & 1u);
+                if (p.done) p.done[i] = flags ? 1 : 0;
             }
         }
     }
@@ -831,7 +833,7 @@ struct cge_manufacturing : HandleBase {
         mfg::Params p{};
         p.state = state; p.pq = pq; p.pm = pm; p.pnext = pnext; p.pts = pts; p.tq = tq; p.tid = tid; p.comp = comp; p.hist = hist;
         p.n = n; p.env0 = env0; p.mode = cfg.autoreset_mode; p.max_steps = cfg.max_steps;
-        p.ep_ret = ep_ret; p.ep_len = ep_len;
+        p.ep_ret = ep_ret; p.ep_len = ep_len; p.done = done_out;
         return p;
     }
     unsigned blocks() const { return (unsigned)((n + mfg::BLOCK - 1) / mfg::BLOCK); }
@@ -966,6 +968,12 @@ size_t cge_manufacturing_device_bytes(const cge_manufacturing *h) { return h ? h
 int cge_manufacturing_episode_stats(cge_manufacturing *h, double *return_out, int32_t *length_out) {
     if (!h) return CGE_ERR_INVALID_ARG;
     h->ep_ret = return_out; h->ep_len = length_out;
+    return CGE_OK;
+}
+
+int cge_manufacturing_done_mask(cge_manufacturing *h, uint8_t *done_out) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    h->done_out = done_out;
     return CGE_OK;
 }
 

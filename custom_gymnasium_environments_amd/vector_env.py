@@ -189,6 +189,7 @@ class FlagsVectorEnv(DeviceVectorEnv):
 
     def _finish_init(self, info_fields):
         self.info_fields = tuple(info_fields)
+        self._done_ptr = 0
         self._obs_shape = (self.num_envs, self._obs_dim)
 
     def reset(self, *, seed=None, options=None):
@@ -208,14 +209,23 @@ class FlagsVectorEnv(DeviceVectorEnv):
         trunc = self._out("truncated", (self.num_envs,), torch.bool)
         same = self._mode_code == _native.AUTORESET_SAME_STEP
         fin = self._out("final_obs", self._obs_shape, torch.float32) if same else None
+        done = None
+        if same or self._ep_ret is not None:                   # terminated | truncated, written by the step kernel itself
+            done = self._out("done", (self.num_envs,), torch.bool)
+            if done.data_ptr() != self._done_ptr:
+                self._done_ptr = done.data_ptr()
+                self._check(self._fn("done_mask")(self._h, self._done_ptr), "done_mask")
+        elif self._done_ptr:
+            self._done_ptr = 0
+            self._check(self._fn("done_mask")(self._h, None), "done_mask")
         self._check(self._fn("step")(self._h, a.data_ptr(), obs.data_ptr(), rew.data_ptr(), term.data_ptr(), trunc.data_ptr(),
                                      fin.data_ptr() if same else None, self._stream()), "step")
         infos = self._infos()
         if same:
             infos["final_obs"] = fin
-            infos["_final_obs"] = term | trunc
+            infos["_final_obs"] = done
         if self._ep_ret is not None:
-            self._episode_infos(infos, term | trunc)
+            self._episode_infos(infos, done)
         return obs, rew, term, trunc, infos
 
     def rollout(self, k_steps, actions=None, action_seed=0, t0=0, trajectory=False, want_obs=True, per_step=False):

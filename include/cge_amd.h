@@ -426,6 +426,9 @@ int cge_fleet_snapshot_get(cge_fleet *h, void *host_buf, void *stream);
 int cge_fleet_snapshot_set(cge_fleet *h, const void *host_buf, void *stream);
 size_t cge_fleet_device_bytes(const cge_fleet *h);
 int cge_fleet_episode_stats(cge_fleet *h, double *return_out, int32_t *length_out);
+/* optional: cge_fleet_step also writes terminated | truncated per env into done_out (device, n_envs bytes) until it is set to NULL —
+ * the mask gymnasium's SAME_STEP infos["_final_obs"] and the episode statistics want, without a second launch */
+int cge_fleet_done_mask(cge_fleet *h, uint8_t *done_out);
 const char *cge_fleet_last_error(const cge_fleet *h);
 const char *cge_fleet_last_kernel(const cge_fleet *h);
 
@@ -470,6 +473,9 @@ int cge_manufacturing_snapshot_get(cge_manufacturing *h, void *host_buf, void *s
 int cge_manufacturing_snapshot_set(cge_manufacturing *h, const void *host_buf, void *stream);
 size_t cge_manufacturing_device_bytes(const cge_manufacturing *h);
 int cge_manufacturing_episode_stats(cge_manufacturing *h, double *return_out, int32_t *length_out);
+/* optional: cge_manufacturing_step also writes terminated | truncated per env into done_out (device, n_envs bytes) until it is set to NULL —
+ * the mask gymnasium's SAME_STEP infos["_final_obs"] and the episode statistics want, without a second launch */
+int cge_manufacturing_done_mask(cge_manufacturing *h, uint8_t *done_out);
 const char *cge_manufacturing_last_error(const cge_manufacturing *h);
 const char *cge_manufacturing_last_kernel(const cge_manufacturing *h);
 
@@ -515,6 +521,9 @@ int cge_hospital_snapshot_get(cge_hospital *h, void *host_buf, void *stream);
 int cge_hospital_snapshot_set(cge_hospital *h, const void *host_buf, void *stream);
 size_t cge_hospital_device_bytes(const cge_hospital *h);
 int cge_hospital_episode_stats(cge_hospital *h, double *return_out, int32_t *length_out);
+/* optional: cge_hospital_step also writes terminated | truncated per env into done_out (device, n_envs bytes) until it is set to NULL —
+ * the mask gymnasium's SAME_STEP infos["_final_obs"] and the episode statistics want, without a second launch */
+int cge_hospital_done_mask(cge_hospital *h, uint8_t *done_out);
 const char *cge_hospital_last_error(const cge_hospital *h);
 const char *cge_hospital_last_kernel(const cge_hospital *h);
 
