@@ -12,7 +12,7 @@
 // 15 medicine counts).  Fatigue / equipment status are genuinely float64 (uniform() starts, +-0.1..0.5 per step, clamps).
 // Queues: the reference's six deques only ever hold six (department, severity) combinations, each FIFO and sorted by
 // arrival: (EMERGENCY,3) (EMERGENCY,4) (EMERGENCY,5) (ICU,5) (WARD,1) (WARD,2).  Each is a power-of-two ring in the env's
-// own 3008-slot region {u32 seq|arrival|insurance_delay, u8 treatment_time}; a department's front is the head with the
+// own 3008-slot region, 8 bytes per slot {u32 seq|arrival|insurance_delay, u32 treatment_time}; a department's front is the head with the
 // smallest sequence number (= patient id).  That makes everything the reference does by walking the deque O(1) amortised:
 // total wait = len*now - sum(arrival); "severity 3 waiting > 30" / "severity 4 waiting > 90" are prefixes tracked by a
 // marker; only severity-5 patients waiting > 60 (a death roll each, in deque order) are visited one by one.
