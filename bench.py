@@ -365,7 +365,7 @@ def main():
 
     class on_stream:                                     # `with on_stream(nm):` = torch.cuda.stream(...) or nothing in a dry run
         def __init__(self, nm):
-            self.cm = None if dry else torch.cuda.stream(streams[nm])
+            self.cm = None if dry or len(names) == 1 else torch.cuda.stream(streams[nm])   # one env type: its stream IS the current one
 
         def __enter__(self):
             return self.cm.__enter__() if self.cm else None
