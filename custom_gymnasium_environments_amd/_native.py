@@ -101,6 +101,7 @@ SIGNATURES = {
     "cge_traffic_reset": (C.c_int, [_vp, _vp, _vp, _vp]),
     "cge_traffic_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cge_traffic_rollout": (C.c_int, [_vp, _i32, _vp, _u64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "cge_traffic_rollout_final_obs": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "cge_traffic_info": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "cge_traffic_total_reward": (C.c_int, [_vp, _vp, _vp]),
     "cge_traffic_state_bytes": (_sz, [_vp]),
@@ -205,6 +206,8 @@ def lib():
             try:
                 fn = getattr(L, name)
             except AttributeError as e:
+                if os.environ.get("CGE_AMD_LIBRARY"):          # A/B against an older build: entry points added since are simply absent
+                    continue
                 raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from e
             fn.restype = res
             fn.argtypes = args

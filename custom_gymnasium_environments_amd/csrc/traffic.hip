@@ -1,6 +1,6 @@
 // traffic.hip — batched TrafficManagementEnv for MI355X (gfx950): kernels + C ABI (include/cge_amd.h).
 //
-// Re-expresses /root/reference/traffic_management_env/ for N independent instances, one lane per env:
+// Re-expresses /root/reference/traffic_management_env/ for N independent instances:
 //   environment.py  reset :141-166, step :168-203, _apply_actions :205-220, _spawn_vehicles :222-249,
 //                   _process_intersections :271-281, _remove_completed_vehicles :283-285,
 //                   _calculate_reward :287-311, _get_observation :313-363
@@ -9,18 +9,31 @@
 //                   get_neighboring_intersections :196-214, get_direction_between_intersections :230-248
 // The reference's O(vehicles x intersections) np.sqrt loop (_update_vehicles :251-269, its CPU hot spot) is a
 // semantic no-op and has no device counterpart; the per-env state collapses, for NI controlled intersections, to
-//   NI lights (phase:2 timer:5), 4 NI queues (len:7 dest:7 wait:18), NI passed, NI total_wait, counters, RNG cursor,
-//   float64 total_reward — 58 dwords = 15 uint4 columns (240 B) for the default 9, struct-of-arrays, all in VGPRs during a step.
-// Layouts: the kernels are templates on the number of controlled intersections — 4, 9 and 16 are instantiated, the three the
-// reference's own scripts construct (simple_test.py:71-76 (3,3)/4, config.py:6-7 (5,5)/9, USAGE_EXAMPLES.md:32-38 (6,6)/16) —
-// and take the grid (rows, cols) at run time: routes walk the WHOLE grid (utils.py:196-214), so cells without an Intersection
-// are visited too; the walk tracks (row, col) and never divides.  max_vehicles and spawn_rate are run-time values as well.
-// Integer dynamics are exact; the reward (np.var included, NumPy's pairwise order) and the obs quotients are
-// float64 in the reference's operation order, so the float32 obs and the reward are bit-identical to the CPU.
-// Draw counts per step are data dependent (a light entering green: randint(5,30); a spawn: random(), randint x2,
-// 1-4 random.choice hops), so the env's MT19937 window is parked in LDS (LdsDraws) and indexed by a per-lane
-// cursor.  The (N, 14 NI + 4) float32 obs is staged through LDS in a few chunks per wave and written with
-// fully used 256-byte store instructions (step()), or streamed row-wise from registers (fused rollout).
+//   NI lights (phase:2 timer:5), 4 NI queues (len:7 dest:7 wait:18), NI passed, NI total_wait, counters, RNG cursor, float64 total_reward.
+//
+// Round 4: ONE ENV = A GROUP OF L = 4 LANES (a DPP quad), 16 envs per wave (rounds 1-3: one lane per env, 58 state dwords + the
+// observation in one lane's registers = 193 VGPRs, two waves per SIMD, a wave-step was one 28-us dependent chain).
+//   * lane ql of a group owns intersections ql, ql + 4, ql + 8, ql + 12 (IPL = ceil(NI / 4) slots, a template parameter): one light,
+//     four queue words, `passed`, `total_wait` per slot — 6 IPL + ~10 group-uniform scalars instead of 58 + 14;
+//   * per-instance reductions (vehicles passed / waiting / queued, the lights that need a timer draw, np.var's pairwise tree) are
+//     quad-permute DPP steps; NumPy's eight-accumulator tree IS the butterfly over two slots (pairwise_sum);
+//   * the env's MT19937 words live, tempered, in a 64-word LDS ring per env next to four 64-bit ACCEPTANCE MASKS (top bit clear,
+//     top two bits != 11, top bits < NI, top five bits < 26): every rejection loop of the reference (`_randbelow`) is then
+//     "count trailing zeros of mask >> cursor" — the draw chain of a step (light timers, spawn test, start, route length, hops)
+//     is straight-line code on group-uniform registers, no loops, no divergence inside a group; a chain that runs off its 32-word
+//     view (rare) redoes the step's draws word by word (slow_draws);
+//   * the ring is refilled 16 words (64 B, one 16-byte load per lane) at a time from words the group twisted ahead of the cursor,
+//     32 words = one 128-byte line per cooperative twist (twist_chunk_group; layout and ready marks as cge_device.hpp: mt_twist_chunk);
+//   * a lane stores the 16-byte pieces of its intersections' observation columns straight from registers; a quad's pieces are
+//     64 contiguous bytes, the four global features one dword per lane;
+//   * the state is array-of-structs (one 8 + 6 NI dword record per env): a wave loads / stores 16 consecutive records;
+//   * waves are dealt to the XCDs in contiguous runs (block b -> chunk (b % 8) * per_xcd + b / 8), so the 64-byte reward and
+//     16-byte flag pieces that neighbouring waves write into one 128-byte line meet in ONE L2;
+//   * NI is a run-time value (2..16) — the kernels are instantiated per IPL, not per layout.
+// Integer dynamics are exact; the reward (np.var included, NumPy's pairwise order) is float64 in the reference's operation
+// order; the average-wait quotients are float32 divisions of exactly representable integers (wait < 2^18, len < 2^7: the
+// correctly rounded float32 quotient equals the float32 of the correctly rounded float64 quotient — a float32 tie point
+// (2M+1)/2^k is either hit exactly or missed by more than 2^-53 relative), so obs and reward are bit-identical to the CPU.
 #include <cstring>
 #include <utility>
 #include <vector>
@@ -31,43 +44,46 @@
 namespace cge {
 namespace traffic {
 
-constexpr int bitlen(int n) { int k = 0; while (n) { ++k; n >>= 1; } return k; }
-
-template <int NI_>
-struct Lay {
-    static constexpr int NI = NI_;
-    static constexpr int NQ = 4 * NI;
-    static constexpr int OBS = 14 * NI + 4;                    // environment.py:108-121
-    // state words: lights (8 bits each) | queues | passed (16 bits each) | total_wait | m0 m1 episodes total_reward(2) mt_old0
-    static constexpr int O_Q = (NI + 3) / 4, O_P = O_Q + NQ, O_TW = O_P + (NI + 1) / 2, O_M = O_TW + NI, NW = O_M + 6;
-    static constexpr int COLS = (NW + 3) / 4;                  // uint4 columns per env (15 for NI = 9)
-    static constexpr int CW = 32, ROW = 33;                    // step(): obs staged through LDS 32 dwords at a time, odd row stride
-    static constexpr int START_BITS = bitlen(NI);              // random.randint(0, NI-1): _randbelow(NI), k = NI.bit_length()
-    static constexpr int HOPS = (NI < 5 ? NI : 5) - 1;         // route_length = randint(2, min(5, NI)) -> 1..HOPS hops (utils.py:181)
-    static constexpr int HOP_BITS = bitlen(HOPS);
-    static_assert(NI >= 2 && NI <= 16, "randint(2, min(5, NI)) needs NI >= 2; 16 intersections fill the register file");
-};
-constexpr int DW = 16;             // MT words per draw-queue fill: one step() call
-constexpr int DWR = 48;            // fused rollout: a window lasts several steps, refilled wave-convergently (ensure)
+constexpr int L = 4;                    // lanes per env: a DPP quad
+constexpr int EPW = 64 / L;             // envs per wave
+constexpr int MAXNI = 16;
 constexpr int BLOCK = 64;
+constexpr int UNIT = 16;                // the LDS draw ring of an env is refilled 16 words (64 B) at a time
+// ring words per env: a fused rollout keeps 64 (a step's chain reads a 32-word view, refills trail the cursor); a step() call parks
+// the two units its one step reads.  Row stride = ring + masks (4 x ring bits) + pad: 16-byte aligned rows, and 8 consecutive envs
+// start in 8 different banks (76 = 12 mod 32, 44 = 12 mod 32)
+template <bool ROLLOUT> struct RingLay { static constexpr int RING = ROLLOUT ? 64 : 32, STRIDE = ROLLOUT ? 76 : 44; };
 // queue word: len | dest << 7 | wait << 14 (len, dest <= max_vehicles <= 127; wait <= max_vehicles * max_steps < 2^18)
 constexpr uint32_t QM = 127u;
 constexpr int QS_DEST = 7, QS_WAIT = 14;
 enum { NS_GREEN = 0, NS_YELLOW = 1, EW_GREEN = 2, EW_YELLOW = 3 };
 enum { NORTH = 0, EAST = 1, SOUTH = 2, WEST = 3 };
 
+constexpr int bitlen(int n) { int k = 0; while (n) { ++k; n >>= 1; } return k; }
+
+// device record of one env (dwords): [0] m0 = timestep:16 | nveh:7 << 16 | needs_reset << 23, [1] m1 = mt_pos:10 | ready mark:5 << 10,
+// [2] episodes, [3] mt_old0, [4..5] total_reward (float64), [6..7] 0, [8 + 4 i + d] queue word of intersection i, direction d,
+// [8 + 4 NI + 2 i] light (phase:2 | timer:5 << 2) | passed << 8, [8 + 4 NI + 2 i + 1] total_wait; padded to whole 16-byte pieces
+__host__ __device__ constexpr int rec_words(int ni) { return (8 + 6 * ni + 3) & ~3; }
+constexpr int O_Q = 8;
+
 struct Cfg {
     double spawn_rate;
     int32_t max_vehicles, max_steps;
     int32_t rows, cols;            // grid_size (environment.py:62): the grid the routes walk
+    int32_t ni;                    // controlled intersections (2..16)
+    uint32_t inv_cols;             // ceil(2^16 / cols): start / cols == (start * inv_cols) >> 16 for start < 16, cols <= 64
+    int32_t start_bits;            // random.randint(0, NI-1): _randbelow(NI), k = NI.bit_length()
+    int32_t hops, hop_bits;        // route_length = randint(2, min(5, NI)) -> 1 + _randbelow(hops), k = hops.bit_length()
 };
 
 struct Params {
-    uint4 *state;
+    uint32_t *state;
     uint32_t *mt;
     int64_t n, env0;
     Cfg cfg;
-    int32_t mode;
+    int32_t mode, recw, obsw;
+    uint32_t nwaves, per_xcd;
     const int32_t *actions;
     const uint8_t *mask;
     float *obs, *final_obs, *reward;
@@ -79,527 +95,916 @@ struct Params {
     int32_t *done_count;
     double *ep_ret;       // episode statistics (cge_traffic_episode_stats), nullable
     int32_t *ep_len;
+    float *fin_rows;      // fused rollout, SAME_STEP: compacted terminal observations (cge_traffic_rollout_final_obs), nullable
+    int64_t *fin_index;   //   [slot] = step-in-call * n + env
+    int64_t fin_cap;
+    int32_t *fin_count;
 };
 
-template <int NI_>
-struct Env {
-    using L = Lay<NI_>;
-    static constexpr int NI = L::NI, NQ = L::NQ, COLS = L::COLS;
-    uint32_t light[NI];     // phase | timer << 2
-    uint32_t q[NQ];         // len:7 | dest:7 << 7 | wait:18 << 14, queue 4*i + dir
-    uint32_t passed[NI], tw[NI];
-    uint32_t timestep, nveh, needs_reset, episodes, mt_pos, mt_pretw;
-    uint32_t mt_old0;       // word 0 of the generator's current generation once the next one has overwritten it (mt_twist_chunk)
-    double total_reward;
+// A wave-uniform base pointer plus a 32-bit per-lane byte offset: the global_store/load form with the base in SGPRs.  A kernel that
+// keeps a 64-bit per-lane pointer per store site instead (13 sites per row, rows for obs and final_obs) spends ~50 VGPRs on addresses.
+template <class T>
+__device__ __forceinline__ T *at(void *ubase, uint32_t voff) { return reinterpret_cast<T *>(static_cast<char *>(ubase) + (size_t)voff); }
+template <class T>
+__device__ __forceinline__ const T *at(const void *ubase, uint32_t voff) { return reinterpret_cast<const T *>(static_cast<const char *>(ubase) + (size_t)voff); }
 
-    __host__ __device__ __forceinline__ void unpack(const uint32_t *raw) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) light[i] = (raw[i >> 2] >> ((i & 3) * 8)) & 0xFFu;
-#pragma unroll
-        for (int k = 0; k < NQ; ++k) q[k] = raw[L::O_Q + k];
-#pragma unroll
-        for (int i = 0; i < NI; ++i) passed[i] = (raw[L::O_P + (i >> 1)] >> ((i & 1) * 16)) & 0xFFFFu;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) tw[i] = raw[L::O_TW + i];
-        const uint32_t m0 = raw[L::O_M], m1 = raw[L::O_M + 1];
-        timestep = m0 & 0xFFFFu; nveh = (m0 >> 16) & 127u; needs_reset = (m0 >> 23) & 1u;
-        mt_pos = m1 & 1023u; mt_pretw = mt_ready_decode((m1 >> 10) & 31u);     // ready mark of the twist-ahead stream (cge_device.hpp)
-        episodes = raw[L::O_M + 2];
-        const uint64_t u = ((uint64_t)raw[L::O_M + 4] << 32) | raw[L::O_M + 3];
-        memcpy(&total_reward, &u, 8);
-        mt_old0 = raw[L::O_M + 5];
-    }
-    __host__ __device__ __forceinline__ void pack(uint32_t *raw) const {
-#pragma unroll
-        for (int j = 0; j < L::O_Q; ++j) raw[j] = 0;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) raw[i >> 2] |= (light[i] & 0xFFu) << ((i & 3) * 8);
-#pragma unroll
-        for (int k = 0; k < NQ; ++k) raw[L::O_Q + k] = q[k];
-#pragma unroll
-        for (int j = L::O_P; j < L::O_TW; ++j) raw[j] = 0;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) raw[L::O_P + (i >> 1)] |= (passed[i] & 0xFFFFu) << ((i & 1) * 16);
-#pragma unroll
-        for (int i = 0; i < NI; ++i) raw[L::O_TW + i] = tw[i];
-        raw[L::O_M] = timestep | (nveh << 16) | (needs_reset << 23);
-        raw[L::O_M + 1] = mt_pos | ((mt_pretw > mt_pos ? mt_ready_encode(mt_pretw) : 0u) << 10);
-        raw[L::O_M + 2] = episodes;
-        uint64_t u;
-        memcpy(&u, &total_reward, 8);
-        raw[L::O_M + 3] = (uint32_t)u; raw[L::O_M + 4] = (uint32_t)(u >> 32);
-        raw[L::O_M + 5] = mt_old0;
-#pragma unroll
-        for (int j = L::NW; j < COLS * 4; ++j) raw[j] = 0;
-    }
-    __device__ __forceinline__ void load(const uint4 *__restrict__ s, int64_t n, int64_t i) {
-        uint32_t raw[COLS * 4];
-#pragma unroll
-        for (int c = 0; c < COLS; ++c) {
-            const uint4 v = s[(int64_t)c * n + i];
-            raw[4 * c] = v.x; raw[4 * c + 1] = v.y; raw[4 * c + 2] = v.z; raw[4 * c + 3] = v.w;
-        }
-        unpack(raw);
-    }
-    __device__ __forceinline__ void store(uint4 *__restrict__ s, int64_t n, int64_t i) const {
-        uint32_t raw[COLS * 4];
-        pack(raw);
-#pragma unroll
-        for (int c = 0; c < COLS; ++c) s[(int64_t)c * n + i] = make_uint4(raw[4 * c], raw[4 * c + 1], raw[4 * c + 2], raw[4 * c + 3]);
-    }
-    __device__ __forceinline__ void reset() {                      // environment.py:141-166 (no draws)
-#pragma unroll
-        for (int i = 0; i < NI; ++i) { light[i] = 0; passed[i] = 0; tw[i] = 0; }   // TrafficLight(): NS_GREEN, timer 0
-#pragma unroll
-        for (int k = 0; k < NQ; ++k) q[k] = 0;
-        timestep = 0; nveh = 0; needs_reset = 0; total_reward = 0.0;
-    }
-};
+// ------------------------------------------------------------------ group (quad) primitives
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true); }
+template <int M>
+__device__ __forceinline__ uint32_t gxor(uint32_t v) {                // value of lane (ql ^ M) of the same group
+    static_assert(M == 1 || M == 2, "a quad");
+    if constexpr (M == 1) return dpp<0xB1>(v);                        // quad_perm [1, 0, 3, 2]
+    else return dpp<0x4E>(v);                                         // quad_perm [2, 3, 0, 1]
+}
+template <int K>
+__device__ __forceinline__ uint32_t gbcast(uint32_t v) { return dpp<K * 0x55>(v); }    // quad_perm [K, K, K, K]
+__device__ __forceinline__ uint32_t gsum(uint32_t v) { v += gxor<1>(v); v += gxor<2>(v); return v; }
+__device__ __forceinline__ uint32_t gor(uint32_t v) { v |= gxor<1>(v); v |= gxor<2>(v); return v; }
+template <int M>
+__device__ __forceinline__ double gxor_f64(double x) {
+    uint64_t u;
+    memcpy(&u, &x, 8);
+    u = ((uint64_t)gxor<M>((uint32_t)(u >> 32)) << 32) | gxor<M>((uint32_t)u);
+    memcpy(&x, &u, 8);
+    return x;
+}
+template <int K>
+__device__ __forceinline__ double gbcast_f64(double x) {
+    uint64_t u;
+    memcpy(&u, &x, 8);
+    u = ((uint64_t)gbcast<K>((uint32_t)(u >> 32)) << 32) | gbcast<K>((uint32_t)u);
+    memcpy(&x, &u, 8);
+    return x;
+}
+// x[i % 4 slot i / 4] of the lane that owns element i (static i), for every lane of the group
+template <int IPL, int I>
+__device__ __forceinline__ double elem_f64(const double (&x)[IPL]) { return gbcast_f64<I % L>(x[I / L]); }
 
-// _spawn_vehicles :222-249 + generate_vehicle_route utils.py:174-193 (called with nveh < max_vehicles).  The route is a random
-// walk over the rows x cols grid (get_neighboring_intersections utils.py:196-214, neighbour order N, S, W, E); only where it
-// starts (the queue), its first hop (the direction, utils.py:230-248) and whether it ends where it started are observable.
-template <int NI, class DRAWS>
-__device__ __forceinline__ void spawn(Env<NI> &e, const Cfg &c, DRAWS &d) {
-    using L = Lay<NI>;
-    if (!(d.random53() < c.spawn_rate)) return;
-    const uint32_t start = d.randbelow((uint32_t)NI, L::START_BITS);   // random.randint(0, num_intersections - 1)
-    const uint32_t hops = 1u + d.randbelow((uint32_t)L::HOPS, L::HOP_BITS);   // randint(2, min(5, num_intersections)) - 1
-    const uint32_t rows = (uint32_t)c.rows, cols = (uint32_t)c.cols;
-    const uint32_t srow = start / cols, scol = start - srow * cols;
-    uint32_t row = srow, col = scol, dir = EAST;
-    for (uint32_t k = 0; k < hops; ++k) {
-        const uint32_t vN = row > 0, vS = row + 1 < rows, vW = col > 0, vE = col + 1 < cols;   // utils.py:206 order N, S, W, E
-        const uint32_t cnt = vN + vS + vW + vE;                      // >= 1: the grid has rows * cols >= NI >= 2 cells (cge_traffic_create)
-        const uint32_t r = d.randbelow(cnt, cnt == 4u ? 3 : (cnt == 1u ? 1 : 2));   // random.choice(neighbours)
-        uint32_t idx = r, mv;                                       // the r-th valid neighbour
-        if (vN && idx == 0) mv = NORTH;
-        else {
-            idx -= vN;
-            if (vS && idx == 0) mv = SOUTH;
-            else {
-                idx -= vS;
-                mv = (vW && idx == 0) ? WEST : EAST;
+// np.add.reduce over n <= 16 float64 values held one per (slot, lane) — element i in slot i / 4 of lane i % 4 — in NumPy's
+// pairwise order (numpy/core/src/umath/loops_utils.h.src: pairwise_sum, n < 128): fewer than 8 terms left to right; otherwise
+// eight accumulators r[j] = a[j] (+= a[8 + j] for each whole further block of 8), res = ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)),
+// then the remaining n % 8 terms left to right.  r0..r3 are slot 0 of lanes 0..3, r4..r7 slot 1: each half of the tree is the
+// two-step xor butterfly over the quad (a + b == b + a bit for bit, so every lane ends with the same sums).
+template <int IPL>
+__device__ __forceinline__ double pairwise_sum(const double (&x)[IPL], int n) {
+    double acc;
+    if (IPL < 2 || n < 8) {
+        acc = elem_f64<IPL, 0>(x);
+        if constexpr (IPL * L > 1) { if (n > 1) acc += elem_f64<IPL, 1>(x); }
+        if constexpr (IPL * L > 2) { if (n > 2) acc += elem_f64<IPL, 2>(x); }
+        if constexpr (IPL * L > 3) { if (n > 3) acc += elem_f64<IPL, 3>(x); }
+        if constexpr (IPL * L > 4) { if (n > 4) acc += elem_f64<IPL, 4 % (IPL * L)>(x); }
+        if constexpr (IPL * L > 5) { if (n > 5) acc += elem_f64<IPL, 5 % (IPL * L)>(x); }
+        if constexpr (IPL * L > 6) { if (n > 6) acc += elem_f64<IPL, 6 % (IPL * L)>(x); }
+        return acc;
+    }
+    if constexpr (IPL >= 2) {
+        double r0 = x[0], r1 = x[1];
+        if constexpr (IPL == 4) { if (n == 16) { r0 += x[2]; r1 += x[3]; } }
+        r0 += gxor_f64<1>(r0); r0 += gxor_f64<2>(r0);
+        r1 += gxor_f64<1>(r1); r1 += gxor_f64<2>(r1);
+        acc = r0 + r1;
+        if constexpr (IPL >= 3) {
+            if (n < 16) {
+                if (n > 8) acc += elem_f64<IPL, 8>(x);
+                if (n > 9) acc += elem_f64<IPL, 9>(x);
+                if (n > 10) acc += elem_f64<IPL, 10>(x);
+                if (n > 11) acc += elem_f64<IPL, 11>(x);
+                if constexpr (IPL == 4) {
+                    if (n > 12) acc += elem_f64<IPL, 12 % (IPL * L)>(x);
+                    if (n > 13) acc += elem_f64<IPL, 13 % (IPL * L)>(x);
+                    if (n > 14) acc += elem_f64<IPL, 14 % (IPL * L)>(x);
+                }
             }
         }
-        row += mv == SOUTH ? 1u : (mv == NORTH ? ~0u : 0u);
-        col += mv == EAST ? 1u : (mv == WEST ? ~0u : 0u);
-        if (k == 0) dir = mv;                                       // utils.py:230-248 (route[0] -> route[1])
     }
-    const uint32_t qi = start * 4u + dir;
-    const uint32_t inc = 1u | ((row == srow && col == scol) ? (1u << QS_DEST) : 0u);   // len += 1, dest += (destination == this intersection)
-#pragma unroll
-    for (int k = 0; k < 4 * NI; ++k) e.q[k] += (qi == (uint32_t)k) ? inc : 0u;
-    e.nveh += 1;
+    return acc;
 }
 
+// ------------------------------------------------------------------ the env's draw stream, group-cooperative
+// Cursor of the env's MT19937 stream as the state record keeps it (cge_device.hpp: pos, pretw, old0), plus the LDS ring:
+//   u   ring counter of the cursor (slot u & 63);  hi  ring counter up to which words are parked (a multiple of 16; hi - u <= 64).
+//       An EMPTY ring is hi = u & ~15: hi - u is then minus the cursor's place in its 16-word unit, and the next unit parked is the one
+//       the cursor stands in (ring units line up with the generator block's 16-word units).
+// Everything here is GROUP-UNIFORM: the four lanes of an env hold the same values and take the same branches.
+struct Cur { uint32_t pos, pretw, old0, u, hi; };
+
+// Twists, in place, the words from `lo` (unwrapped: >= 624 means word lo - 624 of the next generation) to the end of lo's 32-word
+// chunk; lane ql does words c0 + 8 ql .. + 7 (the last chunk of a generation holds 16 words: lanes 0 and 1).  Same contract as
+// cge_device.hpp: mt_twist_chunk (words of the chunk below lo keep their values; old0 receives the outgoing generation's word 0).
+__device__ __forceinline__ uint32_t twist_chunk_group(uint32_t *__restrict__ ublk, uint32_t boff, uint32_t lo, bool go, uint32_t &old0, uint32_t ql) {
+    const uint32_t gen = lo >= (uint32_t)MT_N ? (uint32_t)MT_N : 0u, base = lo - gen, c0 = base & ~31u;
+    const uint32_t len = (uint32_t)MT_N - c0 < 32u ? (uint32_t)MT_N - c0 : 32u;
+    const uint32_t k0 = c0 + 8u * ql;
+    uint32_t first = 0;
+    if (go && 8u * ql < len) {
+        uint32_t a[9], c[8];
+#pragma unroll
+        for (int q = 0; q < 8; q += 4) {
+            const MtQuad v = *at<MtQuad>(ublk, boff + 4u * (k0 + (uint32_t)q));
+            a[q] = v.a; a[q + 1] = v.b; a[q + 2] = v.c; a[q + 3] = v.d;
+            uint32_t ci = k0 + (uint32_t)q + MT_M;                          // == 1 mod 4: 621 is the only piece that touches the mirror
+            ci -= ci > (uint32_t)MT_N ? MT_N : 0;
+            const MtQuad w = *at<MtQuad>(ublk, boff + 4u * ci);
+            c[q] = w.a; c[q + 1] = w.b; c[q + 2] = w.c; c[q + 3] = w.d;
+        }
+        a[8] = *at<uint32_t>(ublk, boff + 4u * (k0 + 8u));                  // <= 624: the mirror of word 0
+        first = a[0];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t y = mt_twist(a[j], a[j + 1], c[j]);
+            a[j] = k0 + (uint32_t)j < base ? a[j] : y;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q += 4) {
+            *at<MtQuad>(ublk, boff + 4u * (k0 + (uint32_t)q)) = MtQuad{a[q], a[q + 1], a[q + 2], a[q + 3]};
+            if (k0 + (uint32_t)q < (uint32_t)MT_PAD) *at<MtQuad>(ublk, boff + 4u * ((uint32_t)MT_N + k0 + (uint32_t)q)) = MtQuad{a[q], a[q + 1], a[q + 2], a[q + 3]};
+        }
+    }
+    const uint32_t w0 = gbcast<0>(first);
+    if (go && c0 == 0u) old0 = w0;                                          // the previous generation's word 0 goes away now
+    return gen + c0 + len;
+}
+
+template <bool ROLLOUT>
+struct Draws {
+    uint32_t *ring;       // this env's LDS row: [0, RING) tempered words, then the 4 acceptance masks (RING bits each, bit r = ring slot r)
+    uint32_t *blk;        // generator block of the wave's first env (wave-uniform)
+    uint32_t boff;        // byte offset of this env's block from there
+    Cur c;
+    uint32_t ql;
+    uint32_t T0, N11, S, A;      // the masks of words [u, u + 32), valid words only
+    uint32_t p;                  // words of the view consumed so far
+    bool ovf;                    // a link ran off the view
+    // a step() call parks what one step typically needs (two units: one 128-byte line); a rollout keeps the ring full
+    static constexpr uint32_t MINV = ROLLOUT ? 49u : 17u;
+    static constexpr uint32_t RING = RingLay<ROLLOUT>::RING, RMASK = RING - 1u;
+
+    __device__ __forceinline__ uint32_t word(uint32_t j) const { return ring[(c.u + j) & RMASK]; }   // tempered word j places after the cursor
+    __device__ __forceinline__ int32_t valid() const { return (int32_t)(c.hi - c.u); }             // parked words from the cursor on (<= 0: none)
+
+    // parks the next unit of 16 generator words for the groups with `want` (ring slots of a fully consumed unit)
+    __device__ __forceinline__ void park_unit(bool want, const Cfg &cfg) {
+        // the unit's words, unwrapped: [pos + (hi - u), + 16); they must be ready (twisted).  Wave-convergent: while some group is
+        // short, the groups that would be short within another unit twist their next chunk in the same round
+        const uint32_t gend = c.pos + (c.hi - c.u) + UNIT;
+        bool twisted = false;
+#pragma unroll 1
+        while (__ballot(want && (c.pretw > c.pos ? c.pretw : c.pos) < gend)) {
+            const uint32_t lo = c.pretw > c.pos ? c.pretw : c.pos;
+            const bool go = want && lo < gend + UNIT;
+            const uint32_t t = twist_chunk_group(blk, boff, lo, go, c.old0, ql);
+            if (go) c.pretw = t;
+            twisted = true;
+        }
+        if (twisted) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the quad's stores before the quad's loads of the same words
+        if (want) {
+            uint32_t gidx = c.pos + (c.hi - c.u);
+            gidx -= gidx >= (uint32_t)MT_N ? MT_N : 0;
+            const uint4 v = *at<uint4>(blk, boff + 4u * (gidx + 4u * ql));                    // gidx is a multiple of 16
+            const uint32_t w[4] = {mt_temper(v.x), mt_temper(v.y), mt_temper(v.z), mt_temper(v.w)};
+            uint32_t t0 = 0, n11 = 0, s = 0, a = 0;
+            const uint32_t ssh = 32u - (uint32_t)cfg.start_bits;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                t0 |= (uint32_t)((w[b] >> 31) == 0u) << b;                  // top bit clear: _randbelow(2^k) halves
+                n11 |= (uint32_t)((w[b] >> 30) != 3u) << b;                 // _randbelow(3), k = 2
+                s |= (uint32_t)((w[b] >> ssh) < (uint32_t)cfg.ni) << b;     // _randbelow(NI)
+                a |= (uint32_t)((w[b] >> 27) < 26u) << b;                   // _randbelow(26), k = 5
+            }
+            const uint32_t slot = c.hi & RMASK;
+            *reinterpret_cast<uint4 *>(ring + slot + 4u * ql) = make_uint4(w[0], w[1], w[2], w[3]);
+            const uint32_t x = gor((t0 | (n11 << 16)) << (4u * ql)), y = gor((s | (a << 16)) << (4u * ql));
+            const uint32_t mine = ql == 0u ? x & 0xFFFFu : ql == 1u ? x >> 16 : ql == 2u ? y & 0xFFFFu : y >> 16;
+            reinterpret_cast<uint16_t *>(ring + RING)[ql * (RING / 16u) + (slot >> 4)] = (uint16_t)mine;     // mask ql, unit slot / 16
+            c.hi += UNIT;
+        }
+    }
+    __device__ __forceinline__ void view() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int32_t nv = valid();
+        const uint32_t vm = nv >= 32 ? 0xFFFFFFFFu : (nv > 0 ? (1u << nv) - 1u : 0u);
+        const uint32_t su = c.u & RMASK, sh = su & 31u;
+        if constexpr (RING == 64u) {
+            const uint4 m0 = *reinterpret_cast<const uint4 *>(ring + RING), m1 = *reinterpret_cast<const uint4 *>(ring + RING + 4);
+            const bool up = su >= 32u;
+            T0 = __builtin_amdgcn_alignbit(up ? m0.x : m0.y, up ? m0.y : m0.x, sh) & vm;
+            N11 = __builtin_amdgcn_alignbit(up ? m0.z : m0.w, up ? m0.w : m0.z, sh) & vm;
+            S = __builtin_amdgcn_alignbit(up ? m1.x : m1.y, up ? m1.y : m1.x, sh) & vm;
+            A = __builtin_amdgcn_alignbit(up ? m1.z : m1.w, up ? m1.w : m1.z, sh) & vm;
+        } else {                                                   // 32-word ring: the view is the mask word rotated to the cursor
+            const uint4 m = *reinterpret_cast<const uint4 *>(ring + RING);
+            T0 = __builtin_amdgcn_alignbit(m.x, m.x, sh) & vm;
+            N11 = __builtin_amdgcn_alignbit(m.y, m.y, sh) & vm;
+            S = __builtin_amdgcn_alignbit(m.z, m.z, sh) & vm;
+            A = __builtin_amdgcn_alignbit(m.w, m.w, sh) & vm;
+        }
+    }
+    __device__ __forceinline__ void consume() {                 // the p words the last chain took leave the stream
+        c.u += p;
+        mt_advance(c.pos, c.pretw, p);
+        p = 0;
+    }
+    // kernel start, and after slow_draws: nothing parked
+    __device__ __forceinline__ void init() { c.u = c.pos & 15u; c.hi = 0; p = 0; ovf = false; }
+    // top of a step: the consumed words go, free units are refilled (wave-convergent), the view is rebuilt.  live: this group owns an env
+    __device__ __forceinline__ void prepare(const Cfg &cfg, uint32_t minv = MINV) {
+        consume();
+#pragma unroll 1
+        while (__ballot(valid() < (int32_t)minv)) park_unit(valid() < (int32_t)minv, cfg);
+        view();
+        ovf = false;
+    }
+    // one `_randbelow`: the first word at or after the cursor that `mask` accepts; returns its top `bits` bits.  Words it skips
+    // are the reference's rejected draws.  No such word inside the view: ovf.
+    __device__ __forceinline__ uint32_t link(uint32_t mask, uint32_t bits, bool act) {
+        const uint32_t m = (uint32_t)((uint64_t)mask >> p);     // p <= 32
+        const uint32_t ps = p + (uint32_t)__builtin_ctz(m | 0x80000000u);
+        const uint32_t v = word(ps) >> (32u - bits);
+        if (act) {
+            if (m == 0u) ovf = true;
+            else p = ps + 1u;
+        }
+        return v;
+    }
+};
+
+// what the draws of one step decide (group-uniform): the timers of the lights that turned green, and the spawned vehicle
+struct DrawOut {
+    uint32_t tv[4];       // 5-bit values of randint(5, 30) - 5 for intersections 0..15 (6 per word, 4 in the last)
+    uint32_t spawn;       // spawned | dir << 1 | dest << 3 | start << 4
+};
+__device__ __forceinline__ void set_tv(DrawOut &o, uint32_t i, uint32_t v, bool act) {
+    const uint32_t wd = i / 6u, sh = (i - wd * 6u) * 5u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o.tv[k] |= (act && wd == (uint32_t)k) ? v << sh : 0u;
+}
+__device__ __forceinline__ uint32_t get_tv(const DrawOut &o, uint32_t i) {
+    const uint32_t wd = i / 6u, sh = (i - wd * 6u) * 5u;
+    uint32_t w = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w |= wd == (uint32_t)k ? o.tv[k] : 0u;
+    return (w >> sh) & 31u;
+}
+
+// one hop of generate_vehicle_route's random walk (utils.py:174-214): random.choice over the valid neighbours in the order N, S, W, E
+__device__ __forceinline__ void walk(uint32_t r, uint32_t vN, uint32_t vS, uint32_t vW, uint32_t &row, uint32_t &col, uint32_t &mv) {
+    uint32_t idx = r;
+    if (vN && idx == 0) mv = NORTH;
+    else {
+        idx -= vN;
+        if (vS && idx == 0) mv = SOUTH;
+        else {
+            idx -= vS;
+            mv = (vW && idx == 0) ? WEST : EAST;
+        }
+    }
+    row += mv == SOUTH ? 1u : (mv == NORTH ? ~0u : 0u);
+    col += mv == EAST ? 1u : (mv == WEST ? ~0u : 0u);
+}
+
+// The draws of one step, in the reference's order, as one straight-line chain on the view's acceptance masks:
+//   TrafficLight.update (utils.py:79-97): random.randint(5, 30) for every light that enters a green phase, intersection order;
+//   _spawn_vehicles (:222-249) if nveh < max_vehicles: random.random() < spawn_rate, randint(0, NI - 1), randint(2, min(5, NI)),
+//   then one random.choice per hop.
+template <bool ROLLOUT>
+__device__ __forceinline__ DrawOut fast_draws(Draws<ROLLOUT> &d, const Cfg &cfg, uint32_t needmask, bool try_spawn) {
+    DrawOut o{{0, 0, 0, 0}, 0};
+    uint32_t nm = needmask;
+#pragma unroll 1
+    while (__ballot(nm != 0u)) {
+        const bool act = nm != 0u;
+        const uint32_t i = (uint32_t)__builtin_ctz(nm | 0x10000u);
+        const uint32_t v = d.link(d.A, 5, act);
+        set_tv(o, i, v, act);
+        nm &= nm - 1u;
+    }
+    if (__ballot(try_spawn)) {
+        // random.random(): two words
+        const uint32_t avail = d.valid() < 32 ? (uint32_t)(d.valid() > 0 ? d.valid() : 0) : 32u;
+        const uint32_t a = d.word(d.p) >> 5, b = d.word(d.p + 1u) >> 6;
+        const double r = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+        bool spawned = false;
+        if (try_spawn) {
+            if (d.p + 2u > avail) d.ovf = true;
+            else { d.p += 2u; spawned = r < cfg.spawn_rate; }
+        }
+        if (__ballot(spawned)) {
+            const uint32_t start = d.link(d.S, (uint32_t)cfg.start_bits, spawned);
+            const uint32_t hmask = cfg.hops == 3 ? d.N11 : d.T0;                 // _randbelow(hops): hops 1, 2, 4 accept "top bit clear"
+            const uint32_t hops = 1u + d.link(hmask, (uint32_t)cfg.hop_bits, spawned);
+            const uint32_t rows = (uint32_t)cfg.rows, cols = (uint32_t)cfg.cols;
+            const uint32_t srow = (start * cfg.inv_cols) >> 16, scol = start - srow * cols;
+            uint32_t row = srow, col = scol, dir = EAST;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool act = spawned && (uint32_t)k < hops;
+                if (__ballot(act)) {
+                    const uint32_t vN = row > 0, vS = row + 1 < rows, vW = col > 0, vE = col + 1 < cols;   // utils.py:206 order N, S, W, E
+                    const uint32_t cnt = vN + vS + vW + vE;                  // >= 1: the grid has rows * cols >= NI >= 2 cells
+                    // random.choice(neighbours) = _randbelow(cnt): k = 3 for 4 (accept < 4: top bit clear), 2 for 3 (reject 11) and 2
+                    // (top bit clear), 1 for 1 (top bit clear)
+                    const uint32_t r2 = d.link(cnt == 3u ? d.N11 : d.T0, cnt == 4u ? 3u : (cnt == 1u ? 1u : 2u), act);
+                    uint32_t mv, nrow = row, ncol = col;
+                    walk(r2, vN, vS, vW, nrow, ncol, mv);
+                    if (act) { row = nrow; col = ncol; if (k == 0) dir = mv; }     // utils.py:230-248 (route[0] -> route[1])
+                }
+            }
+            const uint32_t dest = (row == srow && col == scol) ? 1u : 0u;       // destination == this intersection
+            if (spawned) o.spawn = 1u | (dir << 1) | (dest << 3) | (start << 4);
+        }
+    }
+    return o;
+}
+
+// The same draws word by word, for a group whose chain ran off its view (a light-timer burst after a reset, a long rejection
+// run): rare.  Straight from the generator block through the serial stream of cge_device.hpp (MtStream: a ready word is a load, any
+// other word is twisted on the spot — the four lanes of the quad store the same value), one loop around ONE "next word" site
+// driven by a small state machine over the reference's draw sequence.  The ring is dropped; the next prepare() parks afresh.
+struct SlowOut { uint32_t pos, pretw; DrawOut o; };
+__device__ __forceinline__ SlowOut slow_draws(uint32_t *blk, uint32_t pos, uint32_t pretw, const Cfg &cfg, uint32_t needmask, bool try_spawn) {
+    MtStream st(blk, pos, pretw);
+    SlowOut out;
+    out.o = DrawOut{{0, 0, 0, 0}, 0};
+    enum { LIGHT, RAND_A, RAND_B, START, HOPS, HOP, DONE };
+    uint32_t nm = needmask, stage = nm ? LIGHT : (try_spawn ? RAND_A : DONE);
+    uint32_t ra = 0, start = 0, hops = 0, k = 0, srow = 0, scol = 0, row = 0, col = 0, dir = EAST;
+    const uint32_t rows = (uint32_t)cfg.rows, cols = (uint32_t)cfg.cols;
+#pragma unroll 1
+    while (stage != DONE) {
+        const uint32_t w = st.next();
+        // CPython _randbelow_with_getrandbits(n): r = getrandbits(k); a word with r >= n is dropped and the stage repeats
+        if (stage == LIGHT) {
+            const uint32_t r = w >> 27;
+            if (r < 26u) {
+                set_tv(out.o, (uint32_t)__builtin_ctz(nm), r, true);
+                nm &= nm - 1u;
+                if (!nm) stage = try_spawn ? RAND_A : DONE;
+            }
+        } else if (stage == RAND_A) {
+            ra = w >> 5; stage = RAND_B;
+        } else if (stage == RAND_B) {
+            const double r = ((double)ra * 67108864.0 + (double)(w >> 6)) / 9007199254740992.0;
+            stage = r < cfg.spawn_rate ? START : DONE;
+        } else if (stage == START) {
+            const uint32_t r = w >> (32u - (uint32_t)cfg.start_bits);
+            if (r < (uint32_t)cfg.ni) {
+                start = r; srow = (start * cfg.inv_cols) >> 16; scol = start - srow * cols; row = srow; col = scol;
+                stage = HOPS;
+            }
+        } else if (stage == HOPS) {
+            const uint32_t r = w >> (32u - (uint32_t)cfg.hop_bits);
+            if (r < (uint32_t)cfg.hops) { hops = 1u + r; k = 0; stage = HOP; }
+        } else {
+            const uint32_t vN = row > 0, vS = row + 1 < rows, vW = col > 0, vE = col + 1 < cols;
+            const uint32_t cnt = vN + vS + vW + vE;
+            const uint32_t r = w >> (32u - (cnt == 4u ? 3u : (cnt == 1u ? 1u : 2u)));
+            if (r < cnt) {
+                uint32_t mv;
+                walk(r, vN, vS, vW, row, col, mv);
+                if (k == 0) dir = mv;
+                if (++k == hops) {
+                    out.o.spawn = 1u | (dir << 1) | ((row == srow && col == scol) ? 8u : 0u) | (start << 4);
+                    stage = DONE;
+                }
+            }
+        }
+    }
+    out.pos = st.pos; out.pretw = st.pretw;
+    return out;
+}
+
+// on-device phase clocks (-DCGE_TRAFFIC_TIMING builds only: tools/probes/traffic_timing.py); a TICK drains the wave's memory counters
 #ifdef CGE_TRAFFIC_TIMING
 __device__ unsigned long long g_timing[4096 * 16];
 #define TICK(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = wall_clock64(); \
     if (threadIdx.x == 0 && blockIdx.x < 4096) { g_timing[blockIdx.x * 16 + k] += now_ - t_last; } t_last = now_; } while (0)
 #define TICK_DECL unsigned long long t_last = wall_clock64();
-#define TICK_ARG , unsigned long long &t_last
-#define TICK_PASS , t_last
 #else
 #define TICK(k)
 #define TICK_DECL
-#define TICK_ARG
-#define TICK_PASS
 #endif
-// one reference step() (:168-203); returns terminated, reward in float64
-template <int NI, class DRAWS>
-__device__ __forceinline__ bool env_step(Env<NI> &e, const Cfg &c, const uint32_t (&a)[NI], DRAWS &d, double &reward TICK_ARG) {
-    e.timestep += 1;
-    d.ensure_ahead(12, true);
-    TICK(1);                                                                      // typical step: 1-2 light timers + a spawn with 1-4 hops
+
+// ------------------------------------------------------------------ one env, spread over its quad
+template <int IPL>
+struct Env {
+    uint32_t q[IPL][4];         // queue words of intersection 4 s + ql, directions N, E, S, W
+    uint32_t lp[IPL], tw[IPL];  // light | passed << 8; total_wait
+    // group-uniform
+    uint32_t timestep, nveh, needs_reset, episodes;
+    double total_reward;
+
+    __device__ __forceinline__ void load(const uint32_t *__restrict__ rec, int ni, uint32_t ql, Cur &c) {
+        const uint4 m = *reinterpret_cast<const uint4 *>(rec);
+        const uint2 tr = *reinterpret_cast<const uint2 *>(rec + 4);
+        timestep = m.x & 0xFFFFu; nveh = (m.x >> 16) & 127u; needs_reset = (m.x >> 23) & 1u;
+        c.pos = m.y & 1023u; c.pretw = mt_ready_decode((m.y >> 10) & 31u);
+        episodes = m.z; c.old0 = m.w;
+        const uint64_t u = ((uint64_t)tr.y << 32) | tr.x;
+        memcpy(&total_reward, &u, 8);
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        uint32_t phase = e.light[i] & 3u, timer = e.light[i] >> 2;
-        if (a[i] == 1u && phase != NS_GREEN) { phase = NS_GREEN; timer = 5; }          // _apply_actions :205-220
-        else if (a[i] == 2u && phase != EW_GREEN) { phase = EW_GREEN; timer = 5; }
-        e.light[i] = phase | (timer << 2);
-    }
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {                                                     // TrafficLight.update utils.py:79-97
-        uint32_t phase = e.light[i] & 3u;
-        int timer = (int)(e.light[i] >> 2) - 1;
-        if (timer <= 0) {
-            phase = (phase + 1u) & 3u;
-            timer = (phase & 1u) ? 3 : 5 + (int)d.randbelow(26u, 5);                   // random.randint(5, 30)
+        for (int s = 0; s < IPL; ++s) {
+            const int i = s * L + (int)ql;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            uint2 w = make_uint2(0, 0);
+            if (i < ni) {
+                v = *reinterpret_cast<const uint4 *>(rec + O_Q + 4 * i);
+                w = *reinterpret_cast<const uint2 *>(rec + O_Q + 4 * ni + 2 * i);
+            }
+            q[s][0] = v.x; q[s][1] = v.y; q[s][2] = v.z; q[s][3] = v.w;
+            lp[s] = w.x; tw[s] = w.y;
         }
-        e.light[i] = phase | ((uint32_t)timer << 2);
     }
-    TICK(2);
-    if (e.nveh < (uint32_t)c.max_vehicles) spawn<NI>(e, c, d);                         // returns BEFORE drawing when full
-    TICK(3);
-    uint32_t tp = 0, twsum = 0, tq = 0, qt[NI];
+    __device__ __forceinline__ void store(uint32_t *__restrict__ rec, int ni, uint32_t ql, const Cur &c) const {
+        if (ql == 0u) {
+            uint64_t u;
+            memcpy(&u, &total_reward, 8);
+            *reinterpret_cast<uint4 *>(rec) = make_uint4(timestep | (nveh << 16) | (needs_reset << 23),
+                                                         c.pos | ((c.pretw > c.pos ? mt_ready_encode(c.pretw) : 0u) << 10), episodes, c.old0);
+            *reinterpret_cast<uint4 *>(rec + 4) = make_uint4((uint32_t)u, (uint32_t)(u >> 32), 0u, 0u);
+        }
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {                                                     // process_vehicles utils.py:141-163
-        const uint32_t phase = e.light[i] & 3u;
-        qt[i] = 0;
+        for (int s = 0; s < IPL; ++s) {
+            const int i = s * L + (int)ql;
+            if (i < ni) {
+                *reinterpret_cast<uint4 *>(rec + O_Q + 4 * i) = make_uint4(q[s][0], q[s][1], q[s][2], q[s][3]);
+                *reinterpret_cast<uint2 *>(rec + O_Q + 4 * ni + 2 * i) = make_uint2(lp[s], tw[s]);
+            }
+        }
+    }
+    // the same record into the wave's LDS image of its 16 records (rec = image + g * recw), streamed out by stream_image
+    __device__ __forceinline__ void stage_record(uint32_t *__restrict__ rec, int ni, int recw, uint32_t ql, const Cur &c) const {
+        if (ql == 0u) {
+            uint64_t u;
+            memcpy(&u, &total_reward, 8);
+            *reinterpret_cast<uint4 *>(rec) = make_uint4(timestep | (nveh << 16) | (needs_reset << 23),
+                                                         c.pos | ((c.pretw > c.pos ? mt_ready_encode(c.pretw) : 0u) << 10), episodes, c.old0);
+            *reinterpret_cast<uint4 *>(rec + 4) = make_uint4((uint32_t)u, (uint32_t)(u >> 32), 0u, 0u);
+        }
+        if (ql == 1u) for (int k = O_Q + 6 * ni; k < recw; ++k) rec[k] = 0;       // the record's padding
 #pragma unroll
-        for (int dd = 0; dd < 4; ++dd) {
-            uint32_t &qq = e.q[i * 4 + dd];
-            const uint32_t len = qq & QM;
-            const bool pass = (dd == NORTH || dd == SOUTH) ? phase == NS_GREEN : phase == EW_GREEN;
-            if (len) {
-                if (pass) {
-                    e.passed[i] += len;
-                    e.nveh -= (qq >> QS_DEST) & QM;                                    // reached destination -> removed
-                    qq = 0;
-                } else {
-                    qq += len << QS_WAIT;
-                    e.tw[i] += len;
+        for (int s = 0; s < IPL; ++s) {
+            const int i = s * L + (int)ql;
+            if (i < ni) {
+                *reinterpret_cast<uint4 *>(rec + O_Q + 4 * i) = make_uint4(q[s][0], q[s][1], q[s][2], q[s][3]);
+                *reinterpret_cast<uint2 *>(rec + O_Q + 4 * ni + 2 * i) = make_uint2(lp[s], tw[s]);
+            }
+        }
+    }
+    __device__ __forceinline__ void reset() {                      // environment.py:141-166 (no draws)
+#pragma unroll
+        for (int s = 0; s < IPL; ++s) { lp[s] = 0; tw[s] = 0; q[s][0] = q[s][1] = q[s][2] = q[s][3] = 0; }   // TrafficLight(): NS_GREEN, timer 0
+        timestep = 0; nveh = 0; needs_reset = 0; total_reward = 0.0;
+    }
+};
+
+struct Totals { uint32_t tp, tw, tq; };
+
+template <int IPL>
+__device__ __forceinline__ Totals totals(const Env<IPL> &e) {
+    uint32_t tp = 0, tws = 0, tq = 0;
+#pragma unroll
+    for (int s = 0; s < IPL; ++s) {
+        tp += e.lp[s] >> 8; tws += e.tw[s];
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) tq += e.q[s][dd] & QM;
+    }
+    return Totals{gsum(tp), gsum(tws), gsum(tq)};
+}
+
+// the four global features (:352-361), one per lane: [nveh, tw / max(tp, 1), tq / NI, tp / NI] in float64 (ONE division for the quad;
+// features 1 and 2 are capped at 100 / 50 by cap_feature)
+__device__ __forceinline__ double global_feature(uint32_t ql, uint32_t nveh, const Totals &t, int ni) {
+    const uint32_t num = ql == 0u ? nveh : ql == 1u ? t.tw : ql == 2u ? t.tq : t.tp;
+    const uint32_t den = ql == 0u ? 1u : ql == 1u ? (t.tp > 1u ? t.tp : 1u) : (uint32_t)ni;
+    return (double)num / (double)den;
+}
+__device__ __forceinline__ double cap_feature(uint32_t ql, double v) {
+    const double cap = ql == 1u ? 100.0 : 50.0;
+    return (ql == 1u || ql == 2u) ? (v < cap ? v : cap) : v;
+}
+
+// _get_observation :313-363: this lane's 16-byte pieces of the env's row (its intersections' columns) + its global feature.
+// rows: wave-uniform pointer to the row of the wave's first env; roff: byte offset of this env's row from there
+template <int IPL>
+__device__ __forceinline__ void emit_row(const Env<IPL> &e, float *__restrict__ rows, uint32_t roff, int ni, uint32_t ql, float glob, bool on) {
+    if (!on) return;
+#pragma unroll
+    for (int s = 0; s < IPL; ++s) {
+        const int i = s * L + (int)ql;
+        if (i < ni) {
+            const uint32_t ph = e.lp[s] & 3u;
+            *at<Piece16>(rows, roff + 16u * (uint32_t)i) = Piece16{ph == 0u ? 0x3F800000u : 0u, ph == 1u ? 0x3F800000u : 0u,
+                                                                    ph == 2u ? 0x3F800000u : 0u, ph == 3u ? 0x3F800000u : 0u};
+            float ln[4], av[4];
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {
+                const uint32_t qq = e.q[s][dd], len = qq & QM;
+                ln[dd] = (float)(len < 20u ? len : 20u);
+                const float a = len ? (float)(qq >> QS_WAIT) / (float)len : 0.0f;      // == float32(float64 quotient): see the file header
+                av[dd] = a < 100.0f ? a : 100.0f;
+            }
+            *at<Piece16>(rows, roff + 16u * (uint32_t)(ni + i)) = Piece16{__float_as_uint(ln[0]), __float_as_uint(ln[1]), __float_as_uint(ln[2]), __float_as_uint(ln[3])};
+            *at<Piece16>(rows, roff + 16u * (uint32_t)(2 * ni + i)) = Piece16{__float_as_uint(av[0]), __float_as_uint(av[1]), __float_as_uint(av[2]), __float_as_uint(av[3])};
+            const uint32_t twc = e.tw[s] < 1000u ? e.tw[s] : 1000u;
+            *at<Piece8>(rows, roff + 8u * (uint32_t)(6 * ni + i)) = Piece8{__float_as_uint((float)(e.lp[s] >> 8)), __float_as_uint((float)twc)};
+        }
+    }
+    *at<float>(rows, roff + 4u * (uint32_t)(14 * ni) + 4u * ql) = glob;
+}
+
+// Streams `bytes` (a multiple of 8) of the wave's LDS image to `dst` (16-byte aligned, the image's place in HBM): lane l of the
+// `nact` active lanes (the first nact of the wave) moves the 16-byte pieces l, l + nact, ... — one store instruction = nact x 16
+// CONTIGUOUS bytes, whole 128-byte lines.  (Pieces stored from registers where they arise — 64 contiguous bytes per quad and
+// instruction, every line completed by several instructions — cost 1.38x the bytes at the memory side (PMC WRITE_SIZE) and
+// 40 of the 54 us of a 262,144-env rollout step; round 4, profiles/r04_traffic_store_pattern_ab.txt.)
+template <int MAXW>                    // MAXW: words of the largest image (compile time): a full wave's pieces are read in one batch
+__device__ __forceinline__ void stream_image(const uint32_t *__restrict__ img, void *__restrict__ dst, uint32_t bytes, uint32_t lane, uint32_t nact) {
+    const uint32_t n16 = bytes >> 4;
+    if (nact == 64u) {
+        constexpr int J = (MAXW / 4 + 63) / 64;
+        uint4 v[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {                       // all LDS reads first (past the image's end: its last piece again), then the stores
+            const uint32_t k = lane + 64u * j;
+            v[j] = *reinterpret_cast<const uint4 *>(img + 4u * (k < n16 ? k : n16 - 1u));
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const uint32_t k = lane + 64u * j;
+            if (k < n16) *at<uint4>(dst, 16u * k) = v[j];
+        }
+    } else {
+#pragma unroll 1
+        for (uint32_t k = lane; k < n16; k += nact) *at<uint4>(dst, 16u * k) = *reinterpret_cast<const uint4 *>(img + 4u * k);
+    }
+    if ((bytes & 8u) && lane == 0u) *at<uint2>(dst, 16u * n16) = *reinterpret_cast<const uint2 *>(img + 4u * n16);
+}
+
+struct __attribute__((aligned(8))) Half16 { uint32_t a, b, c, d; };      // a 16-byte piece at 8-byte alignment (LDS rows are 520 B apart)
+
+// The observation rows of the wave's envs, through LDS: the quads write their pieces into an image of 8 consecutive rows (two
+// passes: rows 0..7, rows 8..15 — a 16-row image would leave room for three waves per SIMD), the wave streams the image out.
+// `block`: wave-uniform pointer to the first row of the wave; rows_live: rows of the wave that exist (16 but for the batch's tail)
+template <int IPL, int MAXW>
+__device__ __forceinline__ void emit_staged(const Env<IPL> &e, uint32_t *__restrict__ stage, float *__restrict__ block, int ni, uint32_t lane,
+                                            float glob, uint32_t rows_live) {
+    const uint32_t ql = lane & (uint32_t)(L - 1), g = lane / (uint32_t)L;
+    const uint32_t obsw = (uint32_t)(14 * ni + 4);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (rows_live > 8u * h) {
+            if ((g >> 3) == (uint32_t)h) {
+                uint32_t *row = stage + (g & 7u) * obsw;
+#pragma unroll
+                for (int s = 0; s < IPL; ++s) {
+                    const int i = s * L + (int)ql;
+                    if (i < ni) {
+                        const uint32_t ph = e.lp[s] & 3u;
+                        *reinterpret_cast<Half16 *>(row + 4 * i) = Half16{ph == 0u ? 0x3F800000u : 0u, ph == 1u ? 0x3F800000u : 0u,
+                                                                          ph == 2u ? 0x3F800000u : 0u, ph == 3u ? 0x3F800000u : 0u};
+                        float ln[4], av[4];
+#pragma unroll
+                        for (int dd = 0; dd < 4; ++dd) {
+                            const uint32_t qq = e.q[s][dd], len = qq & QM;
+                            ln[dd] = (float)(len < 20u ? len : 20u);
+                            const float a = len ? (float)(qq >> QS_WAIT) / (float)len : 0.0f;      // == float32(float64 quotient): see the file header
+                            av[dd] = a < 100.0f ? a : 100.0f;
+                        }
+                        *reinterpret_cast<Half16 *>(row + 4 * (ni + i)) = Half16{__float_as_uint(ln[0]), __float_as_uint(ln[1]), __float_as_uint(ln[2]), __float_as_uint(ln[3])};
+                        *reinterpret_cast<Half16 *>(row + 4 * (2 * ni + i)) = Half16{__float_as_uint(av[0]), __float_as_uint(av[1]), __float_as_uint(av[2]), __float_as_uint(av[3])};
+                        const uint32_t twc = e.tw[s] < 1000u ? e.tw[s] : 1000u;
+                        *reinterpret_cast<uint2 *>(row + 12 * ni + 2 * i) = make_uint2(__float_as_uint((float)(e.lp[s] >> 8)), __float_as_uint((float)twc));
+                    }
                 }
+                row[14 * ni + (int)ql] = __float_as_uint(glob);
             }
-            qt[i] += qq & QM;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const uint32_t rows = rows_live - 8u * h < 8u ? rows_live - 8u * h : 8u;
+            stream_image<MAXW>(stage, block + (size_t)(8 * h) * obsw, rows * obsw * 4u, lane, rows_live * (uint32_t)L < 64u ? rows_live * (uint32_t)L : 64u);
+            asm volatile("" ::: "memory");
         }
-        tp += e.passed[i]; twsum += e.tw[i]; tq += qt[i];
-    }
-    // _calculate_reward :287-311; np.var over the NI queue totals (population variance).  NumPy's pairwise summation: fewer than
-    // 8 terms are added left to right, otherwise eight accumulators run over whole blocks of 8, are combined as a tree, and the
-    // remainder follows left to right
-    const double mean = (double)tq / (double)NI;
-    double x[NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) { const double dv = (double)qt[i] - mean; x[i] = dv * dv; }
-    double var;
-    if constexpr (NI < 8) {
-        var = x[0];
-#pragma unroll
-        for (int i = 1; i < NI; ++i) var += x[i];
-    } else {
-        double r8[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) r8[j] = x[j];
-#pragma unroll
-        for (int i = 8; i + 8 <= NI; i += 8)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) r8[j] += x[i + j];
-        var = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
-#pragma unroll
-        for (int i = NI - NI % 8; i < NI; ++i) var += x[i];
-    }
-    var = var / (double)NI;
-    double r = 0.0;
-    r += (double)tp * 1.0;
-    r += (double)twsum * -0.1;
-    r += (double)tq * -0.05;
-    r += 0.5 / (1.0 + var);
-    e.total_reward += r;
-    reward = r;
-    TICK(4);
-    return e.timestep >= (uint32_t)c.max_steps;
-}
-
-struct ObsTotals { uint32_t tp, tw, tq; };
-
-// _get_observation :313-363, element J of the 14 NI + 4 (compile-time J)
-template <int NI, int J>
-__device__ __forceinline__ float obs_val(const Env<NI> &e, const ObsTotals &t) {
-    if constexpr (J < 4 * NI) return (e.light[J / 4] & 3u) == (uint32_t)(J % 4) ? 1.0f : 0.0f;
-    else if constexpr (J < 8 * NI) { const uint32_t len = e.q[J - 4 * NI] & QM; return (float)(len < 20u ? len : 20u); }
-    else if constexpr (J < 12 * NI) {
-        const uint32_t qq = e.q[J - 8 * NI], len = qq & QM;
-        const double avg = len ? (double)(qq >> QS_WAIT) / (double)len : 0.0;
-        return (float)(avg < 100.0 ? avg : 100.0);
-    } else if constexpr (J < 14 * NI) {
-        constexpr int k = J - 12 * NI;
-        if constexpr (k % 2 == 0) return (float)e.passed[k / 2];
-        else return (float)(e.tw[k / 2] < 1000u ? e.tw[k / 2] : 1000u);
-    } else if constexpr (J == 14 * NI) return (float)e.nveh;
-    else if constexpr (J == 14 * NI + 1) { const double v = (double)t.tw / (double)(t.tp > 1u ? t.tp : 1u); return (float)(v < 100.0 ? v : 100.0); }
-    else if constexpr (J == 14 * NI + 2) { const double v = (double)t.tq / (double)NI; return (float)(v < 50.0 ? v : 50.0); }
-    else return (float)((double)t.tp / (double)NI);
-}
-
-template <int NI, int BASE, int... Js>
-__device__ __forceinline__ void fill_chunk(const Env<NI> &e, const ObsTotals &t, float (&out)[sizeof...(Js)], std::integer_sequence<int, Js...>) {
-    ((out[Js] = obs_val<NI, BASE + Js>(e, t)), ...);
-}
-
-// (stored as the dwords they are read back as: float stores that are only ever read through the tile's uint32_t pointer are, by the
-// type-based aliasing rules, dead to the compiler — it dropped whole chunks of them)
-template <int NI, int BASE, int... Js>
-__device__ __forceinline__ void stage_chunk(const Env<NI> &e, const ObsTotals &t, uint32_t *row, std::integer_sequence<int, Js...>) {
-    ((row[Js] = __float_as_uint(obs_val<NI, BASE + Js>(e, t))), ...);
-}
-
-// OWN rows: chunk C of OWN_CH values (or the last OBS % OWN_CH) straight from registers.  (Chunks of 16 or 8 values leave the
-// rollout kernel at 195-197 VGPRs, round 3: the register peak is in env_step, not here.)
-constexpr int OWN_CH = 32;
-template <int NI, int C>
-__device__ __forceinline__ void own_chunks(const Env<NI> &e, const ObsTotals &t, float *row, bool mine) {
-    constexpr int OBS = Lay<NI>::OBS, N = OBS - OWN_CH * C < OWN_CH ? OBS - OWN_CH * C : OWN_CH;
-    if constexpr (N > 0) {
-        float out[N];
-        fill_chunk<NI, C * OWN_CH>(e, t, out, std::make_integer_sequence<int, N>{});
-        store_own_row<N>(row, C * OWN_CH, out, mine);
-        own_chunks<NI, C + 1>(e, t, row, mine);
-    }
-}
-// staged rows: 32 values at a time through the wave's LDS tile (row stride 33: the row writes and the reads below are both
-// conflict-free), then 16-byte stores — 8 lanes cover one row's 128 contiguous bytes, one instruction 8 rows — and the last
-// OBS % 32 values (always even) in 8-byte stores.  Rows start 8-byte aligned (OBS * 4 = 8 (7 NI + 2)).
-template <int NI, int C>
-__device__ __forceinline__ void staged_chunks(const Env<NI> &e, const ObsTotals &t, int64_t nrows, float *__restrict__ dst,
-                                              unsigned long long rowmask, uint32_t *__restrict__ tile) {
-    using L = Lay<NI>;
-    constexpr int N = L::OBS - L::CW * C < L::CW ? L::OBS - L::CW * C : L::CW;
-    if constexpr (N > 0) {
-        const uint32_t lane = threadIdx.x & 63u;
-        stage_chunk<NI, C * L::CW>(e, t, tile + lane * L::ROW, std::make_integer_sequence<int, N>{});
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        uint32_t *out = reinterpret_cast<uint32_t *>(dst) + C * L::CW;
-        if constexpr (N == L::CW) {
-            const uint32_t seg = lane & 7u;
-#pragma unroll 2
-            for (uint32_t r = lane >> 3; r < 64u; r += 8u) {
-                const uint32_t *src = tile + r * L::ROW + seg * 4u;
-                const Piece16 v{src[0], src[1], src[2], src[3]};
-                if ((int64_t)r < nrows && ((rowmask >> r) & 1ull)) *reinterpret_cast<Piece16 *>(out + (int64_t)r * L::OBS + seg * 4u) = v;
-            }
-        } else {
-            constexpr uint32_t PAIRS = N / 2;
-            static_assert(N % 2 == 0, "14 NI + 4 is even");
-#pragma unroll 2
-            for (uint32_t k = lane; k < 64u * PAIRS; k += 64u) {
-                const uint32_t r = k / PAIRS, c2 = (k - r * PAIRS) * 2u;
-                const Piece8 v{tile[r * L::ROW + c2], tile[r * L::ROW + c2 + 1u]};
-                if ((int64_t)r < nrows && ((rowmask >> r) & 1ull)) *reinterpret_cast<Piece8 *>(out + (int64_t)r * L::OBS + c2) = v;
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        staged_chunks<NI, C + 1>(e, t, nrows, dst, rowmask, tile);
     }
 }
 
-// writes the wave's 64 obs rows (rows with their bit in rowmask) to dst (+ row*130 floats).
-// OWN (the fused rollout): every lane streams its own row in 16-byte stores straight from registers (cge_device.hpp:
-// store_own_row), 32 values at a time + the last two — 96 -> 77 us per 262,144-env rollout step (A/B on one box, round 2).
-// !OWN (step()): staged in LDS 32 values at a time and written 8 rows per 16-byte store instruction (staged_chunks); the own-row
-// form is slower there (90.6 vs 81.3 us, round 3), where all waves of the launch reach their stores together.
-template <int NI, bool OWN>
-__device__ __forceinline__ void observe(const Env<NI> &e, int64_t nrows, float *__restrict__ dst, unsigned long long rowmask,
-                                        uint32_t *__restrict__ tile) {
-    using L = Lay<NI>;
-    const uint32_t lane = threadIdx.x & 63u;
-    ObsTotals t{0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < NI; ++i) { t.tp += e.passed[i]; t.tw += e.tw[i]; }
-#pragma unroll
-    for (int k = 0; k < 4 * NI; ++k) t.tq += e.q[k] & QM;
-    if constexpr (OWN) {
-        const bool mine = (int64_t)lane < nrows && ((rowmask >> lane) & 1ull);
-        own_chunks<NI, 0>(e, t, dst + (int64_t)lane * L::OBS, mine);
-    } else {
-        staged_chunks<NI, 0>(e, t, nrows, dst, rowmask, tile);
-    }
+// NI_T: the number of controlled intersections when it is known at compile time (the layouts the reference's scripts build: 4, 9, 16),
+// or 0: read from the config (any 2..16; IPL_T slots per lane)
+// waves per SIMD asked of the register allocator = what the LDS (rings + staging image) admits (A/B knobs: tools/build_variant.sh)
+#ifndef CGE_TRAFFIC_WAVES
+#define CGE_TRAFFIC_WAVES 4
+#endif
+#ifndef CGE_TRAFFIC_WAVES_STEP
+#define CGE_TRAFFIC_WAVES_STEP 5
+#endif
+constexpr int stage_words(int nimax) { return 8 * (14 * nimax + 4) > EPW * rec_words(nimax) ? 8 * (14 * nimax + 4) : EPW * rec_words(nimax); }
+template <int NI_T, int IPL_T, bool ROLLOUT>
+constexpr int waves_per_simd() {                  // min(the knob, what 160 KB of LDS admit of this instance's workgroups)
+    constexpr int lds = 4 * (EPW * RingLay<ROLLOUT>::STRIDE + stage_words(NI_T ? NI_T : L * IPL_T));
+    constexpr int fit = (160 * 1024 / lds) / 4, want = ROLLOUT ? CGE_TRAFFIC_WAVES : CGE_TRAFFIC_WAVES_STEP;
+    return fit < want ? (fit < 1 ? 1 : fit) : want;
 }
-
-template <int NI, bool ROLLOUT>
-__global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
-    using L = Lay<NI>;
-    constexpr int OBS = L::OBS;
-    __shared__ uint32_t tile[64 * L::ROW];
-    constexpr int W = ROLLOUT ? DWR : DW, DROW = W + 1;
-    __shared__ uint32_t draws[64 * DROW];
-    const int64_t i0 = (int64_t)blockIdx.x * BLOCK;
-    const int64_t i = i0 + threadIdx.x;
-    const bool live = i < p.n;
-    const int64_t li = live ? i : i0;
-    const int64_t nrows = p.n - i0 < 64 ? p.n - i0 : 64;
-    Env<NI> e;
-    e.load(p.state, p.n, li);
-    LdsDrawsCall<W> d(draws + (threadIdx.x & 63u) * DROW, p.mt + li * MT_STRIDE, e.mt_pos, e.mt_pretw);
-    d.old0 = e.mt_old0;
-    const uint64_t key = ROLLOUT ? hash_env_key(p.a_seed, (uint64_t)(p.env0 + li)) : 0;
+// The arguments of the rare paths (episode statistics, terminal rows, per-launch sums) are re-read from the kernel-argument
+// segment where they are used instead of being held in SGPRs across the step loop (the loop's own uniform values — output
+// pointers, config, hash constants — already fill the scalar file; 42 were being spilled to VGPR lanes and read back per step).
+typedef const __attribute__((address_space(4))) Params *ColdArgs;
+__device__ __forceinline__ ColdArgs cold_args() {
+    ColdArgs kp = (ColdArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return kp;
+}
+template <int NI_T, int IPL_T, bool ROLLOUT>
+__global__ __launch_bounds__(BLOCK, (waves_per_simd<NI_T, IPL_T, ROLLOUT>())) void step_kernel(Params p) {
+    constexpr int IPL = NI_T ? (NI_T + L - 1) / L : IPL_T;
+    // LDS: the 16 envs' draw rings, and the staging image: 8 observation rows or the 16 state records, whichever is larger
+    constexpr int NIMAX = NI_T ? NI_T : L * IPL_T, STAGE_W = stage_words(NIMAX);
+    constexpr int RSTRIDE = RingLay<ROLLOUT>::STRIDE;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[EPW * RSTRIDE + STAGE_W];
+    uint32_t *const stage = lds + EPW * RSTRIDE;
+    const uint32_t lane = threadIdx.x, ql_ = lane & (uint32_t)(L - 1), g = lane / (uint32_t)L;
+    const uint32_t chunk = (blockIdx.x & 7u) * p.per_xcd + (blockIdx.x >> 3);      // XCD x serves chunks [x per_xcd, (x + 1) per_xcd)
+    const int64_t i0 = (int64_t)chunk * EPW, i = i0 + g;                          // i0: wave-uniform
+    if (chunk >= p.nwaves || i >= p.n) return;                                    // whole groups leave; no barrier anywhere below
+    Cfg cfg = p.cfg;
+    if constexpr (NI_T != 0) {                                                    // fold everything that follows from NI
+        cfg.ni = NI_T; cfg.start_bits = bitlen(NI_T); cfg.hops = (NI_T < 5 ? NI_T : 5) - 1; cfg.hop_bits = bitlen((NI_T < 5 ? NI_T : 5) - 1);
+    }
+    const int ni = cfg.ni, OBS = 14 * ni + 4;
+    const uint32_t rows_live = p.n - i0 < EPW ? (uint32_t)(p.n - i0) : (uint32_t)EPW;
+    uint32_t *rec = p.state + i * p.recw;
+    Env<IPL> e;
+    Draws<ROLLOUT> d;
+    d.ring = lds + g * RSTRIDE; d.blk = p.mt + i0 * MT_STRIDE; d.boff = g * (uint32_t)(MT_STRIDE * 4); d.ql = ql_; d.p = 0; d.ovf = false;
+    const uint32_t roff_ = g * (uint32_t)(OBS * 4);                               // this env's row in the wave's block of 16 rows
+    e.load(rec, ni, ql_, d.c);
+    d.init();
+    const uint64_t key = ROLLOUT ? hash_env_key(p.a_seed, (uint64_t)(p.env0 + i)) : 0;
     double rsum = 0.0;
     int32_t dcount = 0;
     const int ksteps = ROLLOUT ? p.k_steps : 1;
     TICK_DECL
+    TICK(0);                                                                      // record load, kernel start
 #pragma unroll 1
     for (int t = 0; t < ksteps; ++t) {
+        // Opaque to the optimizer: everything derived from the lane's place in its quad would otherwise be hoisted out of the step loop
+        // (machine LICM does not price registers) — ~35 VGPRs of precomputed shifts and offsets held across the whole loop
+        uint32_t ql = ql_, roff = roff_;
+        asm volatile("" : "+v"(ql), "+v"(roff));
+        d.ql = ql;
         double reward = 0.0;
         bool term = false, reset_now = false;
-        if (live) {
-            if (p.mode == CGE_AUTORESET_NEXT_STEP && e.needs_reset) {
-                reset_now = true;
+        const bool stepping = !(p.mode == CGE_AUTORESET_NEXT_STEP && e.needs_reset);
+        if (!stepping) reset_now = true;
+        Totals tot{0, 0, 0};
+        double gfeat = 0.0;
+        if (__ballot(stepping)) {
+            d.prepare(cfg);
+            TICK(1);                                                              // + the outputs of the previous step draining
+            uint32_t a[IPL];
+            if (p.actions) {
+                const int32_t *ap = p.actions + ((int64_t)t * p.n + i) * ni;
+#pragma unroll
+                for (int s = 0; s < IPL; ++s) a[s] = s * L + (int)ql < ni ? (uint32_t)ap[s * L + ql] : 0u;
             } else {
-                uint32_t a[NI];
-                if (p.actions) {
-                    const int32_t *ap = p.actions + ((int64_t)t * p.n + i) * NI;
 #pragma unroll
-                    for (int j = 0; j < NI; ++j) a[j] = (uint32_t)ap[j];
-                } else {
+                for (int s = 0; s < IPL; ++s) a[s] = hash_action_from_key(key, (uint64_t)(p.t0 + t), 3u, (uint32_t)(s * L) + ql);
+            }
+            if (stepping) e.timestep += 1;
+            // _apply_actions :205-220, TrafficLight.update utils.py:79-97
+            uint32_t need = 0;
 #pragma unroll
-                    for (int j = 0; j < NI; ++j) a[j] = hash_action_from_key(key, (uint64_t)(p.t0 + t), 3u, (uint32_t)j);
+            for (int s = 0; s < IPL; ++s) {
+                uint32_t phase = e.lp[s] & 3u, timer = (e.lp[s] >> 2) & 31u;
+                if (a[s] == 1u && phase != NS_GREEN) { phase = NS_GREEN; timer = 5; }
+                else if (a[s] == 2u && phase != EW_GREEN) { phase = EW_GREEN; timer = 5; }
+                int tm = (int)timer - 1;
+                if (tm <= 0) {
+                    phase = (phase + 1u) & 3u;
+                    tm = 3;                                                          // yellow; a green phase draws its timer below
+                    if (!(phase & 1u) && s * L + (int)ql < ni) need |= 1u << (s * L + (int)ql);
                 }
-                TICK(0);
-                (void)0;
-                term = env_step<NI>(e, p.cfg, a, d, reward TICK_PASS);
-                if (!ROLLOUT) d.flush();                          // a rollout keeps its window across steps
+                if (stepping) e.lp[s] = (e.lp[s] & ~127u) | phase | ((uint32_t)tm << 2);
+            }
+            TICK(2);                                                              // actions (hash) + lights
+            const uint32_t needmask = stepping ? gor(need) : 0u;
+            const bool try_spawn = stepping && e.nveh < (uint32_t)cfg.max_vehicles;     // returns BEFORE drawing when full
+            DrawOut o = fast_draws<ROLLOUT>(d, cfg, needmask, try_spawn);
+            if (__ballot(d.ovf)) {
+                if (d.ovf) {
+                    // nothing of the fast chain has been committed: the slow path redoes the step's draws from the step's cursor
+                    const SlowOut so = slow_draws(at<uint32_t>(d.blk, d.boff), d.c.pos, d.c.pretw, cfg, needmask, try_spawn);
+                    d.c.pos = so.pos; d.c.pretw = so.pretw; o = so.o;
+                    d.init();
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < IPL; ++s) {
+                const uint32_t ii = (uint32_t)(s * L) + ql;
+                if ((needmask >> ii) & 1u) e.lp[s] = (e.lp[s] & ~(31u << 2)) | ((5u + get_tv(o, ii)) << 2);      // random.randint(5, 30)
+            }
+            if (o.spawn & 1u) {                                                          // _spawn_vehicles :222-249
+                const uint32_t start = o.spawn >> 4, dir = (o.spawn >> 1) & 3u;
+                const uint32_t inc = 1u | (((o.spawn >> 3) & 1u) << QS_DEST);               // len += 1, dest += (destination == this intersection)
+#pragma unroll
+                for (int s = 0; s < IPL; ++s)
+#pragma unroll
+                    for (int dd = 0; dd < 4; ++dd) e.q[s][dd] += (start == (uint32_t)(s * L) + ql && dir == (uint32_t)dd) ? inc : 0u;
+                e.nveh += 1;
+            }
+            TICK(3);                                                              // draws + their effects
+            // process_vehicles utils.py:141-163
+            uint32_t tp = 0, tws = 0, pk = 0;             // pk: queued | removed << 8
+            uint32_t qt[IPL];
+#pragma unroll
+            for (int s = 0; s < IPL; ++s) {
+                const uint32_t phase = e.lp[s] & 3u;
+                qt[s] = 0;
+                if (stepping) {
+#pragma unroll
+                    for (int dd = 0; dd < 4; ++dd) {
+                        uint32_t &qq = e.q[s][dd];
+                        const uint32_t len = qq & QM;
+                        const bool pass = (dd == NORTH || dd == SOUTH) ? phase == NS_GREEN : phase == EW_GREEN;
+                        if (len) {
+                            if (pass) {
+                                e.lp[s] += len << 8;
+                                pk += ((qq >> QS_DEST) & QM) << 8;                  // reached destination -> removed
+                                qq = 0;
+                            } else {
+                                qq += len << QS_WAIT;
+                                e.tw[s] += len;
+                            }
+                        }
+                        qt[s] += qq & QM;
+                    }
+                }
+                tp += e.lp[s] >> 8; tws += e.tw[s]; pk += qt[s];
+            }
+            tp = gsum(tp); tws = gsum(tws); pk = gsum(pk);
+            const uint32_t tq = pk & 0xFFu;
+            if (stepping) e.nveh -= pk >> 8;
+            tot = Totals{tp, tws, tq};
+            // the division pass: lane 2's quotient tq / NI is also np.var's mean
+            const double quot = global_feature(ql, e.nveh, tot, ni);
+            gfeat = cap_feature(ql, quot);
+            const double mean = gbcast_f64<2>(quot);
+            // _calculate_reward :287-311; np.var over the NI queue totals (population variance)
+            double x[IPL];
+#pragma unroll
+            for (int s = 0; s < IPL; ++s) { const double dv = (double)qt[s] - mean; x[s] = dv * dv; }
+            double var = pairwise_sum<IPL>(x, ni);
+            var = var / (double)ni;
+            double r = 0.0;
+            r += (double)tp * 1.0;
+            r += (double)tws * -0.1;
+            r += (double)tq * -0.05;
+            r += 0.5 / (1.0 + var);
+            if (stepping) {
+                e.total_reward += r;
+                reward = r;
+                term = e.timestep >= (uint32_t)cfg.max_steps;
                 if (term) {
                     e.episodes += 1;
-                    if (p.ep_ret) p.ep_ret[i] = e.total_reward;            // environment.py:189 accumulates it, reset() zeroes it (:150)
-                    if (p.ep_len) p.ep_len[i] = (int32_t)e.timestep;
+                    if (ql == 0u) {
+                        ColdArgs c = cold_args();
+                        if (c->ep_ret) c->ep_ret[i] = e.total_reward;            // environment.py:189 accumulates it, reset() zeroes it (:150)
+                        if (c->ep_len) c->ep_len[i] = (int32_t)e.timestep;
+                    }
                     if (p.mode == CGE_AUTORESET_SAME_STEP) reset_now = true;
                     else if (p.mode == CGE_AUTORESET_NEXT_STEP) e.needs_reset = 1;
                 }
             }
         }
-        const unsigned long long fin_mask = __ballot(live && term && reset_now);
-        if (fin_mask && p.final_obs) observe<NI, ROLLOUT>(e, nrows, p.final_obs + i0 * OBS, fin_mask, tile);   // terminal obs (SAME_STEP)
-        if (reset_now) e.reset();
-        TICK(5);
-        if (p.obs) observe<NI, ROLLOUT>(e, nrows, p.obs + (int64_t)t * p.obs_step_stride + i0 * OBS, ~0ull, tile);
-        TICK(6);
+        TICK(4);                                                                  // vehicles + reward
+        const bool fin = term && reset_now;                     // terminal obs (SAME_STEP)
+        const unsigned long long fin_mask = __ballot(fin && ql == 0u);
+        if (fin_mask) {
+            ColdArgs c = cold_args();
+            if (!ROLLOUT) {
+                if (c->final_obs) emit_row<IPL>(e, c->final_obs + i0 * OBS, roff, ni, ql, (float)gfeat, fin);
+            } else if (c->fin_rows) {
+                // compacted: one counter bump per wave, the wave's terminal rows take consecutive slots
+                uint32_t base = 0;
+                if (lane == (uint32_t)__builtin_ctzll(fin_mask)) base = (uint32_t)atomicAdd(c->fin_count, (int32_t)__popcll(fin_mask));
+                base = (uint32_t)__shfl((int)base, __builtin_ctzll(fin_mask), 64);
+                const int64_t slot = (int64_t)base + __popcll(fin_mask & ((1ull << (lane & ~3u)) - 1ull));
+                const bool on = fin && slot < c->fin_cap;
+                emit_row<IPL>(e, c->fin_rows + (int64_t)base * OBS, (uint32_t)(on ? slot - base : 0) * (uint32_t)(OBS * 4), ni, ql, (float)gfeat, on);
+                if (on && ql == 0u) c->fin_index[slot] = (int64_t)t * c->n + i;
+            }
+        }
+        if (reset_now) { e.reset(); tot = Totals{0, 0, 0}; gfeat = 0.0; }
+        if (!stepping) gfeat = 0.0;
+        TICK(5);                                                                  // final obs / reset
+#ifndef CGE_TRAFFIC_NOEMIT                                                        // (measurement knob: everything computed, no row stored)
+        if (p.obs) emit_staged<IPL, 8 * (14 * NIMAX + 4)>(e, stage, p.obs + (int64_t)t * p.obs_step_stride + i0 * OBS, ni, lane, (float)gfeat, rows_live);
+#else
+        if (p.obs && gfeat == 12345.0) emit_row<IPL>(e, p.obs + (int64_t)t * p.obs_step_stride + i0 * OBS, roff, ni, ql, (float)gfeat, true);
+#endif
+        TICK(6);                                                                  // observation row
+        if (ql == 0u) {
+            if (ROLLOUT) {
+                if (p.reward) *at<float>(p.reward + (int64_t)t * p.n + i0, g * 4u) = (float)reward;
+                if (p.terminated) *at<uint8_t>(p.terminated + (int64_t)t * p.n + i0, g) = term ? 1 : 0;
+            } else {
+                *at<float>(p.reward + i0, g * 4u) = (float)reward;
+                *at<uint8_t>(p.terminated + i0, g) = term ? 1 : 0;
+                if (p.truncated) *at<uint8_t>(p.truncated + i0, g) = 0;
+            }
+        }
+        rsum += reward;
+        dcount += term ? 1 : 0;
 #ifdef CGE_TRAFFIC_TIMING
         if (threadIdx.x == 0 && blockIdx.x < 4096) g_timing[blockIdx.x * 16 + 15] += 1;
 #endif
-        if (live) {
-            if (ROLLOUT) {
-                rsum += reward;
-                dcount += term ? 1 : 0;
-                if (p.reward) p.reward[(int64_t)t * p.n + i] = (float)reward;
-                if (p.terminated) p.terminated[(int64_t)t * p.n + i] = term ? 1 : 0;
-            } else {
-                p.reward[i] = (float)reward;
-                p.terminated[i] = term ? 1 : 0;
-                if (p.truncated) p.truncated[i] = 0;
-            }
-        }
     }
-    if (live) {
-        if (ROLLOUT) d.flush();                                   // the rollout's window is written back once, here
-        e.mt_pos = d.pos; e.mt_pretw = d.pretw; e.mt_old0 = d.old0;
-        e.store(p.state, p.n, i);
-        if (ROLLOUT) {
-            if (p.reward_sum) p.reward_sum[i] = rsum;
-            if (p.done_count) p.done_count[i] = dcount;
-        }
+    d.consume();
+    e.stage_record(stage + g * (uint32_t)p.recw, ni, p.recw, ql_, d.c);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    stream_image<EPW * rec_words(NIMAX)>(stage, p.state + i0 * p.recw, rows_live * (uint32_t)p.recw * 4u, lane, rows_live * (uint32_t)L);
+    if (ROLLOUT && ql_ == 0u) {
+        ColdArgs c = cold_args();
+        if (c->reward_sum) c->reward_sum[i] = rsum;
+        if (c->done_count) c->done_count[i] = dcount;
     }
 }
 
-template <int NI>
-__global__ __launch_bounds__(BLOCK) void reset_kernel(Params p) {
-    using L = Lay<NI>;
-    constexpr int OBS = L::OBS;
-    __shared__ uint32_t tile[64 * L::ROW];
-    const int64_t i0 = (int64_t)blockIdx.x * BLOCK;
-    const int64_t i = i0 + threadIdx.x;
-    const bool live = i < p.n;
-    const int64_t nrows = p.n - i0 < 64 ? p.n - i0 : 64;
-    Env<NI> e;
-    e.load(p.state, p.n, live ? i : i0);
-    if (live && (!p.mask || p.mask[i])) {
-        e.reset();
-        e.store(p.state, p.n, i);
+// reset(mask) + the observation of every env: one lane per env (cold path)
+__global__ __launch_bounds__(256) void reset_kernel(Params p) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n) return;
+    const int ni = p.cfg.ni;
+    uint32_t *rec = p.state + i * p.recw;
+    if (!p.mask || p.mask[i]) {
+        rec[0] = 0;                                             // timestep, nveh, needs_reset; the generator cursor, episodes, old0 stay
+        rec[4] = 0; rec[5] = 0;
+        for (int k = O_Q; k < O_Q + 6 * ni; ++k) rec[k] = 0;
     }
-    if (p.obs) observe<NI, false>(e, nrows, p.obs + i0 * OBS, ~0ull, tile);
+    if (!p.obs) return;
+    float *row = p.obs + i * p.obsw;
+    uint32_t tp = 0, tws = 0, tq = 0;
+    for (int k = 0; k < ni; ++k) {
+        const uint32_t lp = rec[O_Q + 4 * ni + 2 * k], tw = rec[O_Q + 4 * ni + 2 * k + 1];
+        tp += lp >> 8; tws += tw;
+        for (int dd = 0; dd < 4; ++dd) {
+            const uint32_t qq = rec[O_Q + 4 * k + dd], len = qq & QM;
+            tq += len;
+            row[4 * k + dd] = (lp & 3u) == (uint32_t)dd ? 1.0f : 0.0f;
+            row[4 * ni + 4 * k + dd] = (float)(len < 20u ? len : 20u);
+            const double avg = len ? (double)(qq >> QS_WAIT) / (double)len : 0.0;
+            row[8 * ni + 4 * k + dd] = (float)(avg < 100.0 ? avg : 100.0);
+        }
+        row[12 * ni + 2 * k] = (float)(lp >> 8);
+        row[12 * ni + 2 * k + 1] = (float)(tw < 1000u ? tw : 1000u);
+    }
+    const double v1 = (double)tws / (double)(tp > 1u ? tp : 1u), v2 = (double)tq / (double)ni;
+    row[14 * ni] = (float)((rec[0] >> 16) & 127u);
+    row[14 * ni + 1] = (float)(v1 < 100.0 ? v1 : 100.0);
+    row[14 * ni + 2] = (float)(v2 < 50.0 ? v2 : 50.0);
+    row[14 * ni + 3] = (float)((double)tp / (double)ni);
 }
 
-template <int NI>
-__global__ __launch_bounds__(256) void rewind_kernel(uint4 *state, int64_t n) {
+__global__ __launch_bounds__(256) void rewind_kernel(uint32_t *state, int64_t n, int recw) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    constexpr int W = Lay<NI>::O_M + 1;   // m1: the generator cursor
-    uint4 v = state[(int64_t)(W / 4) * n + i];
-    if (W % 4 == 0) v.x = 0; else if (W % 4 == 1) v.y = 0; else if (W % 4 == 2) v.z = 0; else v.w = 0;
-    state[(int64_t)(W / 4) * n + i] = v;
+    state[i * recw + 1] = 0;                                    // m1: the generator cursor and its ready mark
 }
 
-template <int NI>
-__global__ __launch_bounds__(256) void info_kernel(const uint4 *__restrict__ state, int64_t n, int field, int idx, int32_t *__restrict__ out,
-                                                   double *__restrict__ out64) {
-    constexpr int NQ = 4 * NI;
+__global__ __launch_bounds__(256) void info_kernel(const uint32_t *__restrict__ state, int64_t n, int recw, int ni, int field, int idx,
+                                                   int32_t *__restrict__ out, double *__restrict__ out64) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    Env<NI> e;
-    e.load(state, n, i);
-    if (out64) { out64[i] = e.total_reward; return; }
+    const uint32_t *rec = state + i * recw;
+    if (out64) {
+        const uint64_t u = ((uint64_t)rec[5] << 32) | rec[4];
+        double v;
+        memcpy(&v, &u, 8);
+        out64[i] = v;
+        return;
+    }
     int32_t v = 0;
-    uint32_t li = 0, pi = 0, ti = 0, qi = 0;
-#pragma unroll
-    for (int k = 0; k < NI; ++k) if (idx == k) { li = e.light[k]; pi = e.passed[k]; ti = e.tw[k]; }
-#pragma unroll
-    for (int k = 0; k < NQ; ++k) if (idx == k) qi = e.q[k];
+    const uint32_t m0 = rec[0];
     switch (field) {
-        case CGE_TRAFFIC_INFO_TIMESTEP: v = (int32_t)e.timestep; break;
-        case CGE_TRAFFIC_INFO_NUM_VEHICLES: v = (int32_t)e.nveh; break;
-        case CGE_TRAFFIC_INFO_LIGHT_PHASE: v = (int32_t)(li & 3u); break;
-        case CGE_TRAFFIC_INFO_LIGHT_TIMER: v = (int32_t)(li >> 2); break;
-        case CGE_TRAFFIC_INFO_VEHICLES_PASSED: v = (int32_t)pi; break;
-        case CGE_TRAFFIC_INFO_TOTAL_WAITING_TIME: v = (int32_t)ti; break;
-        case CGE_TRAFFIC_INFO_QUEUE_LEN: v = (int32_t)(qi & QM); break;
-        case CGE_TRAFFIC_INFO_QUEUE_DEST: v = (int32_t)((qi >> QS_DEST) & QM); break;
-        case CGE_TRAFFIC_INFO_QUEUE_WAIT: v = (int32_t)(qi >> QS_WAIT); break;
-        case CGE_TRAFFIC_INFO_EPISODES: v = (int32_t)e.episodes; break;
-        case CGE_TRAFFIC_INFO_NEEDS_RESET: v = (int32_t)e.needs_reset; break;
+        case CGE_TRAFFIC_INFO_TIMESTEP: v = (int32_t)(m0 & 0xFFFFu); break;
+        case CGE_TRAFFIC_INFO_NUM_VEHICLES: v = (int32_t)((m0 >> 16) & 127u); break;
+        case CGE_TRAFFIC_INFO_LIGHT_PHASE: v = (int32_t)(rec[O_Q + 4 * ni + 2 * idx] & 3u); break;
+        case CGE_TRAFFIC_INFO_LIGHT_TIMER: v = (int32_t)((rec[O_Q + 4 * ni + 2 * idx] >> 2) & 31u); break;
+        case CGE_TRAFFIC_INFO_VEHICLES_PASSED: v = (int32_t)(rec[O_Q + 4 * ni + 2 * idx] >> 8); break;
+        case CGE_TRAFFIC_INFO_TOTAL_WAITING_TIME: v = (int32_t)rec[O_Q + 4 * ni + 2 * idx + 1]; break;
+        case CGE_TRAFFIC_INFO_QUEUE_LEN: v = (int32_t)(rec[O_Q + idx] & QM); break;
+        case CGE_TRAFFIC_INFO_QUEUE_DEST: v = (int32_t)((rec[O_Q + idx] >> QS_DEST) & QM); break;
+        case CGE_TRAFFIC_INFO_QUEUE_WAIT: v = (int32_t)(rec[O_Q + idx] >> QS_WAIT); break;
+        case CGE_TRAFFIC_INFO_EPISODES: v = (int32_t)rec[2]; break;
+        case CGE_TRAFFIC_INFO_NEEDS_RESET: v = (int32_t)((m0 >> 23) & 1u); break;
     }
     out[i] = v;
 }
 
-
-// ------------------------------------------------------------------ one set of kernels per compiled-in layout
-struct Ops {
-    int ni, cols, obs;
-    const char *step_name, *rollout_name;
-    void (*step)(const Params &, unsigned, hipStream_t);
-    void (*rollout)(const Params &, unsigned, hipStream_t);
-    void (*reset)(const Params &, unsigned, hipStream_t);
-    void (*rewind)(uint4 *, int64_t, hipStream_t);
-    void (*info)(const uint4 *, int64_t, int, int, int32_t *, double *, hipStream_t);
-    void (*to_record)(const uint32_t *raw, int32_t *hd, double *total_reward, int32_t *w, uint32_t *mt_pos, uint32_t *mt_pretw, uint32_t *mt_old0);
-    void (*from_record)(const int32_t *hd, double total_reward, const int32_t *w, uint32_t *raw);
-};
-
-// device record <-> the canonical record's fields (w: phase[ni], timer[ni], passed[ni], total_wait[ni], qlen, qdest, qwait [4 ni])
-template <int NI>
-void to_record(const uint32_t *raw, int32_t *hd, double *total_reward, int32_t *w, uint32_t *mt_pos, uint32_t *mt_pretw, uint32_t *mt_old0) {
-    Env<NI> e;
-    e.unpack(raw);
-    hd[0] = (int32_t)e.timestep; hd[1] = (int32_t)e.nveh; hd[2] = (int32_t)e.needs_reset; hd[3] = 0; hd[4] = (int32_t)e.episodes; hd[5] = 0;
-    *total_reward = e.total_reward; *mt_pos = e.mt_pos; *mt_pretw = e.mt_pretw; *mt_old0 = e.mt_old0;
-    for (int k = 0; k < NI; ++k) { w[k] = (int32_t)(e.light[k] & 3u); w[NI + k] = (int32_t)(e.light[k] >> 2); w[2 * NI + k] = (int32_t)e.passed[k]; w[3 * NI + k] = (int32_t)e.tw[k]; }
-    for (int k = 0; k < 4 * NI; ++k) { w[4 * NI + k] = (int32_t)(e.q[k] & QM); w[8 * NI + k] = (int32_t)((e.q[k] >> QS_DEST) & QM); w[12 * NI + k] = (int32_t)(e.q[k] >> QS_WAIT); }
-}
-template <int NI>
-void from_record(const int32_t *hd, double total_reward, const int32_t *w, uint32_t *raw) {
-    Env<NI> e;
-    memset(&e, 0, sizeof e);
-    e.timestep = (uint32_t)hd[0]; e.nveh = (uint32_t)hd[1]; e.needs_reset = (uint32_t)(hd[2] & 1); e.episodes = (uint32_t)hd[4];
-    e.total_reward = total_reward;
-    for (int k = 0; k < NI; ++k) { e.light[k] = ((uint32_t)w[k] & 3u) | ((uint32_t)w[NI + k] << 2); e.passed[k] = (uint32_t)w[2 * NI + k]; e.tw[k] = (uint32_t)w[3 * NI + k]; }
-    for (int k = 0; k < 4 * NI; ++k) e.q[k] = ((uint32_t)w[4 * NI + k] & QM) | (((uint32_t)w[8 * NI + k] & QM) << QS_DEST) | ((uint32_t)w[12 * NI + k] << QS_WAIT);
-    if (hd[3] >= MT_N) { e.mt_pos = 0; e.mt_pretw = 0; } else { e.mt_pos = (uint32_t)hd[3]; e.mt_pretw = MT_N; }
-    e.pack(raw);
-}
-
-template <int NI>
-Ops make_ops(const char *step_name, const char *rollout_name) {
-    Ops o;
-    o.ni = NI; o.cols = Lay<NI>::COLS; o.obs = Lay<NI>::OBS;
-    o.step_name = step_name; o.rollout_name = rollout_name;
-    o.step = [](const Params &p, unsigned blocks, hipStream_t s) { hipLaunchKernelGGL((step_kernel<NI, false>), dim3(blocks), dim3(BLOCK), 0, s, p); };
-    o.rollout = [](const Params &p, unsigned blocks, hipStream_t s) { hipLaunchKernelGGL((step_kernel<NI, true>), dim3(blocks), dim3(BLOCK), 0, s, p); };
-    o.reset = [](const Params &p, unsigned blocks, hipStream_t s) { hipLaunchKernelGGL(reset_kernel<NI>, dim3(blocks), dim3(BLOCK), 0, s, p); };
-    o.rewind = [](uint4 *st, int64_t n, hipStream_t s) { hipLaunchKernelGGL(rewind_kernel<NI>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st, n); };
-    o.info = [](const uint4 *st, int64_t n, int field, int idx, int32_t *out, double *out64, hipStream_t s) {
-        hipLaunchKernelGGL(info_kernel<NI>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st, n, field, idx, out, out64);
-    };
-    o.to_record = to_record<NI>;
-    o.from_record = from_record<NI>;
-    return o;
-}
-
-static bool ops_for(int ni, Ops &o) {
-    switch (ni) {
-        case 4: o = make_ops<4>("cge::traffic::step_kernel<4, false>", "cge::traffic::step_kernel<4, true>"); return true;       // simple_test.py:71-76
-        case 9: o = make_ops<9>("cge::traffic::step_kernel<9, false>", "cge::traffic::step_kernel<9, true>"); return true;       // config.py:7
-        case 16: o = make_ops<16>("cge::traffic::step_kernel<16, false>", "cge::traffic::step_kernel<16, true>"); return true;   // USAGE_EXAMPLES.md:32-38
-    }
-    return false;
+template <int NI_T, int IPL_T>
+void launch_step(const Params &p, bool rollout, hipStream_t s) {
+    const unsigned blocks = p.per_xcd * 8u;
+    if (rollout) hipLaunchKernelGGL((step_kernel<NI_T, IPL_T, true>), dim3(blocks), dim3(BLOCK), 0, s, p);
+    else hipLaunchKernelGGL((step_kernel<NI_T, IPL_T, false>), dim3(blocks), dim3(BLOCK), 0, s, p);
 }
 
 }  // namespace traffic
@@ -609,20 +1014,80 @@ using namespace cge;
 
 struct cge_traffic : HandleBase {
     cge_traffic_config cfg{};
-    traffic::Ops ops{};
-    uint4 *state = nullptr;
+    int ni = 0, recw = 0, obsw = 0, ipl = 0;
+    uint32_t *state = nullptr;
     uint32_t *mt = nullptr;
+    float *fin_rows = nullptr;
+    int64_t *fin_index = nullptr;
+    int64_t fin_cap = 0;
+    int32_t *fin_count = nullptr;
+    char step_name[64], rollout_name[64];
 
     traffic::Params params() const {
         traffic::Params p{};
         p.state = state; p.mt = mt; p.n = n; p.env0 = env0;
-        p.cfg = traffic::Cfg{cfg.spawn_rate, cfg.max_vehicles, cfg.max_steps, cfg.grid_rows, cfg.grid_cols};
-        p.mode = cfg.autoreset_mode;
+        traffic::Cfg c{};
+        c.spawn_rate = cfg.spawn_rate; c.max_vehicles = cfg.max_vehicles; c.max_steps = cfg.max_steps;
+        c.rows = cfg.grid_rows; c.cols = cfg.grid_cols; c.ni = ni;
+        c.inv_cols = (65536u + (uint32_t)cfg.grid_cols - 1u) / (uint32_t)cfg.grid_cols;
+        c.start_bits = traffic::bitlen(ni);
+        c.hops = (ni < 5 ? ni : 5) - 1;                        // route_length = randint(2, min(5, NI)) (utils.py:181)
+        c.hop_bits = traffic::bitlen(c.hops);
+        p.cfg = c;
+        p.mode = cfg.autoreset_mode; p.recw = recw; p.obsw = obsw;
+        p.nwaves = (uint32_t)((n + traffic::EPW - 1) / traffic::EPW);
+        p.per_xcd = (p.nwaves + 7u) / 8u;
         p.ep_ret = ep_ret; p.ep_len = ep_len;
         return p;
     }
-    unsigned blocks() const { return (unsigned)((n + traffic::BLOCK - 1) / traffic::BLOCK); }
+    void launch(const traffic::Params &p, bool rollout, hipStream_t s) const {
+        switch (ni) {                                      // the layouts the reference's scripts build get their own instance
+            case 4: traffic::launch_step<4, 1>(p, rollout, s); return;       // simple_test.py:71-76
+            case 9: traffic::launch_step<9, 3>(p, rollout, s); return;       // config.py:7
+            case 16: traffic::launch_step<16, 4>(p, rollout, s); return;     // USAGE_EXAMPLES.md:32-38
+        }
+        switch (ipl) {
+            case 1: traffic::launch_step<0, 1>(p, rollout, s); break;
+            case 2: traffic::launch_step<0, 2>(p, rollout, s); break;
+            case 3: traffic::launch_step<0, 3>(p, rollout, s); break;
+            default: traffic::launch_step<0, 4>(p, rollout, s); break;
+        }
+    }
 };
+
+// device record <-> the canonical record's fields (w: phase[ni], timer[ni], passed[ni], total_wait[ni], qlen, qdest, qwait [4 ni])
+static void to_record(const uint32_t *rec, int ni, int32_t *hd, double *total_reward, int32_t *w, uint32_t *mt_pos, uint32_t *mt_pretw, uint32_t *mt_old0) {
+    using namespace traffic;
+    const uint32_t m0 = rec[0], m1 = rec[1];
+    hd[0] = (int32_t)(m0 & 0xFFFFu); hd[1] = (int32_t)((m0 >> 16) & 127u); hd[2] = (int32_t)((m0 >> 23) & 1u); hd[3] = 0; hd[4] = (int32_t)rec[2]; hd[5] = 0;
+    const uint64_t u = ((uint64_t)rec[5] << 32) | rec[4];
+    memcpy(total_reward, &u, 8);
+    *mt_pos = m1 & 1023u; *mt_pretw = mt_ready_decode((m1 >> 10) & 31u); *mt_old0 = rec[3];
+    for (int k = 0; k < ni; ++k) {
+        const uint32_t lp = rec[O_Q + 4 * ni + 2 * k];
+        w[k] = (int32_t)(lp & 3u); w[ni + k] = (int32_t)((lp >> 2) & 31u); w[2 * ni + k] = (int32_t)(lp >> 8); w[3 * ni + k] = (int32_t)rec[O_Q + 4 * ni + 2 * k + 1];
+    }
+    for (int k = 0; k < 4 * ni; ++k) {
+        const uint32_t qq = rec[O_Q + k];
+        w[4 * ni + k] = (int32_t)(qq & QM); w[8 * ni + k] = (int32_t)((qq >> QS_DEST) & QM); w[12 * ni + k] = (int32_t)(qq >> QS_WAIT);
+    }
+}
+static void from_record(const int32_t *hd, double total_reward, const int32_t *w, int ni, int recw, uint32_t *rec) {
+    using namespace traffic;
+    memset(rec, 0, (size_t)recw * 4);
+    rec[0] = (uint32_t)hd[0] | ((uint32_t)hd[1] << 16) | ((uint32_t)(hd[2] & 1) << 23);
+    // a CPython state: index >= 624 = nothing of this generation twisted yet; otherwise the whole generation is ready
+    rec[1] = hd[3] >= MT_N ? 0u : ((uint32_t)hd[3] | (mt_ready_encode(MT_N) << 10));
+    rec[2] = (uint32_t)hd[4];
+    uint64_t u;
+    memcpy(&u, &total_reward, 8);
+    rec[4] = (uint32_t)u; rec[5] = (uint32_t)(u >> 32);
+    for (int k = 0; k < ni; ++k) {
+        rec[O_Q + 4 * ni + 2 * k] = ((uint32_t)w[k] & 3u) | (((uint32_t)w[ni + k] & 31u) << 2) | ((uint32_t)w[2 * ni + k] << 8);
+        rec[O_Q + 4 * ni + 2 * k + 1] = (uint32_t)w[3 * ni + k];
+    }
+    for (int k = 0; k < 4 * ni; ++k) rec[O_Q + k] = ((uint32_t)w[4 * ni + k] & QM) | (((uint32_t)w[8 * ni + k] & QM) << QS_DEST) | ((uint32_t)w[12 * ni + k] << QS_WAIT);
+}
 
 extern "C" {
 
@@ -647,21 +1112,25 @@ int cge_traffic_create(const cge_traffic_config *cfg, int64_t n_envs, int device
     *out = nullptr;
     if (cfg->grid_rows < 1 || cfg->grid_cols < 1 || cfg->grid_rows > 64 || cfg->grid_cols > 64 || cfg->num_intersections < 1)
         return CGE_ERR_INVALID_ARG;
-    // environment.py:79: num_intersections = min(num_intersections, rows * cols); kernels exist for 4, 9 and 16 of them
+    // environment.py:79: num_intersections = min(num_intersections, rows * cols).  2..16: route_length = randint(2, min(5, NI)) raises
+    // for a single intersection (utils.py:181), and an env is spread over 16 (slot, lane) places
     const int cells = cfg->grid_rows * cfg->grid_cols;
     const int ni = cfg->num_intersections < cells ? cfg->num_intersections : cells;
-    traffic::Ops ops;
-    if (!traffic::ops_for(ni, ops)) return CGE_ERR_UNSUPPORTED;
-    // queue word: len:7 dest:7 wait:18; timestep 16 bits
+    if (ni < 2 || ni > traffic::MAXNI) return CGE_ERR_UNSUPPORTED;
+    // queue word: len:7 dest:7 wait:18; timestep 16 bits; passed 24 bits
     if (cfg->autoreset_mode < 0 || cfg->autoreset_mode > 2 || cfg->max_vehicles < 0 || cfg->max_vehicles > 127 || cfg->max_steps <= 0 ||
         cfg->max_steps > 65535 || (int64_t)cfg->max_vehicles * cfg->max_steps > 262143 || !(cfg->spawn_rate >= 0.0))
         return CGE_ERR_INVALID_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return CGE_ERR_NO_DEVICE;
     cge_traffic *h = new cge_traffic();
-    h->cfg = *cfg; h->cfg.num_intersections = ni; h->ops = ops; h->n = n_envs; h->env0 = env_index0; h->device = device;
+    h->cfg = *cfg; h->cfg.num_intersections = ni; h->n = n_envs; h->env0 = env_index0; h->device = device;
+    h->ni = ni; h->recw = traffic::rec_words(ni); h->obsw = 14 * ni + 4; h->ipl = (ni + traffic::L - 1) / traffic::L;
+    const bool own = ni == 4 || ni == 9 || ni == 16;
+    snprintf(h->step_name, sizeof h->step_name, "cge::traffic::step_kernel<%d, %d, false>", own ? ni : 0, h->ipl);
+    snprintf(h->rollout_name, sizeof h->rollout_name, "cge::traffic::step_kernel<%d, %d, true>", own ? ni : 0, h->ipl);
     DeviceGuard g(device);
-    const size_t sb = (size_t)ops.cols * n_envs * sizeof(uint4), mb = (size_t)n_envs * MT_STRIDE * sizeof(uint32_t);
+    const size_t sb = (size_t)h->recw * 4 * n_envs, mb = (size_t)n_envs * MT_STRIDE * sizeof(uint32_t);
     hipError_t e;
     if ((e = hipMalloc(&h->state, sb)) != hipSuccess || (e = hipMalloc(&h->mt, mb)) != hipSuccess ||
         (e = hipMemset(h->state, 0, sb)) != hipSuccess) {     // all-zero state == a freshly reset env
@@ -694,7 +1163,7 @@ int cge_traffic_seed(cge_traffic *h, const uint64_t *seeds, uint64_t base_seed, 
     if (!h) return CGE_ERR_INVALID_ARG;
     DeviceGuard g(h->device);
     CGE_TRY(h, launch_mt_seed(h->mt, MT_STRIDE, h->n, seeds, base_seed, h->env0, 0, as_stream(stream)));
-    h->ops.rewind(h->state, h->n, as_stream(stream));
+    hipLaunchKernelGGL(traffic::rewind_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, as_stream(stream), h->state, h->n, h->recw);
     CGE_TRY(h, hipGetLastError());
     return CGE_OK;
 }
@@ -704,7 +1173,7 @@ int cge_traffic_reset(cge_traffic *h, const uint8_t *mask, float *obs_out, void 
     DeviceGuard g(h->device);
     traffic::Params p = h->params();
     p.mask = mask; p.obs = obs_out;
-    h->ops.reset(p, h->blocks(), as_stream(stream));
+    hipLaunchKernelGGL(traffic::reset_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, as_stream(stream), p);
     CGE_TRY(h, hipGetLastError());
     return CGE_OK;
 }
@@ -718,8 +1187,8 @@ int cge_traffic_step(cge_traffic *h, const int32_t *actions, float *obs_out, flo
     traffic::Params p = h->params();
     p.actions = actions; p.obs = obs_out; p.reward = reward_out; p.terminated = terminated_out; p.truncated = truncated_out;
     p.final_obs = final_obs_out; p.k_steps = 1;
-    h->ops.step(p, h->blocks(), as_stream(stream));
-    h->last_kernel = h->ops.step_name;
+    h->launch(p, false, as_stream(stream));
+    h->last_kernel = h->step_name;
     CGE_TRY(h, hipGetLastError());
     return CGE_OK;
 }
@@ -728,26 +1197,36 @@ int cge_traffic_rollout(cge_traffic *h, int32_t k_steps, const int32_t *actions,
                         int64_t obs_step_stride, float *reward_traj_out, uint8_t *terminated_traj_out, double *reward_sum_out,
                         int32_t *done_count_out, void *stream) {
     if (!h) return CGE_ERR_INVALID_ARG;
-    if (k_steps < 0 || obs_step_stride < 0 || (obs_step_stride != 0 && obs_step_stride < h->n * h->ops.obs))
+    if (k_steps < 0 || obs_step_stride < 0 || (obs_step_stride != 0 && obs_step_stride < h->n * h->obsw))
         return h->fail(CGE_ERR_INVALID_ARG, "cge_traffic_rollout: bad k_steps / obs_step_stride");
     if (k_steps == 0) return CGE_OK;
     DeviceGuard g(h->device);
     traffic::Params p = h->params();
     p.k_steps = k_steps; p.actions = actions; p.a_seed = action_seed; p.t0 = t0; p.obs = obs_out; p.obs_step_stride = obs_step_stride;
     p.reward = reward_traj_out; p.terminated = terminated_traj_out; p.reward_sum = reward_sum_out; p.done_count = done_count_out;
-    h->ops.rollout(p, h->blocks(), as_stream(stream));
-    h->last_kernel = h->ops.rollout_name;
+    p.fin_rows = h->fin_rows; p.fin_index = h->fin_index; p.fin_cap = h->fin_cap; p.fin_count = h->fin_count;
+    h->launch(p, true, as_stream(stream));
+    h->last_kernel = h->rollout_name;
     CGE_TRY(h, hipGetLastError());
+    return CGE_OK;
+}
+
+int cge_traffic_rollout_final_obs(cge_traffic *h, float *rows_out, int64_t *index_out, int64_t capacity, int32_t *count_out) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    if ((rows_out || index_out || count_out) && (!rows_out || !index_out || !count_out || capacity <= 0))
+        return h->fail(CGE_ERR_INVALID_ARG, "cge_traffic_rollout_final_obs: rows, index and count go together (all NULL unregisters)");
+    h->fin_rows = rows_out; h->fin_index = index_out; h->fin_cap = rows_out ? capacity : 0; h->fin_count = count_out;
     return CGE_OK;
 }
 
 int cge_traffic_info(cge_traffic *h, int32_t field_id, int32_t index, int32_t *out, void *stream) {
     if (!h) return CGE_ERR_INVALID_ARG;
     const bool per_queue = field_id >= CGE_TRAFFIC_INFO_QUEUE_LEN && field_id <= CGE_TRAFFIC_INFO_QUEUE_WAIT;
-    if (!out || field_id < 0 || field_id > CGE_TRAFFIC_INFO_NEEDS_RESET || index < 0 || index >= (per_queue ? 4 : 1) * h->ops.ni)
+    if (!out || field_id < 0 || field_id > CGE_TRAFFIC_INFO_NEEDS_RESET || index < 0 || index >= (per_queue ? 4 : 1) * h->ni)
         return h->fail(CGE_ERR_INVALID_ARG, "cge_traffic_info: bad field / index / null out");
     DeviceGuard g(h->device);
-    h->ops.info(h->state, h->n, field_id, index, out, nullptr, as_stream(stream));
+    hipLaunchKernelGGL(traffic::info_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, as_stream(stream), h->state, h->n, h->recw, h->ni,
+                       field_id, index, out, (double *)nullptr);
     CGE_TRY(h, hipGetLastError());
     return CGE_OK;
 }
@@ -755,36 +1234,32 @@ int cge_traffic_info(cge_traffic *h, int32_t field_id, int32_t index, int32_t *o
 int cge_traffic_total_reward(cge_traffic *h, double *out, void *stream) {
     if (!h || !out) return CGE_ERR_INVALID_ARG;
     DeviceGuard g(h->device);
-    h->ops.info(h->state, h->n, 0, 0, nullptr, out, as_stream(stream));
+    hipLaunchKernelGGL(traffic::info_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, as_stream(stream), h->state, h->n, h->recw, h->ni,
+                       0, 0, (int32_t *)nullptr, out);
     CGE_TRY(h, hipGetLastError());
     return CGE_OK;
 }
 
-size_t cge_traffic_state_bytes(const cge_traffic *h) { return h ? 6 * 4 + 8 + (size_t)16 * h->ops.ni * 4 + MT_N * 4 : 0; }
+size_t cge_traffic_state_bytes(const cge_traffic *h) { return h ? 6 * 4 + 8 + (size_t)16 * h->ni * 4 + MT_N * 4 : 0; }
 
 int cge_traffic_get_state(cge_traffic *h, void *host_buf, void *stream) {
     if (!h || !host_buf) return CGE_ERR_INVALID_ARG;
     DeviceGuard g(h->device);
     const int64_t n = h->n;
-    const int cols = h->ops.cols, ni = h->ops.ni;
-    std::vector<uint4> st((size_t)cols * n);
+    const int recw = h->recw, ni = h->ni;
+    std::vector<uint32_t> st((size_t)recw * n);
     std::vector<uint32_t> mt((size_t)n * MT_STRIDE);
     CGE_TRY(h, hipStreamSynchronize(as_stream(stream)));
-    CGE_TRY(h, hipMemcpy(st.data(), h->state, st.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+    CGE_TRY(h, hipMemcpy(st.data(), h->state, st.size() * 4, hipMemcpyDeviceToHost));
     CGE_TRY(h, hipMemcpy(mt.data(), h->mt, mt.size() * 4, hipMemcpyDeviceToHost));
     const size_t rec = cge_traffic_state_bytes(h);
-    std::vector<uint32_t> raw((size_t)cols * 4);
     for (int64_t i = 0; i < n; ++i) {
-        for (int c = 0; c < cols; ++c) {
-            const uint4 v = st[(size_t)c * n + i];
-            raw[4 * c] = v.x; raw[4 * c + 1] = v.y; raw[4 * c + 2] = v.z; raw[4 * c + 3] = v.w;
-        }
         uint8_t *p = (uint8_t *)host_buf + (size_t)i * rec;
         int32_t hd[6];
         int32_t *w = (int32_t *)(p + 32);
         double total_reward;
         uint32_t mt_pos, mt_pretw, mt_old0;
-        h->ops.to_record(raw.data(), hd, &total_reward, w, &mt_pos, &mt_pretw, &mt_old0);
+        to_record(&st[(size_t)i * recw], ni, hd, &total_reward, w, &mt_pos, &mt_pretw, &mt_old0);
         mt_export_cpython(&mt[(size_t)i * MT_STRIDE], mt_pos, mt_pretw, (uint32_t *)(w + 16 * ni), &hd[3], &mt_old0);
         memcpy(p, hd, 24);
         memcpy(p + 24, &total_reward, 8);
@@ -796,11 +1271,10 @@ int cge_traffic_set_state(cge_traffic *h, const void *host_buf, void *stream) {
     if (!h || !host_buf) return CGE_ERR_INVALID_ARG;
     DeviceGuard g(h->device);
     const int64_t n = h->n;
-    const int cols = h->ops.cols, ni = h->ops.ni;
-    std::vector<uint4> st((size_t)cols * n);
+    const int recw = h->recw, ni = h->ni;
+    std::vector<uint32_t> st((size_t)recw * n);
     std::vector<uint32_t> mt((size_t)n * MT_STRIDE, 0u);
     const size_t rec = cge_traffic_state_bytes(h);
-    std::vector<uint32_t> raw((size_t)cols * 4);
     for (int64_t i = 0; i < n; ++i) {
         const uint8_t *p = (const uint8_t *)host_buf + (size_t)i * rec;
         int32_t hd[6];
@@ -812,13 +1286,12 @@ int cge_traffic_set_state(cge_traffic *h, const void *host_buf, void *stream) {
         if (!ok) return h->fail(CGE_ERR_INVALID_ARG, "cge_traffic_set_state: malformed record (a field does not fit the device record)");
         double total_reward;
         memcpy(&total_reward, p + 24, 8);
-        h->ops.from_record(hd, total_reward, w, raw.data());
-        for (int c = 0; c < cols; ++c) st[(size_t)c * n + i] = make_uint4(raw[4 * c], raw[4 * c + 1], raw[4 * c + 2], raw[4 * c + 3]);
+        from_record(hd, total_reward, w, ni, recw, &st[(size_t)i * recw]);
         memcpy(&mt[(size_t)i * MT_STRIDE], w + 16 * ni, MT_N * 4);
         memcpy(&mt[(size_t)i * MT_STRIDE + MT_N], &mt[(size_t)i * MT_STRIDE], MT_PAD * 4);     // mirror words (cge_device.hpp)
     }
     CGE_TRY(h, hipStreamSynchronize(as_stream(stream)));
-    CGE_TRY(h, hipMemcpy(h->state, st.data(), st.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    CGE_TRY(h, hipMemcpy(h->state, st.data(), st.size() * 4, hipMemcpyHostToDevice));
     CGE_TRY(h, hipMemcpy(h->mt, mt.data(), mt.size() * 4, hipMemcpyHostToDevice));
     return CGE_OK;
 }

@@ -12,7 +12,7 @@ INFO_FIELDS = {"timestep": 0, "num_vehicles": 1, "light_phase": 2, "light_timer"
                "total_waiting_time": 5, "queue_len": 6, "queue_dest": 7, "queue_wait": 8, "episodes": 9, "needs_reset": 10}
 LIGHT_PHASES = ("NS_GREEN", "NS_YELLOW", "EW_GREEN", "EW_YELLOW")   # config.py:17
 OBS_DIM = 130                    # default layout (9 intersections); an instance's own width is `env.obs_dim`
-SUPPORTED_INTERSECTIONS = (4, 9, 16)
+SUPPORTED_INTERSECTIONS = tuple(range(2, 17))   # 4, 9, 16 (what the reference's scripts build) have kernels of their own
 
 
 class TrafficVectorEnv(DeviceVectorEnv):
@@ -20,9 +20,10 @@ class TrafficVectorEnv(DeviceVectorEnv):
     one HIP kernel launch.
 
     Constructor arguments as the reference's (environment.py:62-83): `grid_size=(rows, cols)`, `num_intersections` (the env
-    controls NI = min(num_intersections, rows*cols) of them), `max_vehicles`, `spawn_rate`.  Kernels are compiled for NI in
-    {4, 9, 16} — what the reference's own scripts build: simple_test.py:71-76 ((3,3), 4, 20, 0.4), the default ((5,5), 9, 50,
-    0.3), USAGE_EXAMPLES.md:32-38 ((6,6), 16, 80, 0.5) — over any grid.
+    controls NI = min(num_intersections, rows*cols) of them), `max_vehicles`, `spawn_rate`.  Any NI from 2 to 16 over any grid; what
+    the reference's own scripts build — simple_test.py:71-76 ((3,3), 4, 20, 0.4), the default ((5,5), 9, 50, 0.3),
+    USAGE_EXAMPLES.md:32-38 ((6,6), 16, 80, 0.5) — runs on kernels specialised for 4 / 9 / 16.  (NI = 1 raises in the reference at
+    the first spawn: randint(2, 1), utils.py:181.)
     Spaces as the reference (:108-130): actions `MultiDiscrete([3]*NI)` (0 maintain, 1 switch to NS_GREEN, 2 switch to
     EW_GREEN), obs `Box(0, inf, (14*NI + 4,), float32)`; reward is the reference's cumulative
     expression (:287-311) returned as float32; terminated when timestep >= 1000; truncated always False.
@@ -56,7 +57,8 @@ class TrafficVectorEnv(DeviceVectorEnv):
         h = C.c_void_p()
         st = self._lib.cge_traffic_create(C.byref(cfg), self.num_envs, self._dev_index, self.env_index0, C.byref(h))
         if st == -3:
-            raise ValueError(f"num_intersections={self.num_intersections} is not compiled into libcge_amd.so (supported: {SUPPORTED_INTERSECTIONS})")
+            raise ValueError(f"num_intersections={self.num_intersections} is not supported: the device record spreads an env over 16 "
+                             f"(slot, lane) places and the reference needs at least 2 (supported: 2..16)")
         if st == -1:
             raise ValueError("TrafficVectorEnv: grid_size within 1..64 per side, 0 <= max_vehicles <= 127, max_steps <= 65535, "
                              "max_vehicles * max_steps <= 262143 and spawn_rate >= 0 are required")
@@ -110,6 +112,7 @@ class TrafficVectorEnv(DeviceVectorEnv):
         if per_step:
             rt = self._out("reward_traj", (k, self.num_envs), torch.float32)
             tt = self._out("terminated_traj", (k, self.num_envs), torch.bool)
+        self._final_obs_begin()
         self._check(self._lib.cge_traffic_rollout(self._h, k, a.data_ptr() if a is not None else None, int(action_seed), int(t0),
                                                   obs.data_ptr() if obs is not None else None, stride,
                                                   rt.data_ptr() if per_step else None, tt.data_ptr() if per_step else None,

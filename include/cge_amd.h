@@ -227,9 +227,10 @@ typedef struct cge_traffic cge_traffic;
 
 typedef struct {                 /* TrafficManagementEnv.__init__ kwargs (:61-66) + config.py */
     int32_t grid_rows, grid_cols;    /* (5, 5); any grid of 1..64 rows / columns: the routes walk the whole grid (utils.py:196-214) */
-    int32_t num_intersections;       /* 9; the env uses NI = min(num_intersections, rows*cols) (:79).  Kernels are compiled for NI in
-                                      * {4, 9, 16} — the layouts the reference's scripts build (simple_test.py:71-76, config.py:6-7,
-                                      * USAGE_EXAMPLES.md:32-38); any other NI: CGE_ERR_UNSUPPORTED */
+    int32_t num_intersections;       /* 9; the env uses NI = min(num_intersections, rows*cols) (:79).  Any NI from 2 to 16: the layouts the
+                                      * reference's scripts build (4, 9, 16: simple_test.py:71-76, config.py:6-7, USAGE_EXAMPLES.md:32-38)
+                                      * have kernels of their own, the others share run-time-NI instances.  NI = 1 raises in the reference
+                                      * at the first spawn (randint(2, 1), utils.py:181); NI = 1 or > 16: CGE_ERR_UNSUPPORTED */
     int32_t max_vehicles;            /* 50; <= 127 and max_vehicles*max_steps <= 262143 (queue word: len:7 dest:7 wait:18) */
     double spawn_rate;               /* 0.3 */
     int32_t max_steps;               /* MAX_TIMESTEPS = 1000 */
@@ -257,21 +258,29 @@ int cge_traffic_destroy(cge_traffic *h);
 /* reset(seed=s) seeding (:145-147): random.seed(s_i); the NumPy generator it also seeds is never drawn from */
 int cge_traffic_seed(cge_traffic *h, const uint64_t *seeds, uint64_t base_seed, void *stream);
 int cge_traffic_reset(cge_traffic *h, const uint8_t *mask, float *obs_out, void *stream);
-/* actions: int32 [n_envs, 9]; values other than 1/2 maintain the phase, as in the reference (:214-220) */
+/* actions: int32 [n_envs, NI]; values other than 1/2 maintain the phase, as in the reference (:214-220) */
 int cge_traffic_step(cge_traffic *h, const int32_t *actions, float *obs_out, float *reward_out,
                      uint8_t *terminated_out, uint8_t *truncated_out /*nullable*/, float *final_obs_out,
                      void *stream);
-/* k fused steps; actions [k, n_envs, 9] or NULL -> cge_hash_action(seed, env, t, 3, j) for intersection j */
+/* k fused steps; actions [k, n_envs, NI] or NULL -> cge_hash_action(seed, env, t, 3, j) for intersection j */
 int cge_traffic_rollout(cge_traffic *h, int32_t k_steps, const int32_t *actions, uint64_t action_seed, int64_t t0,
                         float *obs_out, int64_t obs_step_stride, float *reward_traj_out,
                         uint8_t *terminated_traj_out, double *reward_sum_out, int32_t *done_count_out,
                         void *stream);
+/* <env>_rollout_final_obs: what makes a SAME_STEP rollout "exactly what k step() calls would return".  step() hands the terminal
+ * observation of an env that finishes to final_obs_out (the reference RETURNS it, environment.py:193-203) while obs_out gets the
+ * reset observation; a fused rollout writes the reset observation to slot t of its trajectory, and the terminal rows go HERE,
+ * compacted: registers caller-owned DEVICE buffers rows_out [capacity, obs_dim], index_out [capacity] (int64: step-in-call * n_envs
+ * + env) and count_out [1] (int32; the caller zeroes it, every later rollout adds the rows it delivers — slot order within a call
+ * is not deterministic, sort by index; rows beyond `capacity` are counted but not stored).  All NULL unregisters.  NEXT_STEP /
+ * DISABLED rollouts deliver nothing (slot t of their trajectory IS the terminal observation). */
+int cge_traffic_rollout_final_obs(cge_traffic *h, float *rows_out, int64_t *index_out, int64_t capacity, int32_t *count_out);
 int cge_traffic_info(cge_traffic *h, int32_t field_id, int32_t index, int32_t *out, void *stream);
 /* info['total_reward'] (:372): float64 running sum of the episode's rewards */
 int cge_traffic_total_reward(cge_traffic *h, double *out, void *stream);
 /* canonical record (host), identical to the oracle's: int32[6] {timestep, n_vehicles, needs_reset, mt_idx,
- * episodes, 0}; double total_reward; int32 phase[9], timer[9], passed[9], total_wait[9], qlen[36], qdest[36],
- * qwait[36]; uint32 mt[624]. */
+ * episodes, 0}; double total_reward; int32 phase[NI], timer[NI], passed[NI], total_wait[NI], qlen[4 NI], qdest[4 NI],
+ * qwait[4 NI]; uint32 mt[624]. */
 size_t cge_traffic_state_bytes(const cge_traffic *h);
 int cge_traffic_get_state(cge_traffic *h, void *host_buf, void *stream);
 int cge_traffic_set_state(cge_traffic *h, const void *host_buf, void *stream);

@@ -88,7 +88,17 @@ LAYOUTS = [dict(grid_size=(3, 3), num_intersections=4, max_vehicles=20, spawn_ra
            dict(grid_size=(6, 6), num_intersections=16, max_vehicles=80, spawn_rate=0.5),         # USAGE_EXAMPLES.md:32-38
            dict(grid_size=(2, 7), num_intersections=9, max_vehicles=5, spawn_rate=0.9),           # a non-square grid, a tight vehicle cap
            dict(grid_size=(2, 2), num_intersections=9, max_vehicles=127, spawn_rate=1.0),         # clamped to 4 intersections; always spawns
-           dict(grid_size=(5, 5), num_intersections=9, max_vehicles=50, spawn_rate=0.0)]          # never spawns
+           dict(grid_size=(5, 5), num_intersections=9, max_vehicles=50, spawn_rate=0.0),          # never spawns
+           # intersection counts none of the reference's scripts use (run-time-NI kernels, one per slot count): np.var's pairwise order
+           # below 8 terms, at 8, and with a remainder after the 8-accumulator block; route lengths 2, 2..3, 2..5
+           dict(grid_size=(1, 2), num_intersections=2, max_vehicles=30, spawn_rate=0.6),
+           dict(grid_size=(2, 3), num_intersections=3, max_vehicles=30, spawn_rate=0.5),
+           dict(grid_size=(4, 4), num_intersections=5, max_vehicles=40, spawn_rate=0.5),
+           dict(grid_size=(3, 3), num_intersections=7, max_vehicles=40, spawn_rate=0.5),
+           dict(grid_size=(3, 3), num_intersections=8, max_vehicles=40, spawn_rate=0.5),
+           dict(grid_size=(5, 4), num_intersections=12, max_vehicles=60, spawn_rate=0.5),
+           dict(grid_size=(4, 5), num_intersections=13, max_vehicles=60, spawn_rate=0.5),
+           dict(grid_size=(5, 5), num_intersections=15, max_vehicles=60, spawn_rate=0.5)]
 
 
 @pytest.mark.parametrize("ctor", LAYOUTS, ids=lambda c: f"{c['grid_size'][0]}x{c['grid_size'][1]}_{c['num_intersections']}_{c['max_vehicles']}_{c['spawn_rate']}")
@@ -139,9 +149,51 @@ def test_layouts_and_knobs_match_oracle(cge, oracle, ctor):
     env.close(); twin.close()
 
 
+@pytest.mark.parametrize("ctor", [dict(), dict(grid_size=(3, 3), num_intersections=4, max_vehicles=20, spawn_rate=0.4),
+                                  dict(grid_size=(4, 5), num_intersections=13, max_vehicles=60, spawn_rate=0.5)], ids=["default", "3x3_4", "4x5_13"])
+def test_same_step_rollout_delivers_terminal_observations(cge, ctor):
+    """SAME_STEP rollout(trajectory=True) + the compacted final-obs output == k step() calls' (obs, infos["final_obs"]): the reference
+    returns the terminal observation from step() (environment.py:193-203); the trajectory's slot holds the reset observation."""
+    n, limit, k = 300, 37, 100
+    env = cge.TrafficVectorEnv(n, autoreset_mode="SameStep", max_steps=limit, **ctor)
+    twin = cge.TrafficVectorEnv(n, autoreset_mode="SameStep", max_steps=limit, **ctor)
+    env.reset(seed=3); twin.reset(seed=3)
+    warm = torch.randint(0, 3, (11, n, env.num_intersections), dtype=torch.int32, device="cuda")
+    mask = (torch.arange(n, device="cuda") % 3 == 0).to(torch.uint8)
+    for e in (env, twin):                                  # desynchronise the episodes: a third of the envs restarts 11 steps late
+        for t in range(11):
+            e.step(warm[t])
+        e.reset(options={"reset_mask": mask})
+    env.collect_final_obs(capacity=4 * n)                  # every env finishes two or three episodes in the k steps
+    acts = torch.randint(0, 3, (k, n, env.num_intersections), dtype=torch.int32, device="cuda")
+    traj, rt, tt, rs, dc = env.rollout(k, actions=acts, trajectory=True, per_step=True)
+    rows, step, who = env.final_obs()
+    assert env.final_obs_dropped() == 0 and rows.shape[0] == int(tt.sum())
+    j = 0
+    for t in range(k):
+        ob, r, te, _, info = twin.step(acts[t])
+        assert torch.equal(ob, traj[t]) and torch.equal(te, tt[t])
+        done = torch.nonzero(te).flatten()
+        m = done.numel()
+        if m:
+            assert torch.equal(step[j:j + m], torch.full((m,), t, device="cuda")) and torch.equal(who[j:j + m], done)
+            assert torch.equal(rows[j:j + m], info["final_obs"][done]), t
+            j += m
+    assert j == rows.shape[0] and j >= n * (k // limit)
+    # a smaller capacity: the counter still counts every terminal row
+    env.collect_final_obs(capacity=50)
+    env.rollout(limit, actions=acts[:limit], trajectory=True, per_step=True)
+    rows, step, who = env.final_obs()
+    assert rows.shape[0] == 50 and env.final_obs_dropped() > 0
+    env.collect_final_obs(capacity=0)
+    env.close(); twin.close()
+
+
 def test_unsupported_layouts_and_out_of_range_knobs_are_refused(cge):
-    with pytest.raises(ValueError, match="not compiled"):
-        cge.TrafficVectorEnv(4, grid_size=(5, 5), num_intersections=7)
+    with pytest.raises(ValueError, match="not supported"):
+        cge.TrafficVectorEnv(4, grid_size=(5, 5), num_intersections=17)
+    with pytest.raises(ValueError, match="not supported"):
+        cge.TrafficVectorEnv(4, grid_size=(1, 1), num_intersections=9)       # one intersection: the reference raises at the first spawn
     with pytest.raises(ValueError):
         cge.TrafficVectorEnv(4, max_vehicles=128)
     with pytest.raises(ValueError):

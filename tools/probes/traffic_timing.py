@@ -1,4 +1,5 @@
-"""Per-phase wall-clock of traffic's rollout step (build with -DCGE_TRAFFIC_TIMING into tools/ab/libcge_ttiming.so)."""
+"""Per-phase wall-clock of traffic's rollout step: tools/build_variant.sh ttiming traffic.hip -DCGE_TRAFFIC_TIMING, then
+CGE_AMD_LIBRARY=tools/ab/libcge_ttiming.so python tools/probes/traffic_timing.py.  One wave = 16 envs."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -8,7 +9,8 @@ L = ctypes.CDLL(_native.LIB_PATH)
 env = cge.TrafficVectorEnv(262144, device="cuda:0")
 env.reset(seed=1)
 buf = (ctypes.c_ulonglong * 16)()
-names = ["actions (hash) + outputs of the previous step", "ensure (window top-up)", "lights", "spawn", "process vehicles + reward", "final_obs / reset", "observe"]
+names = ["kernel start (record load)", "prepare: ring top-up + view (+ the previous step's stores draining)", "actions (hash) + lights", "draws + their effects",
+         "process vehicles + reward", "final_obs / reset", "observation row"]
 for chunk in range(3):
     env.rollout(30, action_seed=7, t0=chunk * 30, trajectory=True)
     torch.cuda.synchronize()
