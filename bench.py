@@ -25,7 +25,10 @@ cores: reported, not the target).  roofline fields:
                the same figure minus the state that legitimately stays in registers and the action read
   traffic      HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/traffic.json,
                2*FETCH_SIZE + WRITE_SIZE per env-step x env-steps per launch); frac_moved = traffic / time / peak
-  peak         8 TB/s (spec); peak_measured = this box's device-to-device copy bandwidth measured in this run
+  peak         8 TB/s (spec); peak_measured = the larger of this box's device-to-device copy bandwidth (bytes read + written) and its
+               pure fill_ (store) rate, both measured in this run and both reported — a write-dominated kernel is held against the fill rate
+The K-step timed region (barrier + synchronize on both sides, max over ranks) is run `--repeats` times (default 9; episodes restarted
+before each one where the workload fixes the episode phase): `value` / `ms_per_step` are the MEDIAN region, `spread` holds min and max.
 """
 import argparse
 import json
@@ -54,7 +57,9 @@ ENVS = {
     # rollout: the 50-candle window (1,200 B) is resident in LDS for a launch (read once: resident_ro); per step only the new candle
     # (24 B, written through) and the generator words (144 B) stream
     "crypto":  dict(algo=2346, obs=1044, state=64, resident=64, resident_ro=1200, stream=168, n_act=5, act_shape=(),   dtype="f64", ref_py="1.64e3-1.68e3 steps/s/process"),
-    "traffic": dict(algo=1134, obs=520, state=240, resident=240, stream=60, n_act=3, act_shape=(9,), dtype="int32", ref_py="1.75e3-1.90e3 steps/s/process"),
+    # round 4: array-of-structs record of 62 dwords padded to 256 B, register-resident over a fused launch; SAME_STEP rollouts also deliver the
+    # terminal row of every episode that ends (final_per_step: 520 B once per 1000-step episode)
+    "traffic": dict(algo=1134, obs=520, state=256, resident=256, stream=60, final_per_step=0.52, n_act=3, act_shape=(9,), dtype="int32", ref_py="1.75e3-1.90e3 steps/s/process"),
     "parking": dict(algo=662,  obs=52, state=288, resident=288, stream=24, n_act=8, act_shape=(),   dtype="f64", ref_py="2.66e4 steps/s/process"),
     "climate": dict(algo=218,  obs=36, state=80, resident=80, stream=0, n_act=None, act_shape=None, dtype="f64", ref_py="1.27e4 steps/s/process"),
     # fleet's rollout is K (step, dense) launch pairs: the record goes through HBM every step
@@ -69,17 +74,23 @@ ENVS = {
 WORKLOADS = {
     "snake_1m": dict(env="snake", n=1 << 20, desc="SnakeEnv 10x10, 1,048,576 parallel envs per GPU, random actions, fused auto-reset"),
     "snake_64k": dict(env="snake", n=1 << 16, desc="SnakeEnv 10x10, 65,536 envs per GPU (quick check)"),
-    "crypto_1m": dict(env="crypto", n=1 << 20, desc="crypto_trading_env discrete, 1,048,576 parallel envs per GPU"),
+    "crypto_1m": dict(env="crypto", n=1 << 20, episode_start=True, episode=1000, traj_gib=128.0,
+                      desc="crypto_trading_env discrete, 1,048,576 parallel envs per GPU, timed from the start of an episode"),
     # episode_start: every env is re-seeded and reset right before each timed region, so the K timed steps are steps 1..K of an
     # episode — the spawn phase (the RNG-heavy one: the reference stops spawning at 50 vehicles, ~step 200) is inside the window,
     # and --steps 1000 times exactly one whole episode
-    "traffic_262k": dict(env="traffic", n=1 << 18, episode_start=True,
+    "traffic_262k": dict(env="traffic", n=1 << 18, episode_start=True, episode=1000,
                          desc="traffic_management_env (9 intersections), 262,144 parallel envs per GPU, timed from the start of an episode"),
-    "parking_131k": dict(env="parking", n=1 << 17, desc="smart_parking_env, 131,072 parallel envs per GPU"),
-    "climate_131k": dict(env="climate", n=1 << 17, desc="smartclimate, 131,072 parallel envs per GPU"),
-    "fleet_131k": dict(env="fleet", n=1 << 17, desc="fleet_management_env, 131,072 parallel envs per GPU"),
-    "manufacturing_131k": dict(env="manufacturing", n=1 << 17, desc="smart_manufacturing_env, 131,072 parallel envs per GPU"),
-    "hospital_131k": dict(env="hospital", n=1 << 17, desc="hospital_management_env, 131,072 parallel envs per GPU"),
+    "parking_131k": dict(env="parking", n=1 << 17, episode_start=True, episode=1440,
+                         desc="smart_parking_env, 131,072 parallel envs per GPU, timed from the start of an episode"),
+    "climate_131k": dict(env="climate", n=1 << 17, episode_start=True, episode=1440,
+                         desc="smartclimate, 131,072 parallel envs per GPU, timed from the start of an episode"),
+    "fleet_131k": dict(env="fleet", n=1 << 17, episode_start=True, episode=800,
+                       desc="fleet_management_env, 131,072 parallel envs per GPU, timed from the start of an episode (episodes end early and restart in place)"),
+    "manufacturing_131k": dict(env="manufacturing", n=1 << 17, episode_start=True, episode=1500,
+                               desc="smart_manufacturing_env, 131,072 parallel envs per GPU, timed from the start of an episode"),
+    "hospital_131k": dict(env="hospital", n=1 << 17, episode_start=True, episode=1440,
+                          desc="hospital_management_env, 131,072 parallel envs per GPU, timed from the start of an episode"),
     "hetero_split_131k": dict(env="hetero_split", n=1 << 17,
                               desc="heterogeneous batch, placement A: every env type x 131,072, the types dealt round-robin over the GPUs "
                                    "(one type per GPU at N=8), results identical to placement B because seeds follow the global env index"),
@@ -91,7 +102,7 @@ WORKLOADS = {
 def roll_algo(name, kc, occupancy=0.0):
     s = ENVS[name]
     return (s["obs"] + 4 + 1 + s["stream"] + 2 * (s["state"] - s["resident"]) + (2.0 * s["resident"] + s.get("resident_ro", 0)) / max(kc, 1)
-            + s.get("algo_per_product", 0) * occupancy)
+            + s.get("algo_per_product", 0) * occupancy + s.get("final_per_step", 0.0))
 
 
 def step_algo(name, occupancy=0.0):
@@ -220,11 +231,18 @@ def roofline(name, path, kernel, gpu_ms, launches, steps_per_launch, n, occupanc
          "timing": "HIP events on the launch stream over the timed region",
          "algorithmic_note": ("fused rollout: obs + reward + flag + generator/table stream + non-resident state, resident record once per launch"
                               if path == "rollout" else "SURVEY 8d per-step figure")}
+    if per_step is not None:
+        r["traffic_note"] = ("2 x FETCH_SIZE + WRITE_SIZE: the gfx950 half-count of wide coalesced reads (MI355X_MICROARCH.md, HBM) applied to ALL "
+                             "reads of the kernel — for scattered 32..128-byte generator reads that may over-count the read side (conservative)")
     if measured:
-        r["peak_measured"] = measured["copy_GBs"]
-        r["frac_of_measured"] = achieved / measured["copy_GBs"]
-        r["peak_measured_note"] = (f"device-to-device copy_ of 2 GiB on this box (read + written bytes / s); pure fill_ "
-                                   f"{measured['fill_GBs']:.0f} GB/s")
+        r["peak_copy_measured"] = measured["copy_GBs"]
+        r["peak_fill_measured"] = measured["fill_GBs"]
+        r["peak_measured"] = max(measured["copy_GBs"], measured["fill_GBs"])
+        r["frac_of_copy"] = achieved / measured["copy_GBs"]
+        r["frac_of_fill"] = achieved / measured["fill_GBs"]
+        r["frac_of_measured"] = achieved / r["peak_measured"]
+        r["peak_measured_note"] = ("this box, this run, 2-GiB torch buffers: copy_ = bytes read + written per second, fill_ = bytes written per second; "
+                                   "peak_measured is the larger: the yardstick for a write-dominated kernel is the fill rate")
     return r
 
 
@@ -297,9 +315,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="snake_1m", choices=sorted(WORKLOADS))
     ap.add_argument("--path", default="rollout", choices=["rollout", "step"])
-    ap.add_argument("--traj-gib", type=float, default=24.0, help="cap on the per-env-type trajectory buffer of the rollout leg")
+    ap.add_argument("--traj-gib", type=float, default=None,
+                    help="cap on the per-env-type trajectory buffer of the rollout leg (default 24; crypto_1m 128: its rows are 1,044 B, and a launch "
+                         "should be long enough to amortise the 1,200-byte window load — 117 steps per launch on the 288-GB part)")
     ap.add_argument("--manifest", default=None, help="write {kernel: env-steps launched} here (tools/profile.sh uses it to turn PMC bytes into bytes per env-step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--repeats", type=int, default=9, help="the K-step timed region is run this many times; value / ms_per_step = the median region")
+    ap.add_argument("--episode", action="store_true", help="--steps := the workload's episode length (one whole episode per timed region)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -331,7 +353,9 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     wl = WORKLOADS[args.workload]
-    n, K, W = wl["n"], args.steps, args.warmup
+    if args.episode and wl.get("episode"):
+        args.steps = wl["episode"]
+    n, K, W, R = wl["n"], args.steps, args.warmup, max(1, args.repeats)
     dev = torch.device("cpu") if dry else torch.device("cuda", local_rank)
     if wl["env"] == "hetero":
         names = sorted(ENVS)
@@ -374,7 +398,8 @@ def main():
             return self.cm.__exit__(*a) if self.cm else False
 
     # rollout leg: kc steps per launch, every step's obs / reward / flag to its own place in a [kc, N, ...] trajectory
-    budget = args.traj_gib * (1 << 30) / (1 if len(names) == 1 else 4)
+    traj_gib = args.traj_gib if args.traj_gib is not None else wl.get("traj_gib", 24.0)
+    budget = traj_gib * (1 << 30) / (1 if len(names) == 1 else 4)
     kc = {nm: max(1, min(K, int(budget // (n * ENVS[nm]["obs"])))) for nm in names}
     launched = {}                                        # kernel name -> env-steps launched (for --manifest)
     ran = {}                                             # (env type, path) -> the kernel the library says it launched last
@@ -385,7 +410,7 @@ def main():
         ran[(nm, path)] = kern
         launched[kern] = launched.get(kern, 0) + n * steps
 
-    def run_rollout(k_total, t0):
+    def run_rollout(k_total, t0, marks=None):
         for nm in names:
             with on_stream(nm):
                 done = 0
@@ -394,62 +419,102 @@ def main():
                     envs[nm].rollout(k, action_seed=123, t0=t0 + done, trajectory=True, per_step=True)
                     count(nm, "rollout", k)
                     done += k
+                    if marks is not None and not dry:                # one event per launch: the cost of a step early / late in the region
+                        ev = torch.cuda.Event(enable_timing=True)
+                        ev.record(streams[nm])
+                        marks[nm].append((ev, done))
 
-    def run_steps(actions, lo, hi):
+    def run_steps(actions, lo, hi, marks=None):
+        seg = max(1, (hi - lo) // 10)
         for t in range(lo, hi):
             for nm in names:
                 with on_stream(nm):
                     envs[nm].step(act_at(nm, actions[nm], t))
+                    if marks is not None and not dry and ((t + 1 - lo) % seg == 0 or t + 1 == hi):
+                        ev = torch.cuda.Event(enable_timing=True)
+                        ev.record(streams[nm])
+                        marks[nm].append((ev, t + 1 - lo))
         for nm in names:
             count(nm, "step", hi - lo)
 
     occupancy = {}
     host_latency_ms = {}
+    spread = {}
+    segments = {}
     primer = [None]
 
     def mean_occupancy():
         return {nm: float(envs[nm].info("in_system").mean().item()) for nm in names if "algo_per_product" in ENVS[nm]}
 
-    def timed(fn, tag=None, again=None):
-        """(wall seconds of fn() between two barriers, per-env GPU milliseconds of its launches).  The wall clock is the contract's
-        number (`value`, `ms_per_step`).  The GPU time feeds the roofline and must be the KERNELS' time: HIP events recorded on an
-        idle stream also count the host's way to the first launch (stream switch, argument checks, the launch itself: 50-100 us,
-        a fifth of a 20-step launch), so with `again` the same launches run a second time queued behind a primer that keeps the
-        card busy while the host enqueues event, launches and event — those events see the kernels back to back.  Without
-        `again` the first pass's events are used."""
-        before = mean_occupancy()
-        barrier()
-        evs = {}
-        if not dry:
-            evs = {nm: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for nm in names}
-        t0 = time.perf_counter()
-        for nm in evs:
-            evs[nm][0].record(streams[nm])          # on the stream the kernels are launched on
-        fn()
-        for nm in evs:
-            evs[nm][1].record(streams[nm])
-        barrier()
-        wall = time.perf_counter() - t0
-        after = mean_occupancy()
-        occupancy[tag] = {nm: 0.5 * (before[nm] + after[nm]) for nm in before}
-        first = {nm: (evs[nm][0].elapsed_time(evs[nm][1]) if evs else wall * 1e3) for nm in names}
-        host_latency_ms[tag] = None
-        if again is not None and evs:
-            ev2 = {nm: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for nm in names}
-            prepare, run = again
-            prepare()
-            if primer[0] is None:
-                primer[0] = (torch.empty(1 << 28, dtype=torch.float32, device=dev), torch.empty(1 << 28, dtype=torch.float32, device=dev))
-            sync()
-            for nm in names:
-                with on_stream(nm):
-                    primer[0][0].copy_(primer[0][1])  # a 1-GiB copy (~0.45 ms at full HBM rate: a spinning wave would let the clocks drop) on this
-                ev2[nm][0].record(streams[nm])        # stream: the queue behind it fills before it ends
-            run()
-            for nm in names:
-                ev2[nm][1].record(streams[nm])
+    def restart_episodes():
+        if wl.get("episode_start"):
+            for e in envs.values():
+                e.reset(seed=0)
+
+    def median(xs):
+        xs = sorted(xs)
+        return xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2])
+
+    def timed(fn, tag, second_pass):
+        """R repeats of one timed region = fn(rep, marks): K steps between two barriers (the contract's clock).  Returns (median wall
+        seconds, per-env GPU milliseconds of the median region's launches).  The wall clock is `value` / `ms_per_step`.  The GPU time
+        feeds the roofline and must be the KERNELS' time: HIP events recorded on an idle stream also count the host's way to the first
+        launch (stream switch, argument checks, the launch itself: 15-100 us, up to a fifth of a 20-step launch), so with `second_pass` the
+        same launches run again queued behind a primer that keeps the card busy while the host enqueues event, launches and event —
+        those events see the kernels back to back.  Without it the first passes' events are used."""
+        walls, firsts, occ = [], [], []
+        for rep in range(R):
+            restart_episodes()
+            before = mean_occupancy()
             barrier()
-            second = {nm: ev2[nm][0].elapsed_time(ev2[nm][1]) for nm in names}
+            evs = {}
+            if not dry:
+                evs = {nm: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for nm in names}
+            marks = {nm: [] for nm in names}
+            t0 = time.perf_counter()
+            for nm in evs:
+                evs[nm][0].record(streams[nm])          # on the stream the kernels are launched on
+            fn(rep, marks)
+            for nm in evs:
+                evs[nm][1].record(streams[nm])
+            barrier()
+            walls.append(time.perf_counter() - t0)
+            after = mean_occupancy()
+            occ.append({nm: 0.5 * (before[nm] + after[nm]) for nm in before})
+            firsts.append({nm: (evs[nm][0].elapsed_time(evs[nm][1]) if evs else walls[-1] * 1e3) for nm in names})
+            if evs:                                     # us per step of each segment of the region (a launch of the rollout leg, a tenth of the step() leg)
+                seg = {}
+                for nm in names:
+                    prev_ev, prev_done, out = evs[nm][0], 0, []
+                    for ev, done in marks[nm]:
+                        out.append({"steps": [prev_done + 1, done], "us_per_step": prev_ev.elapsed_time(ev) * 1e3 / max(done - prev_done, 1)})
+                        prev_ev, prev_done = ev, done
+                    seg[nm] = out
+                segments[tag] = seg
+        occupancy[tag] = {nm: sum(o[nm] for o in occ) / len(occ) for nm in occ[0]} if occ and occ[0] else {}
+        wall = median(walls)
+        spread[tag] = {"repeats": R, "min_ms_per_step": min(walls) * 1e3 / K, "max_ms_per_step": max(walls) * 1e3 / K,
+                       "all_ms_per_step": [w * 1e3 / K for w in walls]}
+        first = {nm: median([f[nm] for f in firsts]) for nm in names}
+        host_latency_ms[tag] = None
+        if second_pass and not dry:
+            seconds = []
+            for rep in range(min(R, 3)):
+                ev2 = {nm: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for nm in names}
+                restart_episodes()
+                if primer[0] is None:
+                    primer[0] = (torch.empty(1 << 28, dtype=torch.float32, device=dev), torch.empty(1 << 28, dtype=torch.float32, device=dev))
+                sync()
+                for nm in names:
+                    with on_stream(nm):
+                        primer[0][0].copy_(primer[0][1])  # a 1-GiB copy (~0.45 ms at full HBM rate: a spinning wave would let the clocks drop) on this
+                    ev2[nm][0].record(streams[nm])        # stream: the queue behind it fills before it ends
+                fn(R + rep, None)
+                for nm in names:
+                    ev2[nm][1].record(streams[nm])
+                barrier()
+                seconds.append({nm: ev2[nm][0].elapsed_time(ev2[nm][1]) for nm in names})
+            second = {nm: median([x[nm] for x in seconds]) for nm in names}
             host_latency_ms[tag] = {nm: first[nm] - second[nm] for nm in names}
             return wall, second
         return wall, first
@@ -464,30 +529,18 @@ def main():
         count(nm, "rollout", min(kc[nm], K))
     sync()
     run_rollout(max(W, 1), K)                                        # W untimed warm-up steps
-
-    def restart_episodes():
-        if wl.get("episode_start"):
-            for e in envs.values():
-                e.reset(seed=0)
-    restart_episodes()
     t_roll = 0 if wl.get("episode_start") else K + max(W, 1)
-
-    # the same K steps once more (from the same episode phase where the workload fixes it)
-    again = (restart_episodes, lambda: run_rollout(K, t_roll if wl.get("episode_start") else t_roll + K))
-    # ... only where the second pass does the same work as the first: snake (episodes of tens of steps: a steady state) and the workloads
-    # that restart their episodes; crypto, manufacturing and hospital steps cost more the later they come in an episode, and their
-    # launches are long enough for the host's 30-100 us not to matter
+    # the events' second pass only where it repeats the first pass's work: snake (episodes of tens of steps: a steady state) and the
+    # workloads that restart their episodes before every region
     same_work = len(names) == 1 and (names[0] == "snake" or bool(wl.get("episode_start")))
-    results["rollout"] = timed(lambda: run_rollout(K, t_roll), "rollout", again=again if same_work else None)
+    results["rollout"] = timed(lambda rep, marks: run_rollout(K, t_roll if wl.get("episode_start") else t_roll + rep * K, marks), "rollout", same_work)
     if not dry:
         for e in envs.values():                                      # the trajectory buffers are not needed by the API leg
             e._bufs.pop("traj", None)
         torch.cuda.empty_cache()
     actions = {nm: (None if dry else make_actions(nm, K + W, n, dev)) for nm in names}  # API path: K step() calls, HBM-resident actions
     run_steps(actions, 0, W)
-    restart_episodes()
-    results["step"] = timed(lambda: run_steps(actions, W, W + K), "step",
-                            again=(restart_episodes, lambda: run_steps(actions, W, W + K)) if same_work else None)
+    results["step"] = timed(lambda rep, marks: run_steps(actions, W, W + K, marks), "step", same_work)
     if "snake" in envs:
         assert envs["snake"].invalid_action_count() == 0
     measured = None
@@ -509,7 +562,12 @@ def main():
 
         def block(path):
             wall, gpu_ms = walls[path], results[path][1]
-            b = {"path": path, "value": total_envs * K / wall, "unit": "env-steps/s", "ms_per_step": wall * 1e3 / K}
+            b = {"path": path, "value": total_envs * K / wall, "unit": "env-steps/s", "ms_per_step": wall * 1e3 / K, "spread": spread[path]}
+            if segments.get(path) and len(names) == 1:
+                sg = segments[path][names[0]]
+                if sg:
+                    b["phases"] = {"early_us_per_step": sg[0]["us_per_step"], "late_us_per_step": sg[-1]["us_per_step"], "segments": sg,
+                                   "note": "HIP events between the launches (rollout leg) / every tenth of the region (step() leg) of the last repeat"}
             rl = {}
             for nm in names:
                 kern = ran[(nm, path)]                   # set by the timed region's own launches (the last thing each leg ran)
@@ -535,8 +593,8 @@ def main():
                        "timing": "wall clock of the timed region (barrier + synchronize on both sides), all env types' streams together",
                        "algorithmic_note": "sum over the env types of each type's own figure (roofline_per_env_type)"}
                 if measured:
-                    agg["peak_measured"] = measured["copy_GBs"]
-                    agg["frac_of_measured"] = agg["achieved"] / measured["copy_GBs"]
+                    agg["peak_measured"] = max(measured["copy_GBs"], measured["fill_GBs"])
+                    agg["frac_of_measured"] = agg["achieved"] / agg["peak_measured"]
                 b["roofline_aggregate"] = agg
             return b
 
@@ -544,7 +602,7 @@ def main():
         out = {
             "metric": "env steps/sec (whole node) at 1M parallel envs; achieved HBM GB/s vs peak",
             "value": hb["value"], "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": hb["ms_per_step"], "higher_is_better": True, "scaling": "strong" if split else "weak", "vs_baseline": None,
+            "ms_per_step": hb["ms_per_step"], "spread": hb["spread"], "higher_is_better": True, "scaling": "strong" if split else "weak", "vs_baseline": None,
             "dtype": ENVS[names[0]]["dtype"] if len(names) == 1 else "mixed", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {wl['desc']}", "envs_per_gpu": n * len(names), "env_types": names,
                        "path": (("rollout: K (step, dense-reset) launch pairs queued by one C-ABI call, every step's obs / reward / flag written to "
@@ -554,13 +612,17 @@ def main():
                                  f"[{kc[names[0]]}, N, ...] trajectory in HBM, device-side action hash")
                                 if head == "rollout" else "K C-ABI step() calls through the VectorEnv facade, HBM-resident actions"),
                        "autoreset": "SameStep", "parallelism": f"env-sharded x{world}, no data-path collective",
-                       "episode_phase": (f"steps 1..{K} of an episode (envs reset right before the timed region)" if wl.get("episode_start")
+                       "episode_phase": (f"steps 1..{K} of an episode (envs reset right before every timed region"
+                                         + (f"; a whole episode is {wl['episode']} steps: --episode" if wl.get("episode") and K != wl["episode"] else "") + ")"
+                                         if wl.get("episode_start")
                                          else f"steady state: the timed region starts {K + max(W, 1) + min(kc[names[0]], K)} steps after reset")},
             "roofline": hb["roofline"] if len(names) == 1 else hb["roofline_aggregate"],
         }
         if dry:
             out["data"] = "DRY RUN (CGE_BENCH_DRYRUN=1): no device work, numbers are meaningless"
             out["roofline"] = None
+        if hb.get("phases"):
+            out["phases"] = hb["phases"]
         if len(names) > 1:
             out["roofline_per_env_type"] = hb["roofline"]
         out["api_step" if other == "step" else "fused_rollout"] = block(other)
