@@ -69,6 +69,8 @@ SIGNATURES = {
     "cge_snake_reset": (C.c_int, [_vp, _vp, _vp, _vp]),
     "cge_snake_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cge_snake_rollout": (C.c_int, [_vp, _i32, _vp, _u64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "cge_snake_rollout_final_obs": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "cge_snake_final_obs_segment": (_i64, [_vp]),
     "cge_snake_info": (C.c_int, [_vp, _i32, _vp, _vp]),
     "cge_snake_render_rgb": (C.c_int, [_vp, _vp, _vp]),
     "cge_snake_state_bytes": (_sz, [_vp]),
@@ -86,6 +88,8 @@ SIGNATURES = {
     "cge_crypto_reset": (C.c_int, [_vp, _vp, _vp, _vp]),
     "cge_crypto_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cge_crypto_rollout": (C.c_int, [_vp, _i32, _vp, _u64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "cge_crypto_rollout_final_obs": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "cge_crypto_final_obs_segment": (_i64, [_vp]),
     "cge_crypto_info": (C.c_int, [_vp, _i32, _vp, _vp]),
     "cge_crypto_state_bytes": (_sz, [_vp]),
     "cge_crypto_get_state": (C.c_int, [_vp, _vp, _vp]),
@@ -102,6 +106,7 @@ SIGNATURES = {
     "cge_traffic_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cge_traffic_rollout": (C.c_int, [_vp, _i32, _vp, _u64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "cge_traffic_rollout_final_obs": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "cge_traffic_final_obs_segment": (_i64, [_vp]),
     "cge_traffic_info": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "cge_traffic_total_reward": (C.c_int, [_vp, _vp, _vp]),
     "cge_traffic_state_bytes": (_sz, [_vp]),
@@ -117,6 +122,8 @@ SIGNATURES = {
     "cge_parking_reset": (C.c_int, [_vp, _vp, _vp, _vp]),
     "cge_parking_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cge_parking_rollout": (C.c_int, [_vp, _i32, _vp, _u64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "cge_parking_rollout_final_obs": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "cge_parking_final_obs_segment": (_i64, [_vp]),
     "cge_parking_info": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "cge_parking_info64": (C.c_int, [_vp, _i32, _vp, _vp]),
     "cge_parking_snapshot_bytes": (_sz, [_vp]),
@@ -132,6 +139,8 @@ SIGNATURES = {
     "cge_climate_reset": (C.c_int, [_vp, _vp, _vp, _vp]),
     "cge_climate_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cge_climate_rollout": (C.c_int, [_vp, _i32, _vp, _vp, _u64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "cge_climate_rollout_final_obs": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "cge_climate_final_obs_segment": (_i64, [_vp]),
     "cge_climate_info": (C.c_int, [_vp, _i32, _vp, _vp]),
     "cge_climate_snapshot_bytes": (_sz, [_vp]),
     "cge_climate_snapshot_get": (C.c_int, [_vp, _vp, _vp]),
@@ -146,6 +155,8 @@ SIGNATURES = {
     "cge_fleet_reset": (C.c_int, [_vp, _vp, _vp, _vp]),
     "cge_fleet_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cge_fleet_rollout": (C.c_int, [_vp, _i32, _vp, _u64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "cge_fleet_rollout_final_obs": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "cge_fleet_final_obs_segment": (_i64, [_vp]),
     "cge_fleet_info": (C.c_int, [_vp, _i32, _vp, _vp]),
     "cge_fleet_snapshot_bytes": (_sz, [_vp]),
     "cge_fleet_snapshot_get": (C.c_int, [_vp, _vp, _vp]),
@@ -161,6 +172,8 @@ SIGNATURES = {
     "cge_manufacturing_reset": (C.c_int, [_vp, _vp, _vp, _vp]),
     "cge_manufacturing_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cge_manufacturing_rollout": (C.c_int, [_vp, _i32, _vp, _u64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "cge_manufacturing_rollout_final_obs": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "cge_manufacturing_final_obs_segment": (_i64, [_vp]),
     "cge_manufacturing_info": (C.c_int, [_vp, _i32, _vp, _vp]),
     "cge_manufacturing_snapshot_bytes": (_sz, [_vp]),
     "cge_manufacturing_snapshot_get": (C.c_int, [_vp, _vp, _vp]),
@@ -176,6 +189,8 @@ SIGNATURES = {
     "cge_hospital_reset": (C.c_int, [_vp, _vp, _vp, _vp]),
     "cge_hospital_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cge_hospital_rollout": (C.c_int, [_vp, _i32, _vp, _u64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "cge_hospital_rollout_final_obs": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "cge_hospital_final_obs_segment": (_i64, [_vp]),
     "cge_hospital_info": (C.c_int, [_vp, _i32, _vp, _vp]),
     "cge_hospital_snapshot_bytes": (_sz, [_vp]),
     "cge_hospital_snapshot_get": (C.c_int, [_vp, _vp, _vp]),

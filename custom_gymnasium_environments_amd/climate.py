@@ -26,8 +26,10 @@ class ClimateVectorEnv(DeviceVectorEnv):
     metadata = {"render_modes": []}
 
     def __init__(self, num_envs, device="cuda:0", autoreset_mode="NextStep", env_index0=0, max_occupancy=8, episode_minutes=1440,
-                 reuse_buffers=False, info_fields=(), record_episode_statistics=False):
+                 reuse_buffers=False, info_fields=(), record_episode_statistics=False, reference_info=False):
         self._init_common(num_envs, device, autoreset_mode, env_index0, reuse_buffers)
+        self._reference_info = bool(reference_info)
+        self._last_obs = None
         lo = np.array([0.0, 0, 0.0, 10.0, 16.0, 0, 0, 0, 0]); hi = np.array([50.0, max_occupancy, 23.99, 50.0, 32.0, 1, 1, 1, 1])
         self.single_observation_space = Box(lo, hi, (OBS_DIM,), np.float32)
         self.single_action_space = {"ac_temp": Box(16.0, 32.0, (1,), np.float32), "lights": Box(0, 1, (4,), np.int8)}
@@ -58,6 +60,7 @@ class ClimateVectorEnv(DeviceVectorEnv):
         obs = self._out("obs", self._obs_shape, torch.float32)
         self._check(self._lib.cge_climate_reset(self._h, mask.data_ptr() if mask is not None else None, obs.data_ptr(),
                                                 self._stream()), "reset")
+        self._last_obs = obs
         return obs, self._infos()
 
     def step(self, actions):
@@ -72,6 +75,7 @@ class ClimateVectorEnv(DeviceVectorEnv):
         fin = self._out("final_obs", self._obs_shape, torch.float32) if same else None
         self._check(self._lib.cge_climate_step(self._h, ac.data_ptr(), li.data_ptr(), obs.data_ptr(), rew.data_ptr(), term.data_ptr(),
                                                None, fin.data_ptr() if same else None, self._stream()), "step")
+        self._last_obs = obs
         infos = self._infos()
         if same:
             infos["final_obs"] = fin
@@ -109,4 +113,24 @@ class ClimateVectorEnv(DeviceVectorEnv):
         return out
 
     def _infos(self):
-        return {f: self.info(f) for f in self.info_fields}
+        d = {f: self.info(f) for f in self.info_fields}
+        if self._reference_info:
+            d.update(self.reference_info())
+        return d
+
+    def reference_info(self, obs=None):
+        """The reference's step() `info` under ITS keys (env.py:105-110): the three terms of calculate_reward (utils.py:30-50) —
+        comfort (10 / 5 / 0 / -15 |T - 22| by the room temperature's band), ac_penalty = -0.5 |ac_setting - outside_temp|,
+        light_penalty = -max(0, lights_on - min(4, ceil(num_people / 2))) — and comfort_time, energy_usage, step; float64, from the
+        env's CURRENT state (room / outside temperature, AC setting and occupancy from the state record, the light switches from the
+        observation: `obs`, default the last one step() / reset() returned).  `reference_info=True` merges it into every `infos`."""
+        obs = self._last_obs if obs is None else obs
+        room, out, ac, people = self.info("room_temp"), self.info("outside_temp"), self.info("ac_setting"), self.info("num_people")
+        comfort = torch.where((room >= 20) & (room <= 24), torch.full_like(room, 10.0),
+                              torch.where((room >= 18) & (room <= 26), torch.full_like(room, 5.0),
+                                          torch.where((room >= 16) & (room <= 28), torch.zeros_like(room), -15.0 * (room - 22.0).abs())))
+        lights_on = obs[:, 5:9].to(torch.float64).sum(1)
+        required = torch.clamp(torch.ceil(people / 2.0), max=4.0)
+        return {"comfort": comfort, "ac_penalty": -0.5 * (ac - out).abs(), "light_penalty": -torch.clamp(lights_on - required, min=0.0),
+                "comfort_time": self.info("comfort_time").to(torch.int64), "energy_usage": self.info("energy_usage"),
+                "step": self.info("step").to(torch.int64)}

@@ -872,6 +872,58 @@ __device__ __forceinline__ void coop_flush(LdsBulkDraws<W> &d, int row_stride) {
     }
 }
 
+// ------------------------------------------------------------------ terminal observations of fused SAME_STEP rollouts
+// A fused rollout writes the RESET observation of an env that finishes at step t to slot t of its trajectory; the terminal one —
+// what step() hands to final_obs_out — goes to a side buffer compacted PER SEGMENT: the envs one wave steps (64 consecutive envs; 16
+// for traffic) own fin_cap consecutive rows, the wave keeps the segment's fill count in a register for the whole launch and writes it
+// out once at the end.  No atomics and nothing a wave waits for: a returning atomic in the step loop would wait, like a load, for
+// every observation store issued before it (one in-order memory counter per wave), and one counter for 16,384 waves saturates at
+// ~90 updates per microsecond.
+struct FinalSeg {
+    void *rows;
+    int64_t *index;
+    int32_t *count;
+    int64_t cap, n;
+};
+// The lanes of the wave that are active here AND have `fin` take consecutive slots after `used` (wave-uniform); returns the lane's
+// global row index into rows / index (or -1: not a finishing lane, nothing registered, segment full) and records (t, env) for it.
+// The caller adds wave_count(fin) to `used` where the wave is convergent again.
+__device__ __forceinline__ int64_t final_slot(const FinalSeg &f, int64_t seg, uint32_t used, bool fin, int64_t t, int64_t i) {
+    if (!f.rows) return -1;
+    const unsigned long long m = __ballot(fin);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t slot = used + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (!fin || (int64_t)slot >= f.cap) return -1;
+    const int64_t gs = seg * f.cap + slot;
+    f.index[gs] = t * f.n + i;
+    return gs;
+}
+
+// Where row r of a wave's staged tile goes: row r of the destination (dense), or — compacted terminal rows — the rows of `mask` in
+// lane order, at most `room` of them (the caller points the destination at the segment's first free row).
+struct RowMap {
+    unsigned long long mask;
+    int64_t nrows, room;
+    bool compact;
+    __device__ __forceinline__ bool row(uint32_t r, int64_t &out) const {
+        if ((int64_t)r >= nrows || !((mask >> r) & 1ull)) return false;
+        if (!compact) { out = (int64_t)r; return true; }
+        const int64_t k = (int64_t)__popcll(mask & ((1ull << r) - 1ull));
+        out = k;
+        return k < room;
+    }
+};
+// wave-convergent bookkeeping of one step's terminal rows for the tile-staged kernels: records (t, env) of the finishing lanes, returns
+// the map and the destination of the segment's first free row; the caller stores the rows and adds popcount(mask) to `used`
+template <class T>
+__device__ __forceinline__ RowMap final_rows(const FinalSeg &f, int64_t seg, uint32_t used, bool fin, unsigned long long fin_mask, int64_t nrows, int64_t t,
+                                             int64_t i, int64_t row_elems, T *&dst) {
+    (void)final_slot(f, seg, used, fin, t, i);
+    const int64_t room = f.cap - (int64_t)used;
+    dst = static_cast<T *>(f.rows) + (seg * f.cap + (int64_t)used) * row_elems;
+    return RowMap{fin_mask, nrows, room > 0 ? room : 0, true};
+}
+
 // ------------------------------------------------------------------ small register arrays
 // Runtime-indexed register arrays go to scratch on hipcc; these helpers keep every index static
 // (fully unrolled select chains) so the env state stays in VGPRs.

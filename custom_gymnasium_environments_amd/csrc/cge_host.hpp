@@ -23,6 +23,11 @@ struct HandleBase {
     double *ep_ret = nullptr;      // episode-statistics outputs registered by <env>_episode_stats (caller-owned device buffers)
     int32_t *ep_len = nullptr;
     uint8_t *done_out = nullptr;   // step(): terminated | truncated per env, registered by <env>_done_mask (caller-owned device buffer, nullable)
+    // <env>_rollout_final_obs: terminal observations of SAME_STEP rollouts, compacted per SEGMENT of consecutive envs (one wave's envs)
+    void *fin_rows = nullptr;      // [n_segments * fin_cap, *obs_shape]
+    int64_t *fin_index = nullptr;  // [n_segments * fin_cap]: step-in-call * n_envs + env
+    int64_t fin_cap = 0;           // rows per segment
+    int32_t *fin_count = nullptr;  // [n_segments]: rows the last rollout delivered for the segment (may exceed fin_cap: the surplus was dropped)
 
     int fail(int status, const char *what, hipError_t e = hipSuccess) {
         char buf[512];
@@ -48,6 +53,23 @@ struct DeviceGuard {
         if (switched) (void)hipSetDevice(prev);
     }
 };
+
+// shared body of cge_<env>_rollout_final_obs
+template <class H>
+int register_final_obs(H *h, void *rows, int64_t *index, int64_t seg_capacity, int32_t *count, const char *who) {
+    if (!h) return CGE_ERR_INVALID_ARG;
+    if ((rows || index || count) && (!rows || !index || !count || seg_capacity <= 0)) return h->fail(CGE_ERR_INVALID_ARG, who);
+    h->fin_rows = rows; h->fin_index = index; h->fin_cap = rows ? seg_capacity : 0; h->fin_count = count;
+    return CGE_OK;
+}
+
+// the two entry points every env type exports for it (inside extern "C"); SEG = envs per segment = envs one wave steps
+#define CGE_DEFINE_FINAL_OBS(ENV, ROWTYPE, SEG)                                                                                          \
+    int cge_##ENV##_rollout_final_obs(cge_##ENV *h, ROWTYPE *rows_out, int64_t *index_out, int64_t seg_capacity, int32_t *count_out) {   \
+        return cge::register_final_obs(h, rows_out, index_out, seg_capacity, count_out,                                                  \
+                                       "cge_" #ENV "_rollout_final_obs: rows, index and count go together (all NULL unregisters)");      \
+    }                                                                                                                                    \
+    int64_t cge_##ENV##_final_obs_segment(const cge_##ENV *h) { return h ? (SEG) : 0; }
 
 #define CGE_TRY(h, expr)                                                   \
     do {                                                                   \

@@ -32,6 +32,7 @@ struct Params {
     const uint64_t *seeds;
     uint64_t base_seed;
     float *obs, *final_obs, *reward;
+    FinalSeg fin;          // fused rollouts (SAME_STEP): terminal rows compacted per wave (cge_climate_rollout_final_obs); rows nullable
     uint8_t *terminated, *truncated;
     int32_t k_steps;
     uint64_t a_seed;
@@ -121,7 +122,7 @@ __device__ __forceinline__ bool env_step(Env &e, int32_t max_occ, int32_t max_st
     return e.step >= (uint32_t)max_steps;
 }
 
-__device__ __forceinline__ void observe(const Env &e, int64_t nrows, float *__restrict__ dst, unsigned long long rowmask, uint32_t *__restrict__ tile) {
+__device__ __forceinline__ void observe(const Env &e, const RowMap &rm, float *__restrict__ dst, uint32_t *__restrict__ tile) {
     const uint32_t lane = threadIdx.x & 63u;
     float *row = reinterpret_cast<float *>(tile) + lane * OBS;                           // env.py:74-83
     row[0] = (float)e.room; row[1] = (float)e.people; row[2] = (float)((double)(e.step % 1440u) / 60.0);
@@ -132,7 +133,8 @@ __device__ __forceinline__ void observe(const Env &e, int64_t nrows, float *__re
     uint32_t r = lane / (uint32_t)OBS, col = lane - r * (uint32_t)OBS;
 #pragma unroll 1
     for (int m = 0; m < OBS; ++m) {
-        if ((int64_t)r < nrows && ((rowmask >> r) & 1ull)) reinterpret_cast<uint32_t *>(dst)[(int64_t)r * OBS + col] = tile[r * OBS + col];
+        int64_t to;
+        if (rm.row(r, to)) reinterpret_cast<uint32_t *>(dst)[to * OBS + col] = tile[r * OBS + col];
         col += 64u % OBS; r += 64u / OBS;
         if (col >= (uint32_t)OBS) { col -= OBS; r += 1u; }
     }
@@ -152,6 +154,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
     const uint64_t key = ROLLOUT ? hash_env_key(p.a_seed, (uint64_t)(p.env0 + li)) : 0;
     double rsum = 0.0;
     int32_t dcount = 0;
+    uint32_t fin_used = 0;                                         // terminal rows this wave has delivered to its segment (fused rollouts)
     const int ksteps = ROLLOUT ? p.k_steps : 1;
 #pragma unroll 1
     for (int t = 0; t < ksteps; ++t) {
@@ -184,10 +187,20 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
                 }
             }
         }
-        const unsigned long long fin_mask = __ballot(live && term && reset_now);
-        if (fin_mask && p.final_obs) observe(e, nrows, p.final_obs + i0 * OBS, fin_mask, tile);
+        const bool fin = live && term && reset_now;
+        const unsigned long long fin_mask = __ballot(fin);
+        if (fin_mask) {                                            // terminal rows: step() -> final_obs_out; fused rollout -> the wave's segment
+            if (!ROLLOUT) {
+                if (p.final_obs) observe(e, RowMap{fin_mask, nrows, 0, false}, p.final_obs + i0 * OBS, tile);
+            } else if (p.fin.rows) {
+                float *fdst;
+                const RowMap rm = final_rows<float>(p.fin, (int64_t)blockIdx.x, fin_used, fin, fin_mask, nrows, t, i, OBS, fdst);
+                observe(e, rm, fdst, tile);
+            }
+            fin_used += (uint32_t)__popcll(fin_mask);
+        }
         if (reset_now) do_reset(e, p.max_occ);
-        if (p.obs) observe(e, nrows, p.obs + (int64_t)t * p.obs_step_stride + i0 * OBS, ~0ull, tile);
+        if (p.obs) observe(e, RowMap{~0ull, nrows, 0, false}, p.obs + (int64_t)t * p.obs_step_stride + i0 * OBS, tile);
         if (live) {
             if (ROLLOUT) {
                 rsum += reward;
@@ -205,6 +218,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
         e.store(p.state, p.n, i);
         if (ROLLOUT) {
             if (p.reward_sum) p.reward_sum[i] = rsum;
+            if (p.fin.count && threadIdx.x == 0) p.fin.count[blockIdx.x] = (int32_t)fin_used;
             if (p.done_count) p.done_count[i] = dcount;
         }
     }
@@ -228,7 +242,7 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(Params p, int what) {
             e.store(p.state, p.n, i);
         }
     }
-    if (what == 0 && p.obs) observe(e, nrows, p.obs + i0 * OBS, ~0ull, tile);
+    if (what == 0 && p.obs) observe(e, RowMap{~0ull, nrows, 0, false}, p.obs + i0 * OBS, tile);
 }
 
 __global__ __launch_bounds__(256) void info_kernel(const uint4 *__restrict__ state, int64_t n, int field, double *__restrict__ out) {
@@ -365,11 +379,14 @@ int cge_climate_rollout(cge_climate *h, int32_t k_steps, const float *ac_temp, c
     climate::Params p = h->params();
     p.k_steps = k_steps; p.ac = ac_temp; p.lights = lights; p.a_seed = action_seed; p.t0 = t0; p.obs = obs_out; p.obs_step_stride = obs_step_stride;
     p.reward = reward_traj_out; p.terminated = terminated_traj_out; p.reward_sum = reward_sum_out; p.done_count = done_count_out;
+    p.fin = FinalSeg{h->fin_rows, h->fin_index, h->fin_count, h->fin_cap, h->n};
     hipLaunchKernelGGL(climate::step_kernel<true>, dim3(h->blocks()), dim3(climate::BLOCK), 0, as_stream(stream), p);
     h->last_kernel = "cge::climate::step_kernel<true>";
     CGE_TRY(h, hipGetLastError());
     return CGE_OK;
 }
+
+CGE_DEFINE_FINAL_OBS(climate, float, 64)
 
 int cge_climate_info(cge_climate *h, int32_t field_id, double *out, void *stream) {
     if (!h || !out || field_id < 0 || field_id > CGE_CLIMATE_INFO_NEEDS_RESET) return CGE_ERR_INVALID_ARG;

@@ -61,6 +61,7 @@ struct Params {
     const void *actions;
     const uint8_t *mask;
     float *obs, *final_obs;
+    FinalSeg fin;          // fused rollouts (SAME_STEP): terminal rows compacted per workgroup of 64 envs (cge_crypto_rollout_final_obs); rows nullable
     float *reward;
     uint8_t *terminated, *truncated;
     int32_t k_steps;
@@ -580,7 +581,8 @@ __device__ __forceinline__ void features_resident(const Env &e, const Params &p,
 // whose mailbox word has all bits of `need` and a destination are written (to obs only if to_obs_only).  flagsv: the workgroup's
 // mailbox words; closes: its current closes; inv: 64 doubles of scratch for 1 / close; base_*: row 0 of the workgroup (or null).
 __device__ __forceinline__ void ratio_rows_resident(const HistLds &hist, int oldest, const uint32_t *flagsv, const double *closes, double *inv_lds,
-                                                    uint32_t need, float *base_obs, float *base_final, bool to_obs_only, int env_lo, int env_hi) {
+                                                    uint32_t need, float *base_obs, float *base_final, bool to_obs_only, int env_lo, int env_hi,
+                                                    bool final_compact = false) {
     const uint32_t lane = hist.lane;
     inv_lds[lane] = 1.0 / closes[lane];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -596,6 +598,9 @@ __device__ __forceinline__ void ratio_rows_resident(const HistLds &hist, int old
         const uint32_t dest = to_obs_only ? DEST_OBS : (f >> 2) & 3u;
         float *base = dest == DEST_FINAL ? base_final : base_obs;
         const bool want = in && (f & need) == need && dest != DEST_NONE && base != nullptr;
+        // a terminal row: row e2 of the workgroup's block of final_obs_out (step()), or — fused rollouts — the slot wave A assigned it in
+        // the workgroup's segment of the compacted side output (bits 8.. of its mailbox word)
+        const uint32_t drow = (dest == DEST_FINAL && final_compact) ? f >> 8 : e2;
         int slot = oldest + (int)c2;
         slot -= slot >= HLEN ? HLEN : 0;
         const double x = hist.lcb[HistLds::at(slot, e2)];
@@ -603,7 +608,7 @@ __device__ __forceinline__ void ratio_rows_resident(const HistLds &hist, int old
         const double inv = inv_lds[e2];
         const float v[5] = {(float)((double)o.x * inv), (float)((double)o.y * inv), (float)((double)o.z * inv), (float)(x * inv), (float)((double)o.w * inv)};
         if (want) {
-            float *dstp = base + (int64_t)e2 * OBS + 5u * c2;
+            float *dstp = base + (int64_t)drow * OBS + 5u * c2;
             *reinterpret_cast<Piece16 *>(dstp) = Piece16{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
             dstp[4] = v[4];
         }
@@ -726,8 +731,8 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
             if (role == 2u) { t_last = wall_clock64(); }
 #endif
             float *base_obs = p.obs ? p.obs + (int64_t)t * p.obs_step_stride + i0 * OBS : nullptr;
-            float *base_final = p.final_obs ? p.final_obs + i0 * OBS : nullptr;
-            ratio_rows_resident(hist, next_phase, mailu - lane, mail - lane + 192, inv_scratch, 0u, base_obs, base_final, false, env_lo, env_hi);
+            float *base_final = p.fin.rows ? static_cast<float *>(p.fin.rows) + (int64_t)blockIdx.x * p.fin.cap * OBS : (p.final_obs ? p.final_obs + i0 * OBS : nullptr);
+            ratio_rows_resident(hist, next_phase, mailu - lane, mail - lane + 192, inv_scratch, 0u, base_obs, base_final, false, env_lo, env_hi, p.fin.rows != nullptr);
 #ifdef CGE_CRYPTO_TIMING
             if (role == 2u) { TICK(6); }
 #endif
@@ -771,7 +776,8 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
             v.cash = mail[0]; v.holdings = mail[64]; v.psych = mail[128]; v.close = mail[192]; v.cash_kind = u & 3u;
             const uint32_t dest = (u >> 2) & 3u;
             float *obs_row = p.obs ? p.obs + (int64_t)t * p.obs_step_stride + li * OBS : nullptr;
-            float *row = dest == DEST_FINAL ? p.final_obs + li * OBS : obs_row;
+            float *row = dest != DEST_FINAL ? obs_row
+                         : p.fin.rows ? static_cast<float *>(p.fin.rows) + ((int64_t)blockIdx.x * p.fin.cap + (u >> 8)) * OBS : p.final_obs + li * OBS;
             const bool want = dest != DEST_NONE && row != nullptr;
             if (__ballot(want)) features_resident(v, p, hist, next_phase, want ? row : obs_row, want);
             TICK(5);
@@ -808,6 +814,7 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
     const uint64_t key = hash_env_key(p.a_seed, (uint64_t)(p.env0 + li));
     double rsum = 0.0;
     int32_t dcount = 0;
+    uint32_t fin_used = 0;                                      // terminal rows this workgroup has delivered to its segment (fused rollouts)
 #pragma unroll 1
     for (int t = 0; t < p.k_steps; ++t) {
         double reward = 0.0;
@@ -854,11 +861,18 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
         const unsigned long long rm = __ballot(reset_now);
         // rows of this step: a SAME_STEP terminal row goes to final_obs (and the reset row to obs afterwards), a NEXT_STEP
         // reset-only row only exists after the reset
-        const uint32_t dest = !live ? DEST_NONE : (term && reset_now) ? (p.final_obs ? DEST_FINAL : DEST_NONE) : reset_now ? DEST_NONE : DEST_OBS;
+        // (fused rollouts: the terminal rows of the workgroup's envs take the next slots of its segment of the compacted side output)
+        const bool fin = live && term && reset_now;
+        const unsigned long long fm = __ballot(fin);
+        const uint32_t fslot = fin_used + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull));
+        const bool fin_ok = p.fin.rows ? (int64_t)fslot < p.fin.cap : p.final_obs != nullptr;
+        if (fin && p.fin.rows && fin_ok) p.fin.index[(int64_t)blockIdx.x * p.fin.cap + fslot] = (int64_t)t * p.n + i;
+        fin_used += (uint32_t)__popcll(fm);
+        const uint32_t dest = !live ? DEST_NONE : fin ? (fin_ok ? DEST_FINAL : DEST_NONE) : reset_now ? DEST_NONE : DEST_OBS;
         // does this lane step at t+1 (then wave C draws its gaussian now)?  not when the step is a NEXT_STEP reset-only one
         const bool steps_next = live && !(p.mode == CGE_AUTORESET_NEXT_STEP && e.needs_reset && !reset_now);
         mail[0] = e.cash; mail[64] = e.holdings; mail[128] = e.psych; mail[192] = e.close;
-        *mailu = e.cash_kind | (dest << 2) | (reset_now ? F_RESET : 0u) | (steps_next ? F_DRAW_NEXT : 0u);
+        *mailu = e.cash_kind | (dest << 2) | (reset_now ? F_RESET : 0u) | (steps_next ? F_DRAW_NEXT : 0u) | ((fin && p.fin.rows ? fslot : 0u) << 8);
         if (lane == 0) *waveflag = rm ? 1u : 0u;
         lds_barrier();                                          // bar2: window(t) is complete
         TICK(2);
@@ -903,6 +917,7 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
         e.store(p.scal, p.n, i);
         if (p.reward_sum) p.reward_sum[i] = rsum;
         if (p.done_count) p.done_count[i] = dcount;
+        if (p.fin.count && lane == 0) p.fin.count[blockIdx.x] = (int32_t)fin_used;
     }
 }
 
@@ -1120,10 +1135,13 @@ int cge_crypto_rollout(cge_crypto *h, int32_t k_steps, const void *actions, uint
     crypto::Params p = h->params();
     p.k_steps = k_steps; p.actions = actions; p.a_seed = action_seed; p.t0 = t0; p.obs = obs_out; p.obs_step_stride = obs_step_stride;
     p.reward = reward_traj_out; p.terminated = terminated_traj_out; p.reward_sum = reward_sum_out; p.done_count = done_count_out;
+    p.fin = FinalSeg{h->fin_rows, h->fin_index, h->fin_count, h->fin_cap, h->n};
     CGE_TRY(h, launch_resident(h, p, as_stream(stream), false));
     h->phase = (h->phase + k_steps) % crypto::HLEN;
     return CGE_OK;
 }
+
+CGE_DEFINE_FINAL_OBS(crypto, float, 64)
 
 int cge_crypto_info(cge_crypto *h, int32_t field_id, double *out, void *stream) {
     if (!h) return CGE_ERR_INVALID_ARG;

@@ -45,6 +45,7 @@ struct Params {
     const int32_t *actions;
     const uint8_t *mask;
     float *obs, *final_obs, *reward;
+    FinalSeg fin;          // rollouts (SAME_STEP): terminal rows compacted per segment of 64 envs (cge_fleet_rollout_final_obs); rows nullable
     uint8_t *terminated, *truncated;
     int32_t k_steps;
     uint64_t a_seed;
@@ -460,7 +461,11 @@ __device__ __forceinline__ void lane_step(const Params &p, Env &e, int64_t i, ui
     e.pending = work ? 1u : 0u;
     e.seq = (e.seq + 1u) & 15u;
     if (work) {
-        const uint32_t sub = wave_id % (uint32_t)NSUB;
+        // the sub-list follows from the ENV (the block that owns it), not from whoever steps it: a pipelined dense launch steps envs of any
+        // block, and filing them under its own block index let a sub-list receive more than its sub_cap = ceil(blocks / 64) * 64 entries
+        // (a NextStep mass reset re-lists every env while step blocks append to the same lists)
+        (void)wave_id;
+        const uint32_t sub = (uint32_t)(i / BLOCK) % (uint32_t)NSUB;
         const uint32_t slot = atomicAdd(work_counter(p.work_count, p.parity, sub), 1u);
         work_sublist(p, p.parity, sub)[slot] = work_entry(i, work, e.lpos, e.lpretw, e.ppos, e.ppretw);
     }
@@ -532,7 +537,7 @@ __global__ __launch_bounds__(BLOCK) void dense_kernel(Params p, int what) {
 #endif
     __shared__ uint32_t tile[DL * ROW];
     __shared__ uint32_t drawsP[DL * PROW], drawsL[DL * LROW];
-    __shared__ int64_t row_env[DL];
+    __shared__ int64_t row_env[DL], row_fin[DL];
     __shared__ uint32_t traffic_acc[2 * DL];
     const uint32_t lane = threadIdx.x & 63u;
     // lane s holds sub-list s's entry count and the running total up to and including it
@@ -609,7 +614,20 @@ __global__ __launch_bounds__(BLOCK) void dense_kernel(Params p, int what) {
         TICK(3);
         if (lane < (uint32_t)DL) row_env[lane] = live ? i : -1;
         const int nlive = (int)(count - first < (uint32_t)DL ? count - first : (uint32_t)DL);
-        const bool fin = what == 0 && (work & W_RESET) && p.mode == CGE_AUTORESET_SAME_STEP && p.final_obs;
+        // terminal rows: step() -> row env of final_obs_out; rollout -> the next slot of the env's 64-env segment of the compacted side
+        // output.  This kernel serves work-list entries, not contiguous envs, and a rollout is one launch per step, so the segment's
+        // fill count lives in memory (zeroed by cge_fleet_rollout): one returning atomic per finishing env, a handful per segment and step
+        const bool fin = what == 0 && (work & W_RESET) && p.mode == CGE_AUTORESET_SAME_STEP && (p.final_obs || p.fin.rows);
+        if (lane < (uint32_t)DL) {
+            int64_t to = live ? i : -1;
+            if (p.fin.rows && fin && live) {
+                const int64_t seg = i >> 6;
+                const int32_t slot = atomicAdd(p.fin.count + seg, 1);
+                to = -1;
+                if ((int64_t)slot < p.fin.cap) { to = seg * p.fin.cap + slot; p.fin.index[to] = t_row * p.fin.n + i; }
+            }
+            row_fin[lane] = to;
+        }
 #pragma unroll 1
         for (int pass = 0; pass < 2; ++pass) {
             // pass 0: terminal obs (after the redraws) of the envs that finished -> final_obs; pass 1: reset, then obs
@@ -620,7 +638,8 @@ __global__ __launch_bounds__(BLOCK) void dense_kernel(Params p, int what) {
                 coop_update_traffic(e, L, (work & W_RESET) != 0, drawsL, traffic_acc);
             }
             if (pass == 1) TICK(5);
-            float *dst = pass == 0 ? p.final_obs : (p.obs ? p.obs + t_row * p.obs_step_stride : nullptr);
+            float *dst = pass == 0 ? (p.fin.rows ? static_cast<float *>(p.fin.rows) : p.final_obs) : (p.obs ? p.obs + t_row * p.obs_step_stride : nullptr);
+            const int64_t *rows_to = pass == 0 ? row_fin : row_env;
             const unsigned long long m = __ballot(want);
             if (!m || !dst) continue;
             if (PIPE && pass == 1 && p.obs_step_stride == 0) continue;   // rows in place: this launch's own step rewrites them below
@@ -628,8 +647,8 @@ __global__ __launch_bounds__(BLOCK) void dense_kernel(Params p, int what) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll 1
             for (int r = 0; r < nlive; ++r) {                  // each listed env's 304-byte row: two 64-lane stores
-                if (!((m >> r) & 1ull)) continue;
-                uint32_t *drow = reinterpret_cast<uint32_t *>(dst + row_env[r] * OBS);
+                if (!((m >> r) & 1ull) || rows_to[r] < 0) continue;
+                uint32_t *drow = reinterpret_cast<uint32_t *>(dst + rows_to[r] * OBS);
                 drow[lane] = tile[r * ROW + lane];
                 if (lane < (uint32_t)(OBS - 64)) drow[64 + lane] = tile[r * ROW + 64 + lane];
             }
@@ -883,11 +902,15 @@ int cge_fleet_rollout(cge_fleet *h, int32_t k_steps, const int32_t *actions, uin
     p.k_steps = k_steps; p.actions = actions; p.a_seed = action_seed; p.t0 = t0; p.obs = obs_out; p.obs_step_stride = obs_step_stride;
     p.reward = reward_traj_out; p.terminated = terminated_traj_out; p.reward_sum = reward_sum_out; p.done_count = done_count_out;
     p.accumulate = 1;
+    p.fin = FinalSeg{h->fin_rows, h->fin_index, h->fin_count, h->fin_cap, h->n};
+    if (h->fin_count) CGE_TRY(h, hipMemsetAsync(h->fin_count, 0, (size_t)((h->n + 63) / 64) * sizeof(int32_t), as_stream(stream)));
     if (reward_sum_out) CGE_TRY(h, hipMemsetAsync(reward_sum_out, 0, (size_t)h->n * sizeof(double), as_stream(stream)));
     if (done_count_out) CGE_TRY(h, hipMemsetAsync(done_count_out, 0, (size_t)h->n * sizeof(int32_t), as_stream(stream)));
     CGE_TRY(h, h->launch_rollout(p, k_steps, as_stream(stream)));
     return CGE_OK;
 }
+
+CGE_DEFINE_FINAL_OBS(fleet, float, 64)
 
 int cge_fleet_info(cge_fleet *h, int32_t field_id, double *out, void *stream) {
     if (!h || !out || field_id < 0 || field_id > CGE_FLEET_INFO_FUEL2) return CGE_ERR_INVALID_ARG;

@@ -66,6 +66,7 @@ struct Params {
     float *reward;
     uint8_t *terminated, *truncated;
     float *final_obs;
+    FinalSeg fin;          // fused rollouts (SAME_STEP): terminal rows compacted per wave (cge_hospital_rollout_final_obs); rows nullable
     const uint8_t *mask;
     double *reward_sum;
     int32_t *done_count;
@@ -497,7 +498,8 @@ struct StepOut {
 };
 
 // obs_row: this env's row of the obs output (null: no observation wanted)
-__device__ __forceinline__ void wave_step(const Params &p, int64_t i, bool live, int32_t action, Misc &m, Draws &D, float *obs_row, StepOut &out) {
+__device__ __forceinline__ void wave_step(const Params &p, int64_t i, bool live, int32_t action, Misc &m, Draws &D, float *obs_row, StepOut &out,
+                                          int64_t t = 0, uint32_t fin_used = 0) {
     const Ring rg{reinterpret_cast<uint2 *>(p.ring) + i * RING};
     const bool reset_only = live && p.mode == CGE_AUTORESET_NEXT_STEP && m.needs_reset;
     const bool run = live && !reset_only;
@@ -622,7 +624,14 @@ __device__ __forceinline__ void wave_step(const Params &p, int64_t i, bool live,
         done = flags != 0u;
         my_dst = obs_row;
         if (done && p.mode == CGE_AUTORESET_SAME_STEP) {
-            my_dst = p.final_obs ? p.final_obs + i * OBS : nullptr;
+            // step(): row i of final_obs_out; fused rollout: the next slots of the wave's segment of the compacted side output (the lanes
+            // that are in here together rank themselves by a ballot, cge_device.hpp: final_slot)
+            if (p.fin.rows) {
+                const int64_t gs = final_slot(p.fin, (int64_t)blockIdx.x, fin_used, true, t, i);
+                my_dst = gs >= 0 ? static_cast<float *>(p.fin.rows) + gs * OBS : nullptr;
+            } else {
+                my_dst = p.final_obs ? p.final_obs + i * OBS : nullptr;
+            }
             if (my_dst) {
                 Doctors dc;
                 Beds bd;
@@ -794,6 +803,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
     const uint64_t key = ROLLOUT ? hash_env_key(p.a_seed, (uint64_t)(p.env0 + li)) : 0;
     double rsum = 0.0;
     int32_t dcount = 0;
+    uint32_t fin_used = 0;                                     // terminal rows this wave has delivered to its segment (fused rollouts)
     const int ksteps = ROLLOUT ? p.k_steps : 1;
 #pragma unroll 1
     for (int t = 0; t < ksteps; ++t) {
@@ -802,7 +812,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
         float *obs_row = (p.obs && live) ? p.obs + (int64_t)t * p.obs_step_stride + i * OBS : nullptr;
         int64_t lt = li;
         if (ROLLOUT) asm volatile("" : "+v"(lt));              // opaque per iteration: keeps the 48 column addresses from being hoisted out of the t loop (+72 VGPRs)
-        wave_step(p, lt, live, a, m, D, obs_row, o);
+        wave_step(p, lt, live, a, m, D, obs_row, o, t, fin_used);
+        if (ROLLOUT && p.mode == CGE_AUTORESET_SAME_STEP) fin_used += (uint32_t)__popcll(__ballot(live && o.flags != 0u));
         if (live) {
             if (ROLLOUT) {
                 rsum += (double)o.reward;
@@ -824,6 +835,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
         if (ROLLOUT) {
             if (p.reward_sum) p.reward_sum[i] = rsum;
             if (p.done_count) p.done_count[i] = dcount;
+            if (p.fin.count && threadIdx.x == 0) p.fin.count[blockIdx.x] = (int32_t)fin_used;
         }
     }
 }
@@ -1061,11 +1073,14 @@ int cge_hospital_rollout(cge_hospital *h, int32_t k_steps, const int32_t *action
     hosp::Params p = h->params();
     p.k_steps = k_steps; p.actions = actions; p.a_seed = action_seed; p.t0 = t0; p.obs = obs_out; p.obs_step_stride = obs_step_stride;
     p.reward = reward_traj_out; p.terminated = terminated_traj_out; p.reward_sum = reward_sum_out; p.done_count = done_count_out;
+    p.fin = FinalSeg{h->fin_rows, h->fin_index, h->fin_count, h->fin_cap, h->n};
     hipLaunchKernelGGL(hosp::step_kernel<true>, dim3(h->blocks()), dim3(hosp::BLOCK), 0, as_stream(stream), p);
     h->last_kernel = "cge::hosp::step_kernel<true>";
     CGE_TRY(h, hipGetLastError());
     return CGE_OK;
 }
+
+CGE_DEFINE_FINAL_OBS(hospital, float, 64)
 
 int cge_hospital_info(cge_hospital *h, int32_t field_id, double *out, void *stream) {
     if (!h || !out || field_id < 0 || field_id > CGE_HOSPITAL_INFO_OVERFLOW) return CGE_ERR_INVALID_ARG;

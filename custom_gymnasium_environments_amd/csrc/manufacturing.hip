@@ -60,6 +60,7 @@ struct Params {
     float *reward;
     uint8_t *terminated, *truncated;
     float *final_obs;
+    FinalSeg fin;          // fused rollouts (SAME_STEP): terminal rows compacted per wave (cge_manufacturing_rollout_final_obs); rows nullable
     const uint8_t *mask;
     const uint64_t *seeds;
     uint64_t base_seed;
@@ -633,10 +634,10 @@ __device__ __forceinline__ void stage_row(const Env &e, const double (&mean)[6],
     row[56] = (float)e.raw;
 }
 
-__device__ __forceinline__ void store_rows(int64_t nrows, float *__restrict__ dst, unsigned long long rowmask, const uint32_t *__restrict__ tile) {
+__device__ __forceinline__ void store_rows(const RowMap &rm, float *__restrict__ dst, const uint32_t *__restrict__ tile) {
     const uint32_t lane = threadIdx.x & 63u;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (nrows == 64 && rowmask == ~0ull && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0u) {
+    if (rm.nrows == 64 && rm.mask == ~0ull && !rm.compact && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0u) {
         // the wave's 64 rows are one contiguous 18,688-byte image, in LDS as in the destination: 1168 16-byte pieces
 #pragma unroll 5
         for (uint32_t k = lane; k < (uint32_t)(64 * OBS / 4); k += 64u) reinterpret_cast<uint4 *>(dst)[k] = reinterpret_cast<const uint4 *>(tile)[k];
@@ -644,7 +645,8 @@ __device__ __forceinline__ void store_rows(int64_t nrows, float *__restrict__ ds
         uint32_t r = 0, col = lane;                             // OBS = 73 > 64: lane walks the tile linearly
 #pragma unroll 1
         for (int m = 0; m < OBS; ++m) {
-            if ((int64_t)r < nrows && ((rowmask >> r) & 1ull)) reinterpret_cast<uint32_t *>(dst)[(int64_t)r * OBS + col] = tile[r * OBS + col];
+            int64_t to;
+            if (rm.row(r, to)) reinterpret_cast<uint32_t *>(dst)[to * OBS + col] = tile[r * OBS + col];
             col += 64u;
             if (col >= (uint32_t)OBS) { col -= OBS; r += 1u; }
         }
@@ -674,6 +676,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     const uint64_t key = ROLLOUT ? hash_env_key(p.a_seed, (uint64_t)(p.env0 + li)) : 0;
     double rsum = 0.0;
     int32_t dcount = 0;
+    uint32_t fin_used = 0;                                     // terminal rows this wave has delivered to its segment (fused rollouts)
     const int ksteps = ROLLOUT ? p.k_steps : 1;
 #ifdef CGE_MFG_TIMING
     unsigned long long t_last = wall_clock64();
@@ -701,22 +704,33 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             }
         }
         const bool want_obs = p.obs != nullptr;                // a rollout writes the obs of every step (stride 0: in place)
-        const unsigned long long fin_mask = __ballot(reset_now);
-        if (want_obs || (fin_mask && p.final_obs)) {
+        // terminal rows: step() -> final_obs_out (SAME_STEP); fused rollout -> the wave's segment of the compacted side output
+        const bool fin = live && flags && reset_now;
+        const unsigned long long fin_mask = __ballot(ROLLOUT ? fin : reset_now);
+        const bool want_fin = fin_mask && (ROLLOUT ? p.fin.rows != nullptr : p.final_obs != nullptr);
+        if (want_obs || want_fin) {
             double mean[6];
             type_means(e, tb, live, mean);
             TICK(2);
-            if (fin_mask && p.final_obs) {
+            if (want_fin) {
                 stage_row(e, mean, reinterpret_cast<float *>(tile) + lane * OBS);
-                store_rows(nrows, p.final_obs + i0 * OBS, fin_mask, tile);
+                if (!ROLLOUT) {
+                    store_rows(RowMap{fin_mask, nrows, 0, false}, p.final_obs + i0 * OBS, tile);
+                } else {
+                    float *fdst;
+                    const RowMap rm = final_rows<float>(p.fin, (int64_t)blockIdx.x, fin_used, fin, fin_mask, nrows, t, i, OBS, fdst);
+                    store_rows(rm, fdst, tile);
+                }
             }
+            if (ROLLOUT) fin_used += (uint32_t)__popcll(fin_mask);
             if (reset_now) do_reset(e);                        // fresh episode: nothing in the system, means default to 85
             if (want_obs) {
                 stage_row(e, mean, reinterpret_cast<float *>(tile) + lane * OBS);
-                store_rows(nrows, p.obs + (int64_t)t * p.obs_step_stride + i0 * OBS, ~0ull, tile);
+                store_rows(RowMap{~0ull, nrows, 0, false}, p.obs + (int64_t)t * p.obs_step_stride + i0 * OBS, tile);
             }
-        } else if (reset_now) {
-            do_reset(e);
+        } else {
+            if (ROLLOUT) fin_used += (uint32_t)__popcll(fin_mask);     // (no side output registered: the count still says what was dropped)
+            if (reset_now) do_reset(e);
         }
         TICK(3);
 #ifdef CGE_MFG_TIMING
@@ -740,6 +754,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         e.store(p.state, p.n, i);
         if (ROLLOUT) {
             if (p.reward_sum) p.reward_sum[i] = rsum;
+            if (p.fin.count && threadIdx.x == 0) p.fin.count[blockIdx.x] = (int32_t)fin_used;
             if (p.done_count) p.done_count[i] = dcount;
         }
     }
@@ -775,7 +790,7 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(Params p, int what) {
         double mean[6];
         type_means(e, tb, live, mean);
         stage_row(e, mean, reinterpret_cast<float *>(tile) + lane * OBS);
-        store_rows(nrows, p.obs + i0 * OBS, ~0ull, tile);
+        store_rows(RowMap{~0ull, nrows, 0, false}, p.obs + i0 * OBS, tile);
     }
 }
 
@@ -810,6 +825,7 @@ __global__ __launch_bounds__(256) void info_kernel(const uint4 *__restrict__ sta
         case CGE_MANUFACTURING_INFO_EPISODES: v = e.episodes; break;
         case CGE_MANUFACTURING_INFO_NEEDS_RESET: v = e.needs_reset; break;
         case CGE_MANUFACTURING_INFO_OVERFLOW: v = e.overflow; break;
+        default: if (field >= CGE_MANUFACTURING_INFO_COMPLETED_TYPE0 && field < CGE_MANUFACTURING_INFO_COMPLETED_TYPE0 + 6) v = fld9(e.completed, field - CGE_MANUFACTURING_INFO_COMPLETED_TYPE0);
     }
     out[i] = v;
 }
@@ -947,14 +963,17 @@ int cge_manufacturing_rollout(cge_manufacturing *h, int32_t k_steps, const int32
     mfg::Params p = h->params();
     p.k_steps = k_steps; p.actions = actions; p.a_seed = action_seed; p.t0 = t0; p.obs = obs_out; p.obs_step_stride = obs_step_stride;
     p.reward = reward_traj_out; p.terminated = terminated_traj_out; p.reward_sum = reward_sum_out; p.done_count = done_count_out;
+    p.fin = FinalSeg{h->fin_rows, h->fin_index, h->fin_count, h->fin_cap, h->n};
     hipLaunchKernelGGL(mfg::step_kernel<true>, dim3(h->blocks()), dim3(mfg::BLOCK), 0, as_stream(stream), p);
     h->last_kernel = "cge::mfg::step_kernel<true>";
     CGE_TRY(h, hipGetLastError());
     return CGE_OK;
 }
 
+CGE_DEFINE_FINAL_OBS(manufacturing, float, 64)
+
 int cge_manufacturing_info(cge_manufacturing *h, int32_t field_id, double *out, void *stream) {
-    if (!h || !out || field_id < 0 || field_id > CGE_MANUFACTURING_INFO_OVERFLOW) return CGE_ERR_INVALID_ARG;
+    if (!h || !out || field_id < 0 || field_id > CGE_MANUFACTURING_INFO_COMPLETED_TYPE0 + 5) return CGE_ERR_INVALID_ARG;
     DeviceGuard g(h->device);
     hipLaunchKernelGGL(mfg::info_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, as_stream(stream), h->state, h->n, field_id, out);
     CGE_TRY(h, hipGetLastError());

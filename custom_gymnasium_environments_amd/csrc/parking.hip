@@ -44,6 +44,7 @@ struct Params {
     const int32_t *actions;
     const uint8_t *mask;
     float *obs, *final_obs, *reward;
+    FinalSeg fin;          // fused rollouts (SAME_STEP): terminal rows compacted per wave (cge_parking_rollout_final_obs); rows nullable
     uint8_t *terminated, *truncated;
     int32_t k_steps;
     uint64_t a_seed;
@@ -282,8 +283,7 @@ __device__ __forceinline__ bool env_step(Env &e, int32_t max_steps, int32_t a, L
 }
 
 // _get_observation :306-369 -> 13 float32 staged [64][13] in LDS, then coalesced
-__device__ __forceinline__ void observe(const Env &e, int64_t nrows, float *__restrict__ dst, unsigned long long rowmask,
-                                        uint32_t *__restrict__ tile) {
+__device__ __forceinline__ void observe(const Env &e, const RowMap &rm, float *__restrict__ dst, uint32_t *__restrict__ tile) {
     const uint32_t lane = threadIdx.x & 63u;
     double v[OBS];
     uint32_t occ[3] = {0, 0, 0};
@@ -309,7 +309,8 @@ __device__ __forceinline__ void observe(const Env &e, int64_t nrows, float *__re
     uint32_t r = lane / (uint32_t)OBS, col = lane - r * (uint32_t)OBS;
 #pragma unroll 1
     for (int m = 0; m < OBS; ++m) {
-        if ((int64_t)r < nrows && ((rowmask >> r) & 1ull)) reinterpret_cast<uint32_t *>(dst)[(int64_t)r * OBS + col] = tile[r * OBS + col];
+        int64_t to;
+        if (rm.row(r, to)) reinterpret_cast<uint32_t *>(dst)[to * OBS + col] = tile[r * OBS + col];
         col += 64u % OBS; r += 64u / OBS;
         if (col >= (uint32_t)OBS) { col -= OBS; r += 1u; }
     }
@@ -331,6 +332,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
     const uint64_t key = ROLLOUT ? hash_env_key(p.a_seed, (uint64_t)(p.env0 + li)) : 0;
     double rsum = 0.0;
     int32_t dcount = 0;
+    uint32_t fin_used = 0;                                         // terminal rows this wave has delivered to its segment (fused rollouts)
     const int ksteps = ROLLOUT ? p.k_steps : 1;
 #pragma unroll 1
     for (int t = 0; t < ksteps; ++t) {
@@ -353,10 +355,20 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
                 }
             }
         }
-        const unsigned long long fin_mask = __ballot(live && term && reset_now);
-        if (fin_mask && p.final_obs) observe(e, nrows, p.final_obs + i0 * OBS, fin_mask, tile);
+        const bool fin = live && term && reset_now;
+        const unsigned long long fin_mask = __ballot(fin);
+        if (fin_mask) {                                            // terminal rows: step() -> final_obs_out; fused rollout -> the wave's segment
+            if (!ROLLOUT) {
+                if (p.final_obs) observe(e, RowMap{fin_mask, nrows, 0, false}, p.final_obs + i0 * OBS, tile);
+            } else if (p.fin.rows) {
+                float *fdst;
+                const RowMap rm = final_rows<float>(p.fin, (int64_t)blockIdx.x, fin_used, fin, fin_mask, nrows, t, i, OBS, fdst);
+                observe(e, rm, fdst, tile);
+            }
+            fin_used += (uint32_t)__popcll(fin_mask);
+        }
         if (reset_now) e.reset();
-        if (p.obs) observe(e, nrows, p.obs + (int64_t)t * p.obs_step_stride + i0 * OBS, ~0ull, tile);
+        if (p.obs) observe(e, RowMap{~0ull, nrows, 0, false}, p.obs + (int64_t)t * p.obs_step_stride + i0 * OBS, tile);
         if (live) {
             if (ROLLOUT) {
                 rsum += reward;
@@ -376,6 +388,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
         e.store(p.state, p.n, i);
         if (ROLLOUT) {
             if (p.reward_sum) p.reward_sum[i] = rsum;
+            if (p.fin.count && threadIdx.x == 0) p.fin.count[blockIdx.x] = (int32_t)fin_used;
             if (p.done_count) p.done_count[i] = dcount;
         }
     }
@@ -397,7 +410,7 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(Params p, int init, int re
         if (rewind) { e.mt_pos = 0; e.mt_pretw = 0; dirty = true; }
         if (dirty) e.store(p.state, p.n, i);
     }
-    if (p.obs) observe(e, nrows, p.obs + i0 * OBS, ~0ull, tile);
+    if (p.obs) observe(e, RowMap{~0ull, nrows, 0, false}, p.obs + i0 * OBS, tile);
 }
 
 __global__ __launch_bounds__(256) void info_kernel(const uint4 *__restrict__ state, int64_t n, int field, int idx, int32_t *__restrict__ out,
@@ -541,11 +554,14 @@ int cge_parking_rollout(cge_parking *h, int32_t k_steps, const int32_t *actions,
     parking::Params p = h->params();
     p.k_steps = k_steps; p.actions = actions; p.a_seed = action_seed; p.t0 = t0; p.obs = obs_out; p.obs_step_stride = obs_step_stride;
     p.reward = reward_traj_out; p.terminated = terminated_traj_out; p.reward_sum = reward_sum_out; p.done_count = done_count_out;
+    p.fin = FinalSeg{h->fin_rows, h->fin_index, h->fin_count, h->fin_cap, h->n};
     hipLaunchKernelGGL(parking::step_kernel<true>, dim3(h->blocks()), dim3(parking::BLOCK), 0, as_stream(stream), p);
     h->last_kernel = "cge::parking::step_kernel<true>";
     CGE_TRY(h, hipGetLastError());
     return CGE_OK;
 }
+
+CGE_DEFINE_FINAL_OBS(parking, float, 64)
 
 int cge_parking_info(cge_parking *h, int32_t field_id, int32_t index, int32_t *out, void *stream) {
     if (!h) return CGE_ERR_INVALID_ARG;

@@ -301,6 +301,7 @@ struct Params {
     float *reward;
     uint8_t *terminated, *truncated;
     int8_t *final_obs;
+    FinalSeg fin;             // fused rollouts (SAME_STEP): terminal rows compacted per wave (cge_snake_rollout_final_obs); rows nullable
     int32_t mode, max_steps, k_steps;
     uint32_t dq_topup;    // rollout: rings with fewer digits than this are topped up when the launch starts (host: by k_steps)
     uint64_t a_seed;
@@ -517,17 +518,28 @@ __device__ __forceinline__ void dq_place_food(Env<G> &e, DqCtx<G> &q, bool need)
 
 enum : uint32_t { T_NEED_FOOD = 1u, T_WAS_RESET = 2u, T_DEFERRED = 4u };
 
-// SameStep: the terminal observation of a lane whose episode just ended (rare lanes only: direct row store)
+// SameStep: the terminal observation of a lane whose episode just ended (rare lanes only: direct row store).  step(): row i of
+// final_obs_out; fused rollout: the next slots of the wave's segment of the compacted side output (FinalSeg, cge_device.hpp) — the
+// lanes that are in here together rank themselves by a ballot; fin_base = rows the segment holds before them
 template <int G>
-__device__ __forceinline__ void write_final_obs(const Env<G> &e, const Params &p, int64_t i) {
-    if (!p.final_obs) return;
+__device__ __forceinline__ void write_final_obs(const Env<G> &e, const Params &p, int64_t i, int64_t t = 0, uint32_t fin_base = 0) {
     using L = Lay<G>;
+    int8_t *dst;
+    if (p.fin.rows) {
+        const int64_t gs = final_slot(p.fin, i >> 6, fin_base, true, t, i);
+        if (gs < 0) return;
+        dst = static_cast<int8_t *>(p.fin.rows) + gs * L::CELLS;
+    } else if (p.final_obs) {
+        dst = p.final_obs + i * L::CELLS;
+    } else {
+        return;
+    }
     if constexpr (L::PACKED) {
-        uint32_t *frow = reinterpret_cast<uint32_t *>(p.final_obs + i * L::CELLS);
+        uint32_t *frow = reinterpret_cast<uint32_t *>(dst);
         e.write_obs_body(frow);
         e.write_obs_food(frow);
     } else {                                                   // odd G: rows are not dword aligned and end inside a dword (rare lanes: byte stores)
-        int8_t *frow = p.final_obs + i * L::CELLS;
+        int8_t *frow = dst;
         const bool fv = e.flags & F_FOOD_VALID;
 #pragma unroll 1
         for (uint32_t c = 0; c < (uint32_t)L::CELLS; ++c) frow[c] = (fv && c == e.food) ? 2 : (int8_t)e.occupied(c);
@@ -538,7 +550,8 @@ __device__ __forceinline__ void write_final_obs(const Env<G> &e, const Params &p
 // window load is issued, the obs body is staged while it is in flight, then the food is placed.
 template <int G, int MODE>
 __device__ __forceinline__ uint32_t transition(Env<G> &e, const Params &p, int64_t i, uint32_t action, bool valid_action,
-                                               uint32_t *__restrict__ obs_row, float &reward, bool &term, bool short_wave) {
+                                               uint32_t *__restrict__ obs_row, float &reward, bool &term, bool short_wave, int64_t t = 0,
+                                               uint32_t fin_base = 0) {
     using L = Lay<G>;
     bool need_food = false, was_reset = false, deferred = false;
     reward = 0.0f;
@@ -565,7 +578,7 @@ __device__ __forceinline__ uint32_t transition(Env<G> &e, const Params &p, int64
                     // then writes the terminal obs, resets, and the caller runs a second round.
                     deferred = true;
                 } else {
-                    write_final_obs(e, p, i);
+                    write_final_obs(e, p, i, t, fin_base);
                     e.reset_body();
                     need_food = true; was_reset = true;
                 }
@@ -583,8 +596,9 @@ __device__ __forceinline__ uint32_t transition(Env<G> &e, const Params &p, int64
 // second half of a SameStep episode end whose last step also ate (see transition): terminal obs with the post-eat food, reset.
 // Returns whether the fresh episode needs its food placed (always, unless the board were full).
 template <int G>
-__device__ __forceinline__ bool finish_deferred(Env<G> &e, const Params &p, int64_t i, uint32_t *__restrict__ obs_row) {
-    write_final_obs(e, p, i);
+__device__ __forceinline__ bool finish_deferred(Env<G> &e, const Params &p, int64_t i, uint32_t *__restrict__ obs_row, int64_t t = 0,
+                                                uint32_t fin_base = 0) {
+    write_final_obs(e, p, i, t, fin_base);
     e.reset_body();
     if (obs_row) e.write_obs_body(obs_row);
     return e.can_place_food();
@@ -720,6 +734,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
     uint64_t key = 0;
     float rsum = 0.0f;
     int32_t dcount = 0;
+    uint32_t fin_used = 0;                                     // terminal rows this wave has delivered to its segment of the side output
     // the digit rings of the wave's envs are parked in LDS for the launch; their loads share the env record's round trip
     DqCtx<G> q{qmem + (threadIdx.x & ~63u) * Q::QROW, (uint32_t)Q::QROW, p.mt + li * MT_STRIDE, p.dq, p.n, li, 0u, false};
     uint4 ring[Q::COLS];
@@ -762,9 +777,11 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
             } else {
                 a = hash_action_from_key(key, (uint64_t)(p.t0 + t), 4u, 0u);
             }
-            tf = transition<G, MODE>(e, p, i, a, a <= 3u, nullptr, r, term, short_wave);
+            tf = transition<G, MODE>(e, p, i, a, a <= 3u, nullptr, r, term, short_wave, t, fin_used);
             need_food = tf & T_NEED_FOOD; was_reset = tf & T_WAS_RESET;
         }
+        // terminal rows: the lanes that finished without eating wrote theirs inside transition(); those that also ate follow below
+        const uint32_t fin_deferred = MODE == CGE_AUTORESET_SAME_STEP ? fin_used + (uint32_t)__popcll(__ballot(term && !(tf & T_DEFERRED))) : 0u;
         // one inlined copy of the placement code, run a second time only when some lane ate on the very step its time limit fired
         // (SameStep: post-eat food, then reset, then the fresh episode's food — rare, wave-uniform)
         bool want = need_food;
@@ -772,9 +789,10 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
         for (int round = 0; round < 2; ++round) {
             dq_place_food<G, false>(e, q, want);
             if (round == 1 || __ballot(tf & T_DEFERRED) == 0ull) break;
-            want = (tf & T_DEFERRED) && finish_deferred<G>(e, p, i, nullptr);
+            want = (tf & T_DEFERRED) && finish_deferred<G>(e, p, i, nullptr, t, fin_deferred);
             if (tf & T_DEFERRED) { was_reset = true; need_food = want; }
         }
+        if (MODE == CGE_AUTORESET_SAME_STEP) fin_used += (uint32_t)__popcll(__ballot(term));
         if (row) {
             unsigned long long rm = __ballot(was_reset);
             while (rm) {                                       // wave-uniform: clear the rows of the envs that were reset
@@ -806,6 +824,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
         q.write_back();
         if (p.reward_sum) p.reward_sum[i] = rsum;
         if (p.done_count) p.done_count[i] = dcount;
+        if (p.fin.count && (threadIdx.x & 63u) == 0u) p.fin.count[wfirst >> 6] = (int32_t)fin_used;
     }
 }
 
@@ -1183,6 +1202,7 @@ int cge_snake_rollout(cge_snake *h, int32_t k_steps, const int32_t *actions, uin
     p.obs = obs_out; p.obs_step_stride = obs_step_stride;
     p.reward = reward_traj_out; p.terminated = terminated_traj_out;
     p.reward_sum = reward_sum_out; p.done_count = done_count_out;
+    p.fin = FinalSeg{h->fin_rows, h->fin_index, h->fin_count, h->fin_cap, h->n};
     // Rings that hold less than one placement round are topped up before the launch's first step; everything else is left to
     // the in-loop refill (wave-convergent, ~0.25 / 64 per env-step).  Measured on 1M envs, us per step at k = 20 / 40 / 100 / 200
     // (gpurun_out/r3_ab_topup.txt, one box): threshold 8-16: 26.5-27.8 / 25.2-26.3 / 24.7-25.4 / 23.4-24.8; 32: 28.5-29.3 / 26.9-27.7 /
@@ -1193,6 +1213,8 @@ int cge_snake_rollout(cge_snake *h, int32_t k_steps, const int32_t *actions, uin
     CGE_TRY(h, hipGetLastError());
     return CGE_OK;
 }
+
+CGE_DEFINE_FINAL_OBS(snake, int8_t, 64)
 
 int cge_snake_info(cge_snake *h, int32_t field_id, int32_t *out, void *stream) {
     if (!h) return CGE_ERR_INVALID_ARG;

@@ -95,10 +95,7 @@ struct Params {
     int32_t *done_count;
     double *ep_ret;       // episode statistics (cge_traffic_episode_stats), nullable
     int32_t *ep_len;
-    float *fin_rows;      // fused rollout, SAME_STEP: compacted terminal observations (cge_traffic_rollout_final_obs), nullable
-    int64_t *fin_index;   //   [slot] = step-in-call * n + env
-    int64_t fin_cap;
-    int32_t *fin_count;
+    FinalSeg fin;         // fused rollout, SAME_STEP: terminal observations compacted per wave (cge_traffic_rollout_final_obs), rows nullable
 };
 
 // A wave-uniform base pointer plus a 32-bit per-lane byte offset: the global_store/load form with the base in SGPRs.  A kernel that
@@ -741,6 +738,7 @@ __global__ __launch_bounds__(BLOCK, (waves_per_simd<NI_T, IPL_T, ROLLOUT>())) vo
     const uint64_t key = ROLLOUT ? hash_env_key(p.a_seed, (uint64_t)(p.env0 + i)) : 0;
     double rsum = 0.0;
     int32_t dcount = 0;
+    uint32_t fin_used = 0;                                                        // terminal rows this wave has delivered (its segment's fill)
     const int ksteps = ROLLOUT ? p.k_steps : 1;
     TICK_DECL
     TICK(0);                                                                      // record load, kernel start
@@ -882,15 +880,14 @@ __global__ __launch_bounds__(BLOCK, (waves_per_simd<NI_T, IPL_T, ROLLOUT>())) vo
             ColdArgs c = cold_args();
             if (!ROLLOUT) {
                 if (c->final_obs) emit_row<IPL>(e, c->final_obs + i0 * OBS, roff, ni, ql, (float)gfeat, fin);
-            } else if (c->fin_rows) {
-                // compacted: one counter bump per wave, the wave's terminal rows take consecutive slots
-                uint32_t base = 0;
-                if (lane == (uint32_t)__builtin_ctzll(fin_mask)) base = (uint32_t)atomicAdd(c->fin_count, (int32_t)__popcll(fin_mask));
-                base = (uint32_t)__shfl((int)base, __builtin_ctzll(fin_mask), 64);
-                const int64_t slot = (int64_t)base + __popcll(fin_mask & ((1ull << (lane & ~3u)) - 1ull));
-                const bool on = fin && slot < c->fin_cap;
-                emit_row<IPL>(e, c->fin_rows + (int64_t)base * OBS, (uint32_t)(on ? slot - base : 0) * (uint32_t)(OBS * 4), ni, ql, (float)gfeat, on);
-                if (on && ql == 0u) c->fin_index[slot] = (int64_t)t * c->n + i;
+            } else if (c->fin.rows) {
+                // the wave's terminal rows take the next slots of the wave's segment (fin_used: register, wave-uniform)
+                const uint32_t slot = fin_used + (uint32_t)__popcll(fin_mask & ((1ull << (lane & ~3u)) - 1ull));
+                const bool on = fin && (int64_t)slot < c->fin.cap;
+                const int64_t gs = (int64_t)chunk * c->fin.cap + slot;
+                emit_row<IPL>(e, static_cast<float *>(c->fin.rows) + (int64_t)chunk * c->fin.cap * OBS, (on ? slot : 0u) * (uint32_t)(OBS * 4), ni, ql, (float)gfeat, on);
+                if (on && ql == 0u) c->fin.index[gs] = (int64_t)t * c->fin.n + i;
+                fin_used += (uint32_t)__popcll(fin_mask);
             }
         }
         if (reset_now) { e.reset(); tot = Totals{0, 0, 0}; gfeat = 0.0; }
@@ -926,6 +923,7 @@ __global__ __launch_bounds__(BLOCK, (waves_per_simd<NI_T, IPL_T, ROLLOUT>())) vo
         ColdArgs c = cold_args();
         if (c->reward_sum) c->reward_sum[i] = rsum;
         if (c->done_count) c->done_count[i] = dcount;
+        if (c->fin.count && g == 0u) c->fin.count[chunk] = (int32_t)fin_used;
     }
 }
 
@@ -1017,10 +1015,6 @@ struct cge_traffic : HandleBase {
     int ni = 0, recw = 0, obsw = 0, ipl = 0;
     uint32_t *state = nullptr;
     uint32_t *mt = nullptr;
-    float *fin_rows = nullptr;
-    int64_t *fin_index = nullptr;
-    int64_t fin_cap = 0;
-    int32_t *fin_count = nullptr;
     char step_name[64], rollout_name[64];
 
     traffic::Params params() const {
@@ -1204,20 +1198,14 @@ int cge_traffic_rollout(cge_traffic *h, int32_t k_steps, const int32_t *actions,
     traffic::Params p = h->params();
     p.k_steps = k_steps; p.actions = actions; p.a_seed = action_seed; p.t0 = t0; p.obs = obs_out; p.obs_step_stride = obs_step_stride;
     p.reward = reward_traj_out; p.terminated = terminated_traj_out; p.reward_sum = reward_sum_out; p.done_count = done_count_out;
-    p.fin_rows = h->fin_rows; p.fin_index = h->fin_index; p.fin_cap = h->fin_cap; p.fin_count = h->fin_count;
+    p.fin = FinalSeg{h->fin_rows, h->fin_index, h->fin_count, h->fin_cap, h->n};
     h->launch(p, true, as_stream(stream));
     h->last_kernel = h->rollout_name;
     CGE_TRY(h, hipGetLastError());
     return CGE_OK;
 }
 
-int cge_traffic_rollout_final_obs(cge_traffic *h, float *rows_out, int64_t *index_out, int64_t capacity, int32_t *count_out) {
-    if (!h) return CGE_ERR_INVALID_ARG;
-    if ((rows_out || index_out || count_out) && (!rows_out || !index_out || !count_out || capacity <= 0))
-        return h->fail(CGE_ERR_INVALID_ARG, "cge_traffic_rollout_final_obs: rows, index and count go together (all NULL unregisters)");
-    h->fin_rows = rows_out; h->fin_index = index_out; h->fin_cap = rows_out ? capacity : 0; h->fin_count = count_out;
-    return CGE_OK;
-}
+CGE_DEFINE_FINAL_OBS(traffic, float, traffic::EPW)
 
 int cge_traffic_info(cge_traffic *h, int32_t field_id, int32_t index, int32_t *out, void *stream) {
     if (!h) return CGE_ERR_INVALID_ARG;

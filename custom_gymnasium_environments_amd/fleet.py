@@ -25,8 +25,9 @@ class FleetVectorEnv(FlagsVectorEnv):
     metadata = {"render_modes": []}
 
     def __init__(self, num_envs, device="cuda:0", autoreset_mode="NextStep", env_index0=0, max_timesteps=800, reuse_buffers=False,
-                 info_fields=(), record_episode_statistics=False):
+                 info_fields=(), record_episode_statistics=False, reference_info=False):
         self._init_common(num_envs, device, autoreset_mode, env_index0, reuse_buffers)
+        self._reference_info = bool(reference_info)
         self.single_action_space = MultiDiscrete([8, 8, 8])
         self.single_observation_space = Box(-1.0, 25.0, (OBS_DIM,), np.float32)
         self.action_space = batch_space(self.single_action_space, self.num_envs)
@@ -37,3 +38,15 @@ class FleetVectorEnv(FlagsVectorEnv):
         self._h = h
         self._finish_init(info_fields)
         self.record_episode_statistics(record_episode_statistics)
+
+    def reference_info(self):
+        """The reference's `_get_info()` dict under ITS keys (fleet_env.py:595-608): timestep, active_deliveries (requests not yet
+        completed: a request is marked completed where completed_deliveries is counted, :405,436), completed_deliveries,
+        vehicles_with_fuel (fuel > 0), weather_effect, total_reward, missed_deadlines.  Seven small info kernels: for callbacks, not
+        the hot loop.  `reference_info=True` merges it into every `infos`."""
+        import torch
+        done, fuel = self.info("completed_deliveries"), torch.stack([self.info(f"fuel{k}") for k in range(3)], 1)
+        return {"timestep": self.info("timestep").to(torch.int64), "active_deliveries": (self.info("num_requests") - done).to(torch.int64),
+                "completed_deliveries": done.to(torch.int64), "vehicles_with_fuel": (fuel > 0).sum(1),
+                "weather_effect": self.info("weather_effect"), "total_reward": self.info("total_reward"),
+                "missed_deadlines": self.info("missed_deadlines").to(torch.int64)}

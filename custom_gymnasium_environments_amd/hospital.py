@@ -27,8 +27,9 @@ class HospitalVectorEnv(FlagsVectorEnv):
     metadata = {"render_modes": []}
 
     def __init__(self, num_envs, device="cuda:0", autoreset_mode="NextStep", env_index0=0, max_episode_length=1440, reuse_buffers=False,
-                 info_fields=(), record_episode_statistics=False):
+                 info_fields=(), record_episode_statistics=False, reference_info=False):
         self._init_common(num_envs, device, autoreset_mode, env_index0, reuse_buffers)
+        self._reference_info = bool(reference_info)
         self.single_action_space = Discrete(35)
         self.single_observation_space = Box(0.0, 1.0, (OBS_DIM,), np.float32)
         self.action_space = batch_space(self.single_action_space, self.num_envs)
@@ -39,3 +40,11 @@ class HospitalVectorEnv(FlagsVectorEnv):
         self._h = h
         self._finish_init(info_fields)
         self.record_episode_statistics(record_episode_statistics)
+
+    def reference_info(self):
+        """The reference's step() `info` under ITS keys (hospital_env.py:362-367): deaths, patients_treated,
+        avg_wait_time = total_wait_time / max(patients_treated, 1), time.  `reference_info=True` merges it into every `infos`."""
+        import torch
+        treated = self.info("patients_treated")
+        return {"deaths": self.info("deaths").to(torch.int64), "patients_treated": treated.to(torch.int64),
+                "avg_wait_time": self.info("total_wait_time") / torch.clamp(treated, min=1.0), "time": self.info("time").to(torch.int64)}

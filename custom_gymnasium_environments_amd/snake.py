@@ -30,11 +30,14 @@ class SnakeVectorEnv(DeviceVectorEnv):
     """
 
     _abi = "cge_snake"
+    _obs_dtype = torch.int8
     metadata = {"render_modes": ["rgb_array"]}
 
     def __init__(self, num_envs, grid_size=20, device="cuda:0", autoreset_mode="NextStep", env_index0=0,
-                 max_steps=1000, reuse_buffers=False, info_fields=(), record_episode_statistics=False, render_mode=None):
+                 max_steps=1000, reuse_buffers=False, info_fields=(), record_episode_statistics=False, render_mode=None,
+                 reference_info=False):
         self._init_common(num_envs, device, autoreset_mode, env_index0, reuse_buffers)
+        self._reference_info = bool(reference_info)
         if render_mode not in (None, "rgb_array"):
             raise ValueError("render_mode must be None or 'rgb_array' (the pygame window of 'human' is out of scope)")
         self.render_mode = render_mode
@@ -143,7 +146,16 @@ class SnakeVectorEnv(DeviceVectorEnv):
         return out
 
     def _infos(self):
-        return {f: self.info(f) for f in self.info_fields}
+        d = {f: self.info(f) for f in self.info_fields}
+        if self._reference_info:
+            d.update(self.reference_info())
+        return d
+
+    def reference_info(self):
+        """The reference's `info` (snake_env.py:62,117): {"score", "snake_length"} of the env's CURRENT state — after a SAME_STEP
+        auto-reset that is the fresh episode's (the finished episode's score is what `record_episode_statistics` reports:
+        return = 10 * score - 10 on a crash).  `reference_info=True` merges it into every `infos`."""
+        return {"score": self.info("score"), "snake_length": self.info("snake_length")}
 
     def invalid_action_count(self):
         """Synchronises; number of out-of-range actions since the last call (reference: ValueError)."""

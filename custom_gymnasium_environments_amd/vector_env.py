@@ -161,44 +161,43 @@ class DeviceVectorEnv(VectorEnvBase):
     # ------------------------------------------------------------------ terminal observations of fused SAME_STEP rollouts
     _obs_dtype = torch.float32
 
-    def collect_final_obs(self, capacity=None):
+    def collect_final_obs(self, rows_per_env=4):
         """A SAME_STEP `rollout()` writes the RESET observation of an env that finishes at step t to slot t of its trajectory —
         what `step()` returns as `obs`; the terminal observation, which `step()` hands over as `infos["final_obs"]` (and the
-        reference's own step() returns), goes to a compacted side output once this is enabled: up to `capacity` rows per rollout
-        (default: one per env), read back with `final_obs()`.  `capacity=0` disables it again."""
-        if capacity is None:
-            capacity = self.num_envs
-        if not hasattr(self._lib, f"{self._abi}_rollout_final_obs"):
-            raise NotImplementedError(f"{self._abi}: no rollout_final_obs entry point")
-        if capacity <= 0:
+        reference's own step() returns), goes to a side output once this is enabled.  The rows are compacted per segment of S
+        consecutive envs (the envs one wavefront steps: `self.final_obs_segment`); a segment holds S * rows_per_env rows per rollout
+        call — size it for the episodes a rollout can end (`final_obs_dropped()` says whether it was enough).  Read the rows back with
+        `final_obs()`; `rows_per_env=0` disables the output again."""
+        seg = self.final_obs_segment = int(self._fn("final_obs_segment")(self._h))
+        if rows_per_env <= 0:
             torch.cuda.current_stream(self.device).synchronize()
             self._check(self._fn("rollout_final_obs")(self._h, None, None, 0, None), "rollout_final_obs")
             self._fin = None
             return
-        rows = torch.empty((int(capacity),) + tuple(self._obs_shape[1:]), dtype=self._obs_dtype, device=self.device)
-        index = torch.empty(int(capacity), dtype=torch.int64, device=self.device)
-        count = torch.zeros(1, dtype=torch.int32, device=self.device)
-        self._check(self._fn("rollout_final_obs")(self._h, rows.data_ptr(), index.data_ptr(), int(capacity), count.data_ptr()), "rollout_final_obs")
-        self._fin = (rows, index, count)
+        nseg, cap = -(-self.num_envs // seg), int(seg * rows_per_env)
+        rows = torch.empty((nseg * cap,) + tuple(self._obs_shape[1:]), dtype=self._obs_dtype, device=self.device)
+        index = torch.empty(nseg * cap, dtype=torch.int64, device=self.device)
+        count = torch.zeros(nseg, dtype=torch.int32, device=self.device)
+        self._check(self._fn("rollout_final_obs")(self._h, rows.data_ptr(), index.data_ptr(), cap, count.data_ptr()), "rollout_final_obs")
+        self._fin = (rows, index, count, cap)
 
     def _final_obs_begin(self):
-        fin = getattr(self, "_fin", None)
-        if fin is not None:
-            fin[2].zero_()
+        pass                                     # every rollout call writes the segments' counts itself
 
     def final_obs(self):
         """(rows [m, *obs_shape], step [m], env [m]) delivered by the last rollout(), sorted by (step, env): row j is the terminal
-        observation of env[j] at step step[j] of that call.  Synchronises (it reads the counter).  Rows beyond the capacity were
-        counted, not stored: `m` is min(count, capacity) and `final_obs_dropped()` says how many are missing."""
-        rows, index, count = self._fin
-        m = min(int(count.item()), rows.shape[0])
-        order = torch.argsort(index[:m])
-        idx = index[:m][order]
-        return rows[:m][order], idx // self.num_envs, idx % self.num_envs
+        observation of env[j] at step step[j] of that call.  Gathers the segments' rows on the device (boolean indexing: synchronises)."""
+        rows, index, count, cap = self._fin
+        nseg = count.shape[0]
+        keep = (torch.arange(cap, device=self.device)[None, :] < count.clamp(max=cap)[:, None]).reshape(-1)
+        idx = index[keep]
+        order = torch.argsort(idx)
+        idx = idx[order]
+        return rows[keep][order], idx // self.num_envs, idx % self.num_envs
 
     def final_obs_dropped(self):
-        rows, _, count = self._fin
-        return max(0, int(count.item()) - rows.shape[0])
+        rows, _, count, cap = self._fin
+        return int((count - cap).clamp(min=0).sum().item())
 
     def snapshot(self):
         """Whole-batch checkpoint as an opaque uint8 array (env types without a canonical per-env `get_state` record).
@@ -304,4 +303,11 @@ class FlagsVectorEnv(DeviceVectorEnv):
         return out
 
     def _infos(self):
-        return {f: self.info(f) for f in self.info_fields}
+        d = {f: self.info(f) for f in self.info_fields}
+        if getattr(self, "_reference_info", False):
+            d.update(self.reference_info())
+        return d
+
+    def reference_info(self):
+        """The reference's own `info` dict (its keys, its derived expressions) as tensors; subclasses define it."""
+        raise NotImplementedError

@@ -13,6 +13,18 @@
  *   <env>_step     <->  Env.step(action)        snake_env.py:67-119, crypto:342-398, traffic:168-203
  *   <env>_rollout  <->  the `while not done: env.step(a)` loops of the reference's scripts
  *                       (snake_env_classic/example.py:21-32) fused into one launch
+ *   <env>_rollout_final_obs <-> the terminal observation every reference step() RETURNS (snake_env.py:88-94,113-119 and each env's
+ *                       step()): step() hands it to final_obs_out in SAME_STEP mode while obs_out gets the reset observation; a fused
+ *                       SAME_STEP rollout writes the reset observation to slot t of its trajectory, and the terminal rows go to a side
+ *                       output registered here, so that rollout(trajectory) + this output is exactly what k step() calls return.
+ *                       The rows are compacted per SEGMENT: <env>_final_obs_segment(h) consecutive envs (the envs one wavefront or
+ *                       workgroup steps: 64, traffic 16) own seg_capacity consecutive rows; segment g = envs [g*S, (g+1)*S).
+ *                       Caller-owned DEVICE buffers: rows_out [n_segments * seg_capacity, *obs_shape], index_out [n_segments *
+ *                       seg_capacity] (int64: step-in-call * n_envs + env) and count_out [n_segments] (int32).  Every later rollout
+ *                       call writes count_out[g] = terminal rows segment g produced in THAT call (no zeroing by the caller) and the
+ *                       first min(count, seg_capacity) of them, in step order, to the segment's rows; the surplus is dropped (the count
+ *                       still says so).  All NULL unregisters.  NEXT_STEP / DISABLED rollouts deliver nothing: slot t of their
+ *                       trajectory IS the terminal observation.
  *   <env>_info     <->  the `info` dicts        snake_env.py:63,117
  *   <env>_episode_stats <-> the per-episode return / length that the reference's training scripts read back from their
  *                       vector-env wrapper as episode_return_mean / episode_len_mean
@@ -117,12 +129,16 @@ int cge_snake_step(cge_snake *h, const int32_t *actions, int8_t *obs_out, float 
  * [k_steps, n_envs] int32 or NULL -> cge_hash_action(action_seed, env_index0+i, t0+t, 4, 0).  obs_out
  * (nullable): one [n_envs,G,G] buffer rewritten every step (obs_step_stride = 0) or a trajectory buffer
  * [k_steps, n_envs, G, G] (obs_step_stride = n_envs*G*G).  reward_traj_out / terminated_traj_out
- * (nullable): per-step [k_steps, n_envs] outputs, i.e. exactly what k step() calls would return;
+ * (nullable): per-step [k_steps, n_envs] outputs, i.e. exactly what k step() calls would return (SAME_STEP: together with
+ * the terminal rows of cge_snake_rollout_final_obs);
  * reward_sum_out / done_count_out (nullable) accumulate per env over the k steps. */
 int cge_snake_rollout(cge_snake *h, int32_t k_steps, const int32_t *actions, uint64_t action_seed, int64_t t0,
                       int8_t *obs_out, int64_t obs_step_stride, float *reward_traj_out,
                       uint8_t *terminated_traj_out, float *reward_sum_out, int32_t *done_count_out,
                       void *stream);
+/* terminal observations of SAME_STEP rollouts, compacted per segment of 64 envs: see <env>_rollout_final_obs at the top of this file */
+int cge_snake_rollout_final_obs(cge_snake *h, int8_t *rows_out, int64_t *index_out, int64_t seg_capacity, int32_t *count_out);
+int64_t cge_snake_final_obs_segment(const cge_snake *h);
 int cge_snake_info(cge_snake *h, int32_t field_id, int32_t *out, void *stream);
 /* render_mode="rgb_array" (snake_env.py:175-188): uint8 [n_envs, G, G, 3] (4-byte aligned) — empty (0,0,0), snake (0,255,0),
  * food (255,0,0) — of the CURRENT state of every env.  The pygame window of render_mode="human" (:153-173) is out of scope. */
@@ -201,6 +217,9 @@ int cge_crypto_rollout(cge_crypto *h, int32_t k_steps, const void *actions, uint
                        float *obs_out, int64_t obs_step_stride, float *reward_traj_out,
                        uint8_t *terminated_traj_out, double *reward_sum_out, int32_t *done_count_out,
                        void *stream);
+/* terminal observations of SAME_STEP rollouts, compacted per segment of 64 envs: see <env>_rollout_final_obs at the top of this file */
+int cge_crypto_rollout_final_obs(cge_crypto *h, float *rows_out, int64_t *index_out, int64_t seg_capacity, int32_t *count_out);
+int64_t cge_crypto_final_obs_segment(const cge_crypto *h);
 int cge_crypto_info(cge_crypto *h, int32_t field_id, double *out, void *stream);
 /* canonical record (host), identical to the oracle's: int32[12] {regime, step, needs_reset, cash_kind,
  * P_idx, L_idx, has_gauss, episodes, 0,0,0,0}; double[6] {cash, holdings, psych, trend_strength, gauss, episode_return_so_far (the oracle writes 0)};
@@ -267,14 +286,9 @@ int cge_traffic_rollout(cge_traffic *h, int32_t k_steps, const int32_t *actions,
                         float *obs_out, int64_t obs_step_stride, float *reward_traj_out,
                         uint8_t *terminated_traj_out, double *reward_sum_out, int32_t *done_count_out,
                         void *stream);
-/* <env>_rollout_final_obs: what makes a SAME_STEP rollout "exactly what k step() calls would return".  step() hands the terminal
- * observation of an env that finishes to final_obs_out (the reference RETURNS it, environment.py:193-203) while obs_out gets the
- * reset observation; a fused rollout writes the reset observation to slot t of its trajectory, and the terminal rows go HERE,
- * compacted: registers caller-owned DEVICE buffers rows_out [capacity, obs_dim], index_out [capacity] (int64: step-in-call * n_envs
- * + env) and count_out [1] (int32; the caller zeroes it, every later rollout adds the rows it delivers — slot order within a call
- * is not deterministic, sort by index; rows beyond `capacity` are counted but not stored).  All NULL unregisters.  NEXT_STEP /
- * DISABLED rollouts deliver nothing (slot t of their trajectory IS the terminal observation). */
-int cge_traffic_rollout_final_obs(cge_traffic *h, float *rows_out, int64_t *index_out, int64_t capacity, int32_t *count_out);
+/* terminal observations of SAME_STEP rollouts, compacted per segment of 16 envs: see <env>_rollout_final_obs at the top of this file */
+int cge_traffic_rollout_final_obs(cge_traffic *h, float *rows_out, int64_t *index_out, int64_t seg_capacity, int32_t *count_out);
+int64_t cge_traffic_final_obs_segment(const cge_traffic *h);
 int cge_traffic_info(cge_traffic *h, int32_t field_id, int32_t index, int32_t *out, void *stream);
 /* info['total_reward'] (:372): float64 running sum of the episode's rewards */
 int cge_traffic_total_reward(cge_traffic *h, double *out, void *stream);
@@ -330,6 +344,9 @@ int cge_parking_rollout(cge_parking *h, int32_t k_steps, const int32_t *actions,
                         float *obs_out, int64_t obs_step_stride, float *reward_traj_out,
                         uint8_t *terminated_traj_out, double *reward_sum_out, int32_t *done_count_out,
                         void *stream);
+/* terminal observations of SAME_STEP rollouts, compacted per segment of 64 envs: see <env>_rollout_final_obs at the top of this file */
+int cge_parking_rollout_final_obs(cge_parking *h, float *rows_out, int64_t *index_out, int64_t seg_capacity, int32_t *count_out);
+int64_t cge_parking_final_obs_segment(const cge_parking *h);
 int cge_parking_info(cge_parking *h, int32_t field_id, int32_t index, int32_t *out, void *stream);
 int cge_parking_info64(cge_parking *h, int32_t field_id, double *out, void *stream);
 /* whole-handle checkpoint (host memory, opaque: 32-byte header + the device arrays in device layout); restores only
@@ -381,6 +398,9 @@ int cge_climate_rollout(cge_climate *h, int32_t k_steps, const float *ac_temp, c
                         uint64_t action_seed, int64_t t0, float *obs_out, int64_t obs_step_stride,
                         float *reward_traj_out, uint8_t *terminated_traj_out, double *reward_sum_out,
                         int32_t *done_count_out, void *stream);
+/* terminal observations of SAME_STEP rollouts, compacted per segment of 64 envs: see <env>_rollout_final_obs at the top of this file */
+int cge_climate_rollout_final_obs(cge_climate *h, float *rows_out, int64_t *index_out, int64_t seg_capacity, int32_t *count_out);
+int64_t cge_climate_final_obs_segment(const cge_climate *h);
 int cge_climate_info(cge_climate *h, int32_t field_id, double *out, void *stream);
 /* whole-handle checkpoint (host memory, opaque: 32-byte header + the device arrays in device layout); restores only
  * into a handle created with the same n_envs and config; both calls synchronise `stream` */
@@ -427,6 +447,9 @@ int cge_fleet_step(cge_fleet *h, const int32_t *actions, float *obs_out, float *
 int cge_fleet_rollout(cge_fleet *h, int32_t k_steps, const int32_t *actions, uint64_t action_seed, int64_t t0,
                       float *obs_out, int64_t obs_step_stride, float *reward_traj_out, uint8_t *terminated_traj_out,
                       double *reward_sum_out, int32_t *done_count_out, void *stream);
+/* terminal observations of SAME_STEP rollouts, compacted per segment of 64 envs: see <env>_rollout_final_obs at the top of this file */
+int cge_fleet_rollout_final_obs(cge_fleet *h, float *rows_out, int64_t *index_out, int64_t seg_capacity, int32_t *count_out);
+int64_t cge_fleet_final_obs_segment(const cge_fleet *h);
 int cge_fleet_info(cge_fleet *h, int32_t field_id, double *out, void *stream);
 /* whole-handle checkpoint (host memory, opaque: 32-byte header + the device arrays in device layout); restores only
  * into a handle created with the same n_envs and config; both calls synchronise `stream` */
@@ -459,7 +482,8 @@ enum { /* cge_manufacturing_info float64 fields (info dict :293-299, oee_metrics
     CGE_MANUFACTURING_INFO_IN_SYSTEM = 3, CGE_MANUFACTURING_INFO_COMPLETED = 4, CGE_MANUFACTURING_INFO_SCRAPPED = 5,
     CGE_MANUFACTURING_INFO_PRODUCT_IDS = 6, CGE_MANUFACTURING_INFO_HISTORY_LEN = 7, CGE_MANUFACTURING_INFO_OEE_AVAILABILITY = 8,
     CGE_MANUFACTURING_INFO_OEE_PERFORMANCE = 9, CGE_MANUFACTURING_INFO_OEE_QUALITY = 10, CGE_MANUFACTURING_INFO_TIMESTEP = 11,
-    CGE_MANUFACTURING_INFO_EPISODES = 12, CGE_MANUFACTURING_INFO_NEEDS_RESET = 13, CGE_MANUFACTURING_INFO_OVERFLOW = 14
+    CGE_MANUFACTURING_INFO_EPISODES = 12, CGE_MANUFACTURING_INFO_NEEDS_RESET = 13, CGE_MANUFACTURING_INFO_OVERFLOW = 14,
+    CGE_MANUFACTURING_INFO_COMPLETED_TYPE0 = 15   /* .. + 5: products_completed['A'..'F'] (manufacturing_env.py:157,485), the dict info carries (:296) */
 };
 
 int cge_manufacturing_create(const cge_manufacturing_config *cfg, int64_t n_envs, int device, int64_t env_index0, cge_manufacturing **out);
@@ -474,6 +498,9 @@ int cge_manufacturing_step(cge_manufacturing *h, const int32_t *actions, float *
 int cge_manufacturing_rollout(cge_manufacturing *h, int32_t k_steps, const int32_t *actions, uint64_t action_seed, int64_t t0,
                               float *obs_out, int64_t obs_step_stride, float *reward_traj_out, uint8_t *terminated_traj_out,
                               double *reward_sum_out, int32_t *done_count_out, void *stream);
+/* terminal observations of SAME_STEP rollouts, compacted per segment of 64 envs: see <env>_rollout_final_obs at the top of this file */
+int cge_manufacturing_rollout_final_obs(cge_manufacturing *h, float *rows_out, int64_t *index_out, int64_t seg_capacity, int32_t *count_out);
+int64_t cge_manufacturing_final_obs_segment(const cge_manufacturing *h);
 int cge_manufacturing_info(cge_manufacturing *h, int32_t field_id, double *out, void *stream);
 /* whole-handle checkpoint (host memory, opaque: 32-byte header + the device arrays in device layout); restores only
  * into a handle created with the same n_envs and config; both calls synchronise `stream` */
@@ -522,6 +549,9 @@ int cge_hospital_step(cge_hospital *h, const int32_t *actions, float *obs_out, f
 int cge_hospital_rollout(cge_hospital *h, int32_t k_steps, const int32_t *actions, uint64_t action_seed, int64_t t0,
                          float *obs_out, int64_t obs_step_stride, float *reward_traj_out, uint8_t *terminated_traj_out,
                          double *reward_sum_out, int32_t *done_count_out, void *stream);
+/* terminal observations of SAME_STEP rollouts, compacted per segment of 64 envs: see <env>_rollout_final_obs at the top of this file */
+int cge_hospital_rollout_final_obs(cge_hospital *h, float *rows_out, int64_t *index_out, int64_t seg_capacity, int32_t *count_out);
+int64_t cge_hospital_final_obs_segment(const cge_hospital *h);
 int cge_hospital_info(cge_hospital *h, int32_t field_id, double *out, void *stream);
 /* whole-handle checkpoint (host memory, opaque: 32-byte header + the device arrays in device layout); restores only
  * into a handle created with the same n_envs and config; both calls synchronise `stream` */

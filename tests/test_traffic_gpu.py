@@ -153,7 +153,8 @@ def test_layouts_and_knobs_match_oracle(cge, oracle, ctor):
                                   dict(grid_size=(4, 5), num_intersections=13, max_vehicles=60, spawn_rate=0.5)], ids=["default", "3x3_4", "4x5_13"])
 def test_same_step_rollout_delivers_terminal_observations(cge, ctor):
     """SAME_STEP rollout(trajectory=True) + the compacted final-obs output == k step() calls' (obs, infos["final_obs"]): the reference
-    returns the terminal observation from step() (environment.py:193-203); the trajectory's slot holds the reset observation."""
+    returns the terminal observation from step() (environment.py:193-203); the trajectory's slot holds the reset observation.
+    (All eight env types: tests/test_final_obs_gpu.py; here: the traffic layouts, with desynchronised episodes.)"""
     n, limit, k = 300, 37, 100
     env = cge.TrafficVectorEnv(n, autoreset_mode="SameStep", max_steps=limit, **ctor)
     twin = cge.TrafficVectorEnv(n, autoreset_mode="SameStep", max_steps=limit, **ctor)
@@ -164,7 +165,8 @@ def test_same_step_rollout_delivers_terminal_observations(cge, ctor):
         for t in range(11):
             e.step(warm[t])
         e.reset(options={"reset_mask": mask})
-    env.collect_final_obs(capacity=4 * n)                  # every env finishes two or three episodes in the k steps
+    env.collect_final_obs(rows_per_env=4)                  # every env finishes two or three episodes in the k steps
+    assert env.final_obs_segment == 16
     acts = torch.randint(0, 3, (k, n, env.num_intersections), dtype=torch.int32, device="cuda")
     traj, rt, tt, rs, dc = env.rollout(k, actions=acts, trajectory=True, per_step=True)
     rows, step, who = env.final_obs()
@@ -180,12 +182,6 @@ def test_same_step_rollout_delivers_terminal_observations(cge, ctor):
             assert torch.equal(rows[j:j + m], info["final_obs"][done]), t
             j += m
     assert j == rows.shape[0] and j >= n * (k // limit)
-    # a smaller capacity: the counter still counts every terminal row
-    env.collect_final_obs(capacity=50)
-    env.rollout(limit, actions=acts[:limit], trajectory=True, per_step=True)
-    rows, step, who = env.final_obs()
-    assert rows.shape[0] == 50 and env.final_obs_dropped() > 0
-    env.collect_final_obs(capacity=0)
     env.close(); twin.close()
 
 
