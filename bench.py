@@ -321,6 +321,8 @@ def main():
     ap.add_argument("--manifest", default=None, help="write {kernel: env-steps launched} here (tools/profile.sh uses it to turn PMC bytes into bytes per env-step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--repeats", type=int, default=9, help="the K-step timed region is run this many times; value / ms_per_step = the median region")
+    ap.add_argument("--graph", action="store_true", help="third leg: the step() calls captured in ONE HIP graph (torch.cuda.CUDAGraph) and replayed — "
+                                                         "what the host-bound small batches gain when the per-call launch path is taken off the clock")
     ap.add_argument("--episode", action="store_true", help="--steps := the workload's episode length (one whole episode per timed region)")
     args = ap.parse_args()
 
@@ -541,6 +543,27 @@ def main():
     actions = {nm: (None if dry else make_actions(nm, K + W, n, dev)) for nm in names}  # API path: K step() calls, HBM-resident actions
     run_steps(actions, 0, W)
     results["step"] = timed(lambda rep, marks: run_steps(actions, W, W + K, marks), "step", same_work)
+    graph_leg = None
+    if args.graph and len(names) == 1 and not dry:
+        nm, Kg = names[0], min(K, 256)
+        g = torch.cuda.CUDAGraph()
+        restart_episodes()
+        sync()
+        with torch.cuda.graph(g):                                  # the facade's buffers exist (reuse_buffers=True, the step() leg ran): nothing allocates
+            for t in range(W, W + Kg):
+                envs[nm].step(act_at(nm, actions[nm], t))
+        gw = []
+        for rep in range(R):
+            restart_episodes()
+            barrier()
+            t0 = time.perf_counter()
+            g.replay()
+            barrier()
+            gw.append(time.perf_counter() - t0)
+        gm = median(gw)
+        graph_leg = {"path": "graph", "steps_per_replay": Kg, "_wall": gm, "unit": "env-steps/s", "spread": {"repeats": R, "min_ms_per_step": min(gw) * 1e3 / Kg, "max_ms_per_step": max(gw) * 1e3 / Kg},
+                     "note": f"{Kg} step() calls captured once in a torch.cuda.CUDAGraph and replayed; wall clock between two barriers, max over ranks"}
+        del g
     if "snake" in envs:
         assert envs["snake"].invalid_action_count() == 0
     measured = None
@@ -556,6 +579,10 @@ def main():
         return float(t.item())
 
     walls = {p: reduce_max(results[p][0]) for p in results}
+    if graph_leg:
+        gwall = reduce_max(graph_leg.pop("_wall"))
+        graph_leg["value"] = n * world * graph_leg["steps_per_replay"] / gwall
+        graph_leg["ms_per_step"] = gwall * 1e3 / graph_leg["steps_per_replay"]
     if rank == 0:
         head, other = args.path, ("step" if args.path == "rollout" else "rollout")
         total_envs = n * len(ENVS) if split else n * len(names) * world
@@ -623,6 +650,8 @@ def main():
             out["roofline"] = None
         if hb.get("phases"):
             out["phases"] = hb["phases"]
+        if graph_leg:
+            out["graph_step"] = graph_leg
         if len(names) > 1:
             out["roofline_per_env_type"] = hb["roofline"]
         out["api_step" if other == "step" else "fused_rollout"] = block(other)

@@ -1,9 +1,10 @@
 """GPU parity tests for the SmartClimate hot path (through the C ABI via ClimateVectorEnv).
 
-Float-state env (BASELINE north_star: "within a stated fp32 tolerance"): obs |d| <= 1e-6 + 1e-6|x|, reward
-|d| <= 1e-4 + 1e-6|x| — the device can differ from the CPU only in the last place of log1p/exp inside the
-ziggurat's wedge/tail (1.5 % of normals); the fraction of bit-identical obs values is reported and must stay
-> 0.9999.  Discrete quantities (people, lights, step, flags) are exact."""
+Against the REFERENCE fixtures (NumPy's own generator code ran there) the device is held to bit equality: obs, reward, reset rows.
+Against the C oracle the float fields keep a tolerance (obs |d| <= 1e-6 + 1e-6|x|, reward |d| <= 1e-4 + 1e-6|x|): the oracle takes
+log1p / exp for the ziggurat's wedge and tail (1.5 % of normals) from the host's libm, which may differ from NumPy's and from the
+device's in the last place — the oracle itself is pinned to the same fixtures (tests/test_oracle_climate.py).  Discrete quantities
+(people, lights, step, flags) are exact everywhere."""
 import json
 
 import numpy as np
@@ -40,7 +41,7 @@ def test_same_step_matches_reference_fixture(cge, name):
     ctor = json.loads(str(fx["ctor"])) if "ctor" in fx else {}
     env = cge.ClimateVectorEnv(n, autoreset_mode="SameStep", **ctor)
     obs, _ = env.reset(seed=int(fx["seed0"]))
-    assert _close(_np(obs), fx["obs0"], 1e-6).all()
+    assert np.array_equal(_np(obs), fx["obs0"])
     reset_at = {(int(i), int(t)): k for k, (i, t) in enumerate(fx["reset_index"])}
     ac_d, li_d = torch.from_numpy(AC).cuda(), torch.from_numpy(LI).cuda()
     exact = total = 0
@@ -48,15 +49,13 @@ def test_same_step_matches_reference_fixture(cge, name):
         obs, rew, te, tr, info = env.step({"ac_temp": ac_d[:, t:t + 1], "lights": li_d[:, t]})
         obs, rew, te, fin = _np(obs), _np(rew), _np(te), _np(info["final_obs"])
         assert np.array_equal(te, fx["terminated"][:, t].astype(bool)), t
-        assert _close(rew, fx["reward"][:, t], 1e-4).all(), t
+        # bit-exact, as README / DESIGN 3.6 claim (round 3 measured 216,000 / 216,000 identical values under a 1e-6 tolerance: the
+        # tolerance is gone): float64 room dynamics in the reference's order, the same PCG64 / ziggurat draws, float32 only at the output
+        assert np.array_equal(rew, fx["reward"][:, t].astype(np.float32)), t
         step_obs = np.where(te[:, None], fin, obs)
-        assert _close(step_obs, fx["obs"][:, t], 1e-6).all(), t
-        assert np.array_equal(step_obs[:, [1, 2, 4, 5, 6, 7, 8]], fx["obs"][:, t][:, [1, 2, 4, 5, 6, 7, 8]]), t   # discrete/echo fields exact
-        exact += int((step_obs.view(np.uint32) == fx["obs"][:, t].view(np.uint32)).sum()); total += step_obs.size
+        assert np.array_equal(step_obs.view(np.uint32), fx["obs"][:, t].view(np.uint32)), t
         for i in np.nonzero(te)[0]:
-            assert _close(obs[i], fx["reset_obs"][reset_at[(int(i), t)]], 1e-6).all()
-    print(f"climate fixture: {exact}/{total} obs values bit-identical ({exact / total:.6f})")
-    assert exact / total > 0.9999
+            assert np.array_equal(obs[i], fx["reset_obs"][reset_at[(int(i), t)]])
     env.close()
 
 
