@@ -30,15 +30,27 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_native(force=False, verbose=False, extra_flags=()):
+# Debug builds (extra_flags): -DCGE_MFG_GUARD bounds-checks every table index of the manufacturing kernel and records the first
+# violation instead of dereferencing it (`python -m custom_gymnasium_environments_amd.build --guard` writes libcge_amd_guard.so next to
+# the release library; tools/probes/mfg_guard.py replays the reference fixtures through it).  -DCGE_<ENV>_TIMING: on-device phase clocks.
+GUARD_FLAGS = ("-DCGE_MFG_GUARD",)
+
+
+def build_native(force=False, verbose=False, extra_flags=(), out=None):
     """Compile every .hip under csrc/ into one shared library.  Returns the library path."""
+    if out is not None:
+        return _build(out, "build_" + os.path.splitext(os.path.basename(out))[0], verbose, extra_flags)
     if not force and not is_stale():
         return LIB
+    return _build(LIB, "build", verbose, extra_flags)
+
+
+def _build(lib, objdir, verbose, extra_flags):
     objs = []
     procs = []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    os.makedirs(os.path.join(HERE, objdir), exist_ok=True)
     for src in sources():
-        obj = os.path.join(HERE, "build", os.path.basename(src) + ".o")
+        obj = os.path.join(HERE, objdir, os.path.basename(src) + ".o")
         cmd = [HIPCC, *[f for f in FLAGS if f != "-shared"], *extra_flags, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
@@ -51,10 +63,13 @@ def build_native(force=False, verbose=False, extra_flags=()):
             raise RuntimeError(f"hipcc failed on {src}")
         if verbose and out.strip():
             print(out)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib]
     subprocess.run(cmd, check=True)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build_native(force="--force" in sys.argv, verbose=True))
+    if "--guard" in sys.argv:
+        print(build_native(verbose=True, extra_flags=GUARD_FLAGS, out=os.path.join(HERE, "libcge_amd_guard.so")))
+    else:
+        print(build_native(force="--force" in sys.argv, verbose=True))

@@ -162,6 +162,16 @@ class NumpyVectorEnv:
                     self.env._bufs[b] = views[k]
             if "info/final_obs" in views:
                 self.env._bufs["final_obs"] = views["info/final_obs"]
+            # the env types that report both flags write `terminated | truncated` themselves (cge_<env>_done_mask): it is exposed as
+            # info/_final_obs and info/_episode — point the kernel at the slab (the next step() registers the new address), alias the twin
+            for k in ("info/_final_obs", "info/_episode"):
+                if k in views and "done" in self.env._bufs:
+                    self.env._bufs["done"] = views[k]
+                    for k2 in ("info/_final_obs", "info/_episode"):
+                        if k2 in views and k2 != k:                  # the twin reads the same slab bytes: no copy kernel for it either
+                            views[k2] = self._views[k2] = views[k]
+                            self._layout[k2] = self._layout[k]
+                    break
             if "info/episode/r" in views and self.env._ep_ret is not None:
                 self.env._ep_ret, self.env._ep_len = views["info/episode/r"], views["info/episode/l"]
                 self.env._check(self.env._fn("episode_stats")(self.env._h, self.env._ep_ret.data_ptr(), self.env._ep_len.data_ptr()), "episode_stats")

@@ -124,3 +124,32 @@ def test_pipelined_rollout_equals_step_by_step(cge, mode):
         tot += r.to(torch.float64)
     assert torch.equal(obs, o) and torch.equal(rs, tot)
     a.close(); b.close()
+
+
+def test_pipelined_rollout_with_full_sublists_and_snapshots(cge):
+    """(a) NEXT_STEP with max_timesteps = 50 and n a multiple of 4,096 — every env is truncated at step 50 (the traffic
+    redraw lists it), takes its reset-only step at 51 (listed again), so a pipelined dense launch re-lists the whole population while
+    step blocks append to the same three rotating lists: the sub-lists have zero slack there (sub_cap = ceil(blocks / 64) * 64), and
+    an env filed under the LAUNCHING block instead of its own overflowed one.  One rollout across steps 50 / 51 / 100 / 101 must
+    equal step-by-step.  (b) snapshot -> rollout -> restore -> rollout gives the same trajectory: the per-env `seq` / `pending` bits
+    and the handle's list parity survive the snapshot."""
+    n, K = 4096, 110
+    acts = torch.randint(0, 8, (K, n, 3), dtype=torch.int32, device="cuda")
+    a = cge.FleetVectorEnv(n, autoreset_mode="NextStep", max_timesteps=50)
+    b = cge.FleetVectorEnv(n, autoreset_mode="NextStep", max_timesteps=50)
+    a.reset(seed=2); b.reset(seed=2)
+    a.rollout(7, actions=acts[:7].contiguous())                # an odd number of pipelined launches before the snapshot
+    for t in range(7):
+        b.step(acts[t])
+    snap = a.snapshot()
+    obs, rew, fl, rs, dc = a.rollout(K, actions=acts, trajectory=True, per_step=True)
+    obs, rew, fl = obs.clone(), rew.clone(), fl.clone()
+    for t in range(K):
+        o, r, te, tr, _ = b.step(acts[t])
+        assert torch.equal(obs[t], o), (t, (obs[t] != o).nonzero()[:4])
+        assert torch.equal(rew[t], r) and torch.equal(fl[t], te.to(torch.uint8) | (tr.to(torch.uint8) << 1)), t
+    assert int((fl != 0).sum()) >= 2 * n                       # everybody ran into the time limit twice
+    a.restore(snap)
+    obs2, rew2, fl2, rs2, dc2 = a.rollout(K, actions=acts, trajectory=True, per_step=True)
+    assert torch.equal(obs2, obs) and torch.equal(rew2, rew) and torch.equal(fl2, fl)
+    a.close(); b.close()
