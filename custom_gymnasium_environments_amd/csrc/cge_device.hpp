@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstring>
 
 namespace cge {
 
@@ -1007,5 +1008,211 @@ __device__ __forceinline__ void store_own_row(float *row, int col0, const float 
 #pragma unroll
     for (int q = NF - NF % 4; q < NF; ++q) row[col0 + q] = v[q];
 }
+
+// A wave-uniform base pointer plus a 32-bit per-lane byte offset: the global_store/load form with the base in SGPRs.  A kernel that
+// keeps a 64-bit per-lane pointer per store site instead (13 sites per row, rows for obs and final_obs) spends ~50 VGPRs on addresses.
+template <class T>
+__device__ __forceinline__ T *at(void *ubase, uint32_t voff) { return reinterpret_cast<T *>(static_cast<char *>(ubase) + (size_t)voff); }
+template <class T>
+__device__ __forceinline__ const T *at(const void *ubase, uint32_t voff) { return reinterpret_cast<const T *>(static_cast<const char *>(ubase) + (size_t)voff); }
+
+// ------------------------------------------------------------------ quad primitives: one env = the 4 lanes of a DPP quad (traffic, hospital)
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true); }
+constexpr int QL = 4;                   // lanes per env
+template <int M>
+__device__ __forceinline__ uint32_t gxor(uint32_t v) {                // value of lane (ql ^ M) of the same quad
+    static_assert(M == 1 || M == 2, "a quad");
+    if constexpr (M == 1) return dpp<0xB1>(v);                        // quad_perm [1, 0, 3, 2]
+    else return dpp<0x4E>(v);                                         // quad_perm [2, 3, 0, 1]
+}
+template <int K>
+__device__ __forceinline__ uint32_t gbcast(uint32_t v) { return dpp<K * 0x55>(v); }    // quad_perm [K, K, K, K]
+__device__ __forceinline__ uint32_t gsum(uint32_t v) { v += gxor<1>(v); v += gxor<2>(v); return v; }
+__device__ __forceinline__ uint32_t gor(uint32_t v) { v |= gxor<1>(v); v |= gxor<2>(v); return v; }
+template <int M>
+__device__ __forceinline__ double gxor_f64(double x) {
+    uint64_t u;
+    memcpy(&u, &x, 8);
+    u = ((uint64_t)gxor<M>((uint32_t)(u >> 32)) << 32) | gxor<M>((uint32_t)u);
+    memcpy(&x, &u, 8);
+    return x;
+}
+template <int K>
+__device__ __forceinline__ double gbcast_f64(double x) {
+    uint64_t u;
+    memcpy(&u, &x, 8);
+    u = ((uint64_t)gbcast<K>((uint32_t)(u >> 32)) << 32) | gbcast<K>((uint32_t)u);
+    memcpy(&x, &u, 8);
+    return x;
+}
+
+// Streams `bytes` (a multiple of 8) of the wave's LDS image to `dst` (16-byte aligned, the image's place in HBM): lane l of the
+// `nact` active lanes (the first nact of the wave) moves the 16-byte pieces l, l + nact, ... — one store instruction = nact x 16
+// CONTIGUOUS bytes, whole 128-byte lines.  (Pieces stored from registers where they arise — 64 contiguous bytes per quad and
+// instruction, every line completed by several instructions — cost 1.38x the bytes at the memory side (PMC WRITE_SIZE) and
+// 40 of the 54 us of a 262,144-env rollout step; round 4, profiles/r04_traffic_store_pattern_ab.txt.)
+template <int MAXW>                    // MAXW: words of the largest image (compile time): a full wave's pieces are read in one batch
+__device__ __forceinline__ void stream_image(const uint32_t *__restrict__ img, void *__restrict__ dst, uint32_t bytes, uint32_t lane, uint32_t nact) {
+    const uint32_t n16 = bytes >> 4;
+    if (nact == 64u) {
+        constexpr int J = (MAXW / 4 + 63) / 64;
+        uint4 v[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {                       // all LDS reads first (past the image's end: its last piece again), then the stores
+            const uint32_t k = lane + 64u * j;
+            v[j] = *reinterpret_cast<const uint4 *>(img + 4u * (k < n16 ? k : n16 - 1u));
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const uint32_t k = lane + 64u * j;
+            if (k < n16) *at<uint4>(dst, 16u * k) = v[j];
+        }
+    } else {
+#pragma unroll 1
+        for (uint32_t k = lane; k < n16; k += nact) *at<uint4>(dst, 16u * k) = *reinterpret_cast<const uint4 *>(img + 4u * k);
+    }
+    // the tail of an image that is not a whole number of 16-byte pieces (an odd number of 4-byte-multiple rows): 8, then 4 bytes
+    if ((bytes & 8u) && lane == 0u) *at<uint2>(dst, 16u * n16) = *reinterpret_cast<const uint2 *>(img + 4u * n16);
+    if ((bytes & 4u) && lane == 1u) *at<uint32_t>(dst, (bytes & ~7u) + 0u) = img[(bytes >> 2) - 1u];
+}
+
+
+// ------------------------------------------------------------------ the env's draw stream, group-cooperative
+// Cursor of the env's MT19937 stream as the state record keeps it (cge_device.hpp: pos, pretw, old0), plus the LDS ring:
+//   u   ring counter of the cursor (slot u & 63);  hi  ring counter up to which words are parked (a multiple of 16; hi - u <= 64).
+//       An EMPTY ring is hi = u & ~15: hi - u is then minus the cursor's place in its 16-word unit, and the next unit parked is the one
+//       the cursor stands in (ring units line up with the generator block's 16-word units).
+// Everything here is GROUP-UNIFORM: the four lanes of an env hold the same values and take the same branches.
+struct Cur { uint32_t pos, pretw, old0, u, hi; };
+
+// Twists, in place, the words from `lo` (unwrapped: >= 624 means word lo - 624 of the next generation) to the end of lo's 32-word
+// chunk; lane ql does words c0 + 8 ql .. + 7 (the last chunk of a generation holds 16 words: lanes 0 and 1).  Same contract as
+// cge_device.hpp: mt_twist_chunk (words of the chunk below lo keep their values; old0 receives the outgoing generation's word 0).
+__device__ __forceinline__ uint32_t twist_chunk_group(uint32_t *__restrict__ ublk, uint32_t boff, uint32_t lo, bool go, uint32_t &old0, uint32_t ql) {
+    const uint32_t gen = lo >= (uint32_t)MT_N ? (uint32_t)MT_N : 0u, base = lo - gen, c0 = base & ~31u;
+    const uint32_t len = (uint32_t)MT_N - c0 < 32u ? (uint32_t)MT_N - c0 : 32u;
+    const uint32_t k0 = c0 + 8u * ql;
+    uint32_t first = 0;
+    if (go && 8u * ql < len) {
+        uint32_t a[9], c[8];
+#pragma unroll
+        for (int q = 0; q < 8; q += 4) {
+            const MtQuad v = *at<MtQuad>(ublk, boff + 4u * (k0 + (uint32_t)q));
+            a[q] = v.a; a[q + 1] = v.b; a[q + 2] = v.c; a[q + 3] = v.d;
+            uint32_t ci = k0 + (uint32_t)q + MT_M;                          // == 1 mod 4: 621 is the only piece that touches the mirror
+            ci -= ci > (uint32_t)MT_N ? MT_N : 0;
+            const MtQuad w = *at<MtQuad>(ublk, boff + 4u * ci);
+            c[q] = w.a; c[q + 1] = w.b; c[q + 2] = w.c; c[q + 3] = w.d;
+        }
+        a[8] = *at<uint32_t>(ublk, boff + 4u * (k0 + 8u));                  // <= 624: the mirror of word 0
+        first = a[0];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t y = mt_twist(a[j], a[j + 1], c[j]);
+            a[j] = k0 + (uint32_t)j < base ? a[j] : y;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q += 4) {
+            *at<MtQuad>(ublk, boff + 4u * (k0 + (uint32_t)q)) = MtQuad{a[q], a[q + 1], a[q + 2], a[q + 3]};
+            if (k0 + (uint32_t)q < (uint32_t)MT_PAD) *at<MtQuad>(ublk, boff + 4u * ((uint32_t)MT_N + k0 + (uint32_t)q)) = MtQuad{a[q], a[q + 1], a[q + 2], a[q + 3]};
+        }
+    }
+    const uint32_t w0 = gbcast<0>(first);
+    if (go && c0 == 0u) old0 = w0;                                          // the previous generation's word 0 goes away now
+    return gen + c0 + len;
+}
+
+
+// A quad's LDS draw ring for envs with MANY draws per step (hospital: 50-80 words): RW tempered, READY words per env, refilled 16
+// words (one 16-byte load per lane) at a time from words the quad twisted ahead of the cursor.  Everything here is quad-uniform; the
+// four lanes read the same LDS words.  prepare() (top of a step, and before an episode reset's ~165 draws) also twists ahead until
+// FAR = 224 words from the cursor are ready, so a draw beyond the parked words (a burst: a mass-casualty event, a long rejection run) is
+// ONE load from the generator block — no loop, no call, a dozen instructions per draw site.  A step that drew more than FAR words
+// would read unready words: `ovf` is raised instead (sticky, the env's overflow flag) — rejection runs of that length have a
+// probability below 1e-40, and the data-dependent draws (one death roll per critical patient waiting) are bounded far below it by
+// the dynamics themselves (three deaths end the episode).
+// (Rounds 1-3 refilled on demand through a noinline call: values live across a call must sit in callee-saved VGPRs, every other
+// block of eight registers — ~100 live values took ~230 registers; inlining the refill at ~60 draw sites was 26,000 instructions.)
+template <int RW>
+struct QuadRing {
+    static_assert(RW % 16 == 0, "whole 16-word units");
+    static constexpr uint32_t FAR = 224;                        // words ahead of the cursor that prepare() makes ready (mt_make_ready's bound is 227)
+    uint32_t *ring;       // this env's LDS row: RW words
+    uint32_t *blk;        // this env's generator block
+    Cur c;                // c.u / c.hi: ring SLOT of the cursor / of the first unparked word (0 .. RW-1)
+    int32_t nvalid;       // parked words from the cursor on (<= 0: none; negative: minus the cursor's place inside its unit, ring empty)
+    uint32_t ql, p;       // p: words consumed since the last prepare()
+    bool ovf;
+
+    __device__ __forceinline__ void init(uint32_t *row, uint32_t *block, uint32_t pos, uint32_t pretw, uint32_t quad_lane) {
+        ring = row; blk = block; ql = quad_lane; c.pos = pos; c.pretw = pretw; c.old0 = 0; p = 0; ovf = false;
+        restart();
+    }
+    __device__ __forceinline__ void restart() { c.u = c.pos & 15u; c.hi = 0; nvalid = -(int32_t)(c.pos & 15u); }
+    __device__ __forceinline__ uint32_t slot(uint32_t j) const { uint32_t s = c.u + j; s -= s >= (uint32_t)RW ? (uint32_t)RW : 0u; return s; }
+    __device__ __forceinline__ void twist_until(uint32_t end, bool want) {       // wave-convergent: words up to `end` (unwrapped) become ready
+        bool twisted = false;
+#pragma unroll 1
+        while (__ballot(want && (c.pretw > c.pos ? c.pretw : c.pos) < end)) {
+            const uint32_t lo = c.pretw > c.pos ? c.pretw : c.pos;
+            const bool go = want && lo < end;
+            const uint32_t t = twist_chunk_group(blk, 0u, lo, go, c.old0, ql);
+            if (go) c.pretw = t;
+            twisted = true;
+        }
+        if (twisted) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");        // the quad's stores before the quad's loads of the same words
+    }
+    // the consumed words leave, FAR words from the cursor are made ready, every free unit is parked again (wave-convergent)
+    __device__ __forceinline__ void prepare(bool active = true) {
+        if ((int32_t)p > nvalid) {                              // the step ran past the ring: its cursor moves, the ring starts over
+            mt_advance(c.pos, c.pretw, p);
+            restart();
+        } else {
+            c.u = slot(p); nvalid -= (int32_t)p;
+            mt_advance(c.pos, c.pretw, p);
+        }
+        p = 0;
+        twist_until(c.pos + FAR, active);
+#pragma unroll 1
+        while (__ballot(active && nvalid + 16 <= RW)) {
+            if (active && nvalid + 16 <= RW) {
+                uint32_t gidx = c.pos + (uint32_t)nvalid;          // (nvalid < 0: the unit the cursor stands in)
+                gidx -= gidx >= (uint32_t)MT_N ? MT_N : 0;
+                const uint4 v = *reinterpret_cast<const uint4 *>(blk + gidx + 4u * ql);        // gidx is a multiple of 16
+                *reinterpret_cast<uint4 *>(ring + c.hi + 4u * ql) = make_uint4(mt_temper(v.x), mt_temper(v.y), mt_temper(v.z), mt_temper(v.w));
+                c.hi = c.hi + 16u == (uint32_t)RW ? 0u : c.hi + 16u;
+                nvalid += 16;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    // word j places after the cursor when it is not parked: a ready word of the generator block
+    __device__ __forceinline__ uint32_t far_word(uint32_t j) {
+        if (j >= FAR) { ovf = true; return 0u; }                // (0 passes every rejection test: a flagged env cannot spin)
+        uint32_t pos = c.pos + j;
+        pos -= pos >= (uint32_t)MT_N ? MT_N : 0;
+        return mt_temper(blk[pos]);
+    }
+    __device__ __forceinline__ uint32_t next() {
+        const uint32_t j = p++;
+        return (int32_t)j < nvalid ? ring[slot(j)] : far_word(j);
+    }
+    // look-ahead for draw sequences whose word OFFSETS can be computed up front
+    __device__ __forceinline__ bool has(uint32_t n) const { return (int32_t)(p + n) <= nvalid; }
+    __device__ __forceinline__ uint32_t peek(uint32_t j) const { return ring[slot(p + j)]; }
+    __device__ __forceinline__ void skip(uint32_t n) { p += n; }
+    __device__ __forceinline__ uint32_t randbelow(uint32_t n, int kbits) {   // CPython _randbelow_with_getrandbits
+        uint32_t r = next() >> (32 - kbits);
+        while (r >= n) r = next() >> (32 - kbits);
+        return r;
+    }
+    __device__ __forceinline__ double random53() {
+        const uint32_t a = next() >> 5, b = next() >> 6;
+        return (a * 67108864.0 + b) / 9007199254740992.0;
+    }
+    // end of a launch: the cursor as the state record keeps it
+    __device__ __forceinline__ void finish() { mt_advance(c.pos, c.pretw, p); p = 0; }
+};
 
 }  // namespace cge

@@ -98,42 +98,6 @@ struct Params {
     FinalSeg fin;         // fused rollout, SAME_STEP: terminal observations compacted per wave (cge_traffic_rollout_final_obs), rows nullable
 };
 
-// A wave-uniform base pointer plus a 32-bit per-lane byte offset: the global_store/load form with the base in SGPRs.  A kernel that
-// keeps a 64-bit per-lane pointer per store site instead (13 sites per row, rows for obs and final_obs) spends ~50 VGPRs on addresses.
-template <class T>
-__device__ __forceinline__ T *at(void *ubase, uint32_t voff) { return reinterpret_cast<T *>(static_cast<char *>(ubase) + (size_t)voff); }
-template <class T>
-__device__ __forceinline__ const T *at(const void *ubase, uint32_t voff) { return reinterpret_cast<const T *>(static_cast<const char *>(ubase) + (size_t)voff); }
-
-// ------------------------------------------------------------------ group (quad) primitives
-template <int CTRL>
-__device__ __forceinline__ uint32_t dpp(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true); }
-template <int M>
-__device__ __forceinline__ uint32_t gxor(uint32_t v) {                // value of lane (ql ^ M) of the same group
-    static_assert(M == 1 || M == 2, "a quad");
-    if constexpr (M == 1) return dpp<0xB1>(v);                        // quad_perm [1, 0, 3, 2]
-    else return dpp<0x4E>(v);                                         // quad_perm [2, 3, 0, 1]
-}
-template <int K>
-__device__ __forceinline__ uint32_t gbcast(uint32_t v) { return dpp<K * 0x55>(v); }    // quad_perm [K, K, K, K]
-__device__ __forceinline__ uint32_t gsum(uint32_t v) { v += gxor<1>(v); v += gxor<2>(v); return v; }
-__device__ __forceinline__ uint32_t gor(uint32_t v) { v |= gxor<1>(v); v |= gxor<2>(v); return v; }
-template <int M>
-__device__ __forceinline__ double gxor_f64(double x) {
-    uint64_t u;
-    memcpy(&u, &x, 8);
-    u = ((uint64_t)gxor<M>((uint32_t)(u >> 32)) << 32) | gxor<M>((uint32_t)u);
-    memcpy(&x, &u, 8);
-    return x;
-}
-template <int K>
-__device__ __forceinline__ double gbcast_f64(double x) {
-    uint64_t u;
-    memcpy(&u, &x, 8);
-    u = ((uint64_t)gbcast<K>((uint32_t)(u >> 32)) << 32) | gbcast<K>((uint32_t)u);
-    memcpy(&x, &u, 8);
-    return x;
-}
 // x[i % 4 slot i / 4] of the lane that owns element i (static i), for every lane of the group
 template <int IPL, int I>
 __device__ __forceinline__ double elem_f64(const double (&x)[IPL]) { return gbcast_f64<I % L>(x[I / L]); }
@@ -179,51 +143,7 @@ __device__ __forceinline__ double pairwise_sum(const double (&x)[IPL], int n) {
     return acc;
 }
 
-// ------------------------------------------------------------------ the env's draw stream, group-cooperative
-// Cursor of the env's MT19937 stream as the state record keeps it (cge_device.hpp: pos, pretw, old0), plus the LDS ring:
-//   u   ring counter of the cursor (slot u & 63);  hi  ring counter up to which words are parked (a multiple of 16; hi - u <= 64).
-//       An EMPTY ring is hi = u & ~15: hi - u is then minus the cursor's place in its 16-word unit, and the next unit parked is the one
-//       the cursor stands in (ring units line up with the generator block's 16-word units).
-// Everything here is GROUP-UNIFORM: the four lanes of an env hold the same values and take the same branches.
-struct Cur { uint32_t pos, pretw, old0, u, hi; };
-
-// Twists, in place, the words from `lo` (unwrapped: >= 624 means word lo - 624 of the next generation) to the end of lo's 32-word
-// chunk; lane ql does words c0 + 8 ql .. + 7 (the last chunk of a generation holds 16 words: lanes 0 and 1).  Same contract as
-// cge_device.hpp: mt_twist_chunk (words of the chunk below lo keep their values; old0 receives the outgoing generation's word 0).
-__device__ __forceinline__ uint32_t twist_chunk_group(uint32_t *__restrict__ ublk, uint32_t boff, uint32_t lo, bool go, uint32_t &old0, uint32_t ql) {
-    const uint32_t gen = lo >= (uint32_t)MT_N ? (uint32_t)MT_N : 0u, base = lo - gen, c0 = base & ~31u;
-    const uint32_t len = (uint32_t)MT_N - c0 < 32u ? (uint32_t)MT_N - c0 : 32u;
-    const uint32_t k0 = c0 + 8u * ql;
-    uint32_t first = 0;
-    if (go && 8u * ql < len) {
-        uint32_t a[9], c[8];
-#pragma unroll
-        for (int q = 0; q < 8; q += 4) {
-            const MtQuad v = *at<MtQuad>(ublk, boff + 4u * (k0 + (uint32_t)q));
-            a[q] = v.a; a[q + 1] = v.b; a[q + 2] = v.c; a[q + 3] = v.d;
-            uint32_t ci = k0 + (uint32_t)q + MT_M;                          // == 1 mod 4: 621 is the only piece that touches the mirror
-            ci -= ci > (uint32_t)MT_N ? MT_N : 0;
-            const MtQuad w = *at<MtQuad>(ublk, boff + 4u * ci);
-            c[q] = w.a; c[q + 1] = w.b; c[q + 2] = w.c; c[q + 3] = w.d;
-        }
-        a[8] = *at<uint32_t>(ublk, boff + 4u * (k0 + 8u));                  // <= 624: the mirror of word 0
-        first = a[0];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const uint32_t y = mt_twist(a[j], a[j + 1], c[j]);
-            a[j] = k0 + (uint32_t)j < base ? a[j] : y;
-        }
-#pragma unroll
-        for (int q = 0; q < 8; q += 4) {
-            *at<MtQuad>(ublk, boff + 4u * (k0 + (uint32_t)q)) = MtQuad{a[q], a[q + 1], a[q + 2], a[q + 3]};
-            if (k0 + (uint32_t)q < (uint32_t)MT_PAD) *at<MtQuad>(ublk, boff + 4u * ((uint32_t)MT_N + k0 + (uint32_t)q)) = MtQuad{a[q], a[q + 1], a[q + 2], a[q + 3]};
-        }
-    }
-    const uint32_t w0 = gbcast<0>(first);
-    if (go && c0 == 0u) old0 = w0;                                          // the previous generation's word 0 goes away now
-    return gen + c0 + len;
-}
-
+// (Cur and twist_chunk_group, the quad's generator cursor and its cooperative chunk twist: cge_device.hpp)
 template <bool ROLLOUT>
 struct Draws {
     uint32_t *ring;       // this env's LDS row: [0, RING) tempered words, then the 4 acceptance masks (RING bits each, bit r = ring slot r)
@@ -609,34 +529,6 @@ __device__ __forceinline__ void emit_row(const Env<IPL> &e, float *__restrict__ 
         }
     }
     *at<float>(rows, roff + 4u * (uint32_t)(14 * ni) + 4u * ql) = glob;
-}
-
-// Streams `bytes` (a multiple of 8) of the wave's LDS image to `dst` (16-byte aligned, the image's place in HBM): lane l of the
-// `nact` active lanes (the first nact of the wave) moves the 16-byte pieces l, l + nact, ... — one store instruction = nact x 16
-// CONTIGUOUS bytes, whole 128-byte lines.  (Pieces stored from registers where they arise — 64 contiguous bytes per quad and
-// instruction, every line completed by several instructions — cost 1.38x the bytes at the memory side (PMC WRITE_SIZE) and
-// 40 of the 54 us of a 262,144-env rollout step; round 4, profiles/r04_traffic_store_pattern_ab.txt.)
-template <int MAXW>                    // MAXW: words of the largest image (compile time): a full wave's pieces are read in one batch
-__device__ __forceinline__ void stream_image(const uint32_t *__restrict__ img, void *__restrict__ dst, uint32_t bytes, uint32_t lane, uint32_t nact) {
-    const uint32_t n16 = bytes >> 4;
-    if (nact == 64u) {
-        constexpr int J = (MAXW / 4 + 63) / 64;
-        uint4 v[J];
-#pragma unroll
-        for (int j = 0; j < J; ++j) {                       // all LDS reads first (past the image's end: its last piece again), then the stores
-            const uint32_t k = lane + 64u * j;
-            v[j] = *reinterpret_cast<const uint4 *>(img + 4u * (k < n16 ? k : n16 - 1u));
-        }
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-            const uint32_t k = lane + 64u * j;
-            if (k < n16) *at<uint4>(dst, 16u * k) = v[j];
-        }
-    } else {
-#pragma unroll 1
-        for (uint32_t k = lane; k < n16; k += nact) *at<uint4>(dst, 16u * k) = *reinterpret_cast<const uint4 *>(img + 4u * k);
-    }
-    if ((bytes & 8u) && lane == 0u) *at<uint2>(dst, 16u * n16) = *reinterpret_cast<const uint2 *>(img + 4u * n16);
 }
 
 struct __attribute__((aligned(8))) Half16 { uint32_t a, b, c, d; };      // a 16-byte piece at 8-byte alignment (LDS rows are 520 B apart)

@@ -99,9 +99,10 @@ def test_hospital_overflow_flag_is_raised_not_silent():
     env = cge.HospitalVectorEnv(n, autoreset_mode="Disabled")
     env.reset(seed=4)
     assert int(env.info("overflow").sum()) == 0
-    buf, w = _state_words(env, 48)
-    assert int(w[0, victim, 3] & 4095) == int(env.info("next_patient_id")[victim])
-    w[0, victim, 3] = (w[0, victim, 3] & ~np.uint32(4095)) | np.uint32(4094)
+    buf = env.snapshot()                                     # hospital's state: one 212-dword record per env, word 3 = next_id | cursor
+    w = buf[32:32 + 212 * 4 * n].view(np.uint32).reshape(n, 212)
+    assert int(w[victim, 3] & 4095) == int(env.info("next_patient_id")[victim])
+    w[victim, 3] = (w[victim, 3] & ~np.uint32(4095)) | np.uint32(4094)
     env.restore(buf)
     assert int(env.info("next_patient_id")[victim]) == 4094
     for t in range(40):

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 for RND in 1 2; do
 for L in "$@"; do
   T=$(basename $L .so)
-  CGE_AMD_LIBRARY=$R/$L timeout -k 10 400 python3 $R/bench.py --workload $W --steps $K --warmup $WU --no-cpu-baseline > $R/gpurun_out/abb_$T.json 2> $R/gpurun_out/abb_$T.err || { echo "$T failed"; tail -3 $R/gpurun_out/abb_$T.err; continue; }
+  CGE_AMD_LIBRARY=$R/$L timeout -k 10 ${ABTMO:-400} python3 $R/bench.py --workload $W --steps $K --warmup $WU --no-cpu-baseline > $R/gpurun_out/abb_$T.json 2> $R/gpurun_out/abb_$T.err || { echo "$T failed"; tail -3 $R/gpurun_out/abb_$T.err; continue; }
   python3 - "$R/gpurun_out/abb_$T.json" "$T" <<'PY'
 import json,sys
 d=json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
