@@ -1174,15 +1174,25 @@ struct QuadRing {
         }
         p = 0;
         twist_until(c.pos + FAR, active);
-#pragma unroll 1
-        while (__ballot(active && nvalid + 16 <= RW)) {
-            if (active && nvalid + 16 <= RW) {
-                uint32_t gidx = c.pos + (uint32_t)nvalid;          // (nvalid < 0: the unit the cursor stands in)
+        // every free unit: all their loads first (one round trip for the up to RW / 16 of them), then temper and park
+        {
+            constexpr int NU = RW / 16;
+            const int32_t nfree = active ? (RW - nvalid) / 16 : 0;     // (nvalid + (cursor's place in its unit) is a multiple of 16)
+            uint4 v[NU];
+#pragma unroll
+            for (int k = 0; k < NU; ++k) {
+                uint32_t gidx = c.pos + (uint32_t)(nvalid + 16 * (k < nfree ? k : 0));
                 gidx -= gidx >= (uint32_t)MT_N ? MT_N : 0;
-                const uint4 v = *reinterpret_cast<const uint4 *>(blk + gidx + 4u * ql);        // gidx is a multiple of 16
-                *reinterpret_cast<uint4 *>(ring + c.hi + 4u * ql) = make_uint4(mt_temper(v.x), mt_temper(v.y), mt_temper(v.z), mt_temper(v.w));
-                c.hi = c.hi + 16u == (uint32_t)RW ? 0u : c.hi + 16u;
-                nvalid += 16;
+                gidx -= gidx >= (uint32_t)MT_N ? MT_N : 0;
+                v[k] = *reinterpret_cast<const uint4 *>(blk + gidx + 4u * ql);                 // gidx is a multiple of 16 (a unit past the free ones: unit 0 again)
+            }
+#pragma unroll
+            for (int k = 0; k < NU; ++k) {
+                if (k < nfree) {
+                    *reinterpret_cast<uint4 *>(ring + c.hi + 4u * ql) = make_uint4(mt_temper(v[k].x), mt_temper(v[k].y), mt_temper(v[k].z), mt_temper(v[k].w));
+                    c.hi = c.hi + 16u == (uint32_t)RW ? 0u : c.hi + 16u;
+                    nvalid += 16;
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

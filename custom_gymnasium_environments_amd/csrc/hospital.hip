@@ -199,6 +199,46 @@ __device__ __forceinline__ uint32_t dept_sx(uint32_t d) { return d == 0 ? 4u : d
 __device__ __forceinline__ uint32_t dept_sy(uint32_t d) { return d == 0 ? 4u : d == 1 ? 3u : d == 2 ? 2u : d == 3 ? 4u : d == 4 ? 2u : 3u; }
 __device__ __forceinline__ uint32_t treatment_time(uint32_t sev) { return sev == 5 ? 120u : sev == 4 ? 60u : sev == 3 ? 45u : sev == 2 ? 30u : 15u; }   // :148-154
 
+// The six sub-queues' FRONT entries, fetched in one batch at the top of a step (Heads::fetch) so that the bed assignment — three
+// departments, each of which used to start with a dependent ring load, 7.8 of a wave-step's 35 us on the phase clocks — finds them in
+// registers.  Kept current by the step itself: an arrival into an empty sub-queue IS its front, a pop or a transfer re-reads the one
+// sub-queue, an insurance-delay decrement patches the copy.  An entry of an empty sub-queue is never looked at.
+struct Heads {
+    uint2 h[6];
+    __device__ __forceinline__ void fetch(const Misc &m, const Ring &rg) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) h[k] = rg.rec[q_off(k) + m.qh[k]];
+    }
+    __device__ __forceinline__ void refetch(const Misc &m, const Ring &rg, int k) {
+#pragma unroll
+        for (int K = 0; K < 6; ++K) if (k == K) h[K] = rg.rec[q_off(K) + m.qh[K]];
+    }
+};
+template <int K>
+__device__ __forceinline__ void q_push_h(Misc &m, const Ring &rg, Heads &hd, uint32_t arrival, uint32_t ins, uint32_t ttime) {
+    const bool was_empty = m.qc[K] == 0u;
+    const uint32_t id = m.next_id;
+    q_push<K>(m, rg, arrival, ins, ttime);
+    if (was_empty && m.qc[K] == 1u) hd.h[K] = make_uint2(id | (arrival << 12) | (ins << 23), ttime);
+}
+// front of a department's deque from the cached heads: the non-empty sub-queue whose front has the smallest sequence number
+template <int K0, int K1>
+__device__ __forceinline__ int q_front_h(const Misc &m, const Heads &hd, uint32_t &rec, uint32_t &slot, uint32_t &tt) {
+    int best = -1;
+    uint32_t bseq = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = K0; k <= K1; ++k) {
+        if (m.qc[k] > 0 && rec_seq(hd.h[k].x) < bseq) { bseq = rec_seq(hd.h[k].x); best = k; rec = hd.h[k].x; slot = q_off(k) + m.qh[k]; tt = hd.h[k].y; }
+    }
+    return best;
+}
+template <int G>
+__device__ __forceinline__ int dept_front_h(const Misc &m, const Heads &hd, uint32_t &rec, uint32_t &slot, uint32_t &tt) {
+    if (G == 0) return q_front_h<0, 2>(m, hd, rec, slot, tt);
+    if (G == 1) return q_front_h<3, 3>(m, hd, rec, slot, tt);
+    return q_front_h<4, 5>(m, hd, rec, slot, tt);
+}
+
 // ------------------------------------------------------------------ the lane's share of the entities
 __device__ __forceinline__ uint32_t doc_dept(uint32_t m) { return (m >> 8) & 7u; }
 __device__ __forceinline__ uint32_t doc_busy(uint32_t m) { return m >> 11; }
@@ -263,7 +303,7 @@ __device__ __forceinline__ void transfer_dept(Misc &m, const Ring &rg, int32_t &
 // department's available doctors are bit masks OR-ed over the quad (bit = bed / doctor index); every lane walks them alike and the
 // lane that owns the bed / the doctor takes the patient.
 template <int G>
-__device__ __forceinline__ void assign_dept(Misc &m, const Ring &rg, Ent &e, uint32_t ql, uint32_t now) {
+__device__ __forceinline__ void assign_dept(Misc &m, const Ring &rg, Heads &hd, Ent &e, uint32_t ql, uint32_t now) {
     constexpr int b0 = G == 0 ? 0 : G == 1 ? 8 : 18, nb = G == 0 ? 8 : G == 1 ? 6 : 22;
     constexpr uint32_t dept = G == 0 ? 0u : G == 1 ? 1u : 3u;
     uint32_t fb = 0, fd = 0;
@@ -281,10 +321,15 @@ __device__ __forceinline__ void assign_dept(Misc &m, const Ring &rg, Ent &e, uin
 #pragma unroll 1
     while (fb && fd && m.qlen(G) > 0u) {
         uint32_t rec = 0, slot = 0, tt = 0;
-        const int k = dept_front<G>(m, rg, rec, slot, tt);
+        const int k = dept_front_h<G>(m, hd, rec, slot, tt);
         const uint32_t b = (uint32_t)b0 + (uint32_t)__ffs((int)fb) - 1u, di = (uint32_t)__ffs((int)fd) - 1u;
         fb &= fb - 1u; fd &= fd - 1u;
-        if (rec_ins(rec) > 0u) { rg.rec[slot].x = rec - (1u << 23); continue; }
+        if (rec_ins(rec) > 0u) {
+            rg.rec[slot].x = rec - (1u << 23);
+#pragma unroll
+            for (int K = 0; K < 6; ++K) if (k == K) hd.h[K].x = rec - (1u << 23);
+            continue;
+        }
         const uint32_t sev = (uint32_t)(k == 0 ? 3 : k == 1 ? 4 : k == 2 ? 5 : k == 3 ? 5 : k == 4 ? 1 : 2);
         const uint32_t word = 1u | (sev << 1) | (rec_arr(rec) << 4) | (tt << 15);
 #pragma unroll
@@ -294,6 +339,7 @@ __device__ __forceinline__ void assign_dept(Misc &m, const Ring &rg, Ent &e, uin
             if (di == ent(s, ql)) { e.dmeta[s] = (e.dmeta[s] & 2047u) | ((now + tt / 2u) << 11); e.dfat[s] = dmin(100.0, e.dfat[s] + (double)(sev * 2u)); }
         m.total_wait += now - rec_arr(rec);
         q_pop_dyn(m, k, rec_arr(rec));
+        hd.refetch(m, rg, k);                                    // (a second assignment of this department in the same step: rare)
     }
 }
 
@@ -466,9 +512,11 @@ __device__ unsigned long long g_timing[2048 * 16];
 #define TICK(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = wall_clock64(); \
     if (threadIdx.x == 0 && blockIdx.x < 2048) { g_timing[blockIdx.x * 16 + k] += now_ - t_last; } t_last = now_; } while (0)
 #define TICK_DECL unsigned long long t_last = wall_clock64();
+#define TICK_RESTART t_last = wall_clock64();
 #else
 #define TICK(k)
 #define TICK_DECL
+#define TICK_RESTART
 #endif
 // ------------------------------------------------------------------ one step of one env, by its quad
 struct StepOut {
@@ -484,8 +532,8 @@ __device__ __forceinline__ void quad_step(const Params &p, const Ring &rg, int64
     TICK_DECL
     m.time += 1;
     const uint32_t now = m.time;
-    D.prepare();
-    TICK(13);
+    Heads hd;
+    hd.fetch(m, rg);                                       // needed by the bed assignment, ~5 us of draws from here
     // ---- _process_action :371-464 (draws first; the effects on the entities are applied by their owners below)
     if (a >= 0 && a <= 5) {
         if (m.navail > 0) { nurse_pick = D.randbelow(m.navail, bit_length(m.navail)); reward += 10; }
@@ -503,6 +551,7 @@ __device__ __forceinline__ void quad_step(const Params &p, const Ring &rg, int64
     else if (a == 30) reward -= 50;
     else if (a == 32) {                                                                    // transfer: 3 x popleft where len > 10
         transfer_dept<0>(m, rg, reward); transfer_dept<1>(m, rg, reward); transfer_dept<2>(m, rg, reward);
+        hd.fetch(m, rg);
     } else if (a == 33) { m.mass = 1; reward -= 100; }
     else if (a == 34) { m.mass = 0; reward += 5; }
     // ---- _generate_patients :466-525
@@ -525,11 +574,11 @@ __device__ __forceinline__ void quad_step(const Params &p, const Ring &rg, int64
             uint32_t ins = 0;
             if (D.random53() < 0.2) ins = 10u + D.randbelow(21u, 5);
             const uint32_t tt = treatment_time(sev);
-            if (sev == 5u) q_push<3>(m, rg, now, ins, tt);
-            else if (sev == 4u) q_push<1>(m, rg, now, ins, tt);
-            else if (sev == 3u) q_push<0>(m, rg, now, ins, tt);
-            else if (sev == 2u) q_push<5>(m, rg, now, ins, tt);
-            else q_push<4>(m, rg, now, ins, tt);
+            if (sev == 5u) q_push_h<3>(m, rg, hd, now, ins, tt);
+            else if (sev == 4u) q_push_h<1>(m, rg, hd, now, ins, tt);
+            else if (sev == 3u) q_push_h<0>(m, rg, hd, now, ins, tt);
+            else if (sev == 2u) q_push_h<5>(m, rg, hd, now, ins, tt);
+            else q_push_h<4>(m, rg, hd, now, ins, tt);
         }
     }
     TICK(0);
@@ -581,7 +630,7 @@ __device__ __forceinline__ void quad_step(const Params &p, const Ring &rg, int64
     }
     TICK(2);
     // queue -> bed assignment per department (EMERGENCY beds 0-7, ICU 8-13, WARD 18-39; SURGERY's queue is always empty)
-    assign_dept<0>(m, rg, e, ql, now); assign_dept<1>(m, rg, e, ql, now); assign_dept<2>(m, rg, e, ql, now);
+    assign_dept<0>(m, rg, hd, e, ql, now); assign_dept<1>(m, rg, hd, e, ql, now); assign_dept<2>(m, rg, hd, e, ql, now);
     TICK(3);
     uint32_t tired = 0;
 #pragma unroll
@@ -745,7 +794,7 @@ __device__ __forceinline__ void quad_step(const Params &p, const Ring &rg, int64
 }
 
 // the rows of the wave's envs, IMG_ROWS at a time through the LDS image (stream_image: whole 16-byte pieces of contiguous kilobytes)
-constexpr int IMG_ROWS = 4;
+constexpr int IMG_ROWS = 8;            // (registers, not LDS, bound the waves per SIMD: two passes of 8 rows instead of four of 4)
 __device__ __forceinline__ void emit_rows(const Misc &m, const Ent &e, uint32_t lane, int32_t max_steps, uint32_t *__restrict__ image, float *__restrict__ block,
                                           uint32_t rows_live) {
     const uint32_t ql = lane & (uint32_t)(QL - 1), g = lane / (uint32_t)QL;
@@ -778,12 +827,14 @@ __global__ __launch_bounds__(BLOCK, CGE_HOSP_WAVES) void step_kernel(Params p) {
     e.load(rec, ql_);
     Draws D;
     D.init(lds + g * DROW, p.mt + i * MT_STRIDE, m.pos, m.pretw, ql_);
+    D.prepare();
     const Ring rg{reinterpret_cast<uint2 *>(p.ring) + i * RING};
     const uint64_t key = ROLLOUT ? hash_env_key(p.a_seed, (uint64_t)(p.env0 + i)) : 0;
     double rsum = 0.0;
     int32_t dcount = 0;
     uint32_t fin_used = 0;                                     // terminal rows this wave has delivered to its segment (fused rollouts)
     const int ksteps = ROLLOUT ? p.k_steps : 1;
+    TICK_DECL
 #pragma unroll 1
     for (int t = 0; t < ksteps; ++t) {
         uint32_t ql = ql_;
@@ -793,6 +844,7 @@ __global__ __launch_bounds__(BLOCK, CGE_HOSP_WAVES) void step_kernel(Params p) {
         const bool reset_only = p.mode == CGE_AUTORESET_NEXT_STEP && m.needs_reset;
         StepOut o{0, 0u};
         if (!reset_only) quad_step(p, rg, i, ql, a, m, e, D, o);
+        TICK_RESTART
         const bool to_final = o.flags != 0u && p.mode == CGE_AUTORESET_SAME_STEP;
         // the terminal row of a SAME_STEP episode end: step() -> row i of final_obs_out; fused rollout -> the next slot of the wave's
         // segment of the compacted side output
@@ -814,11 +866,18 @@ __global__ __launch_bounds__(BLOCK, CGE_HOSP_WAVES) void step_kernel(Params p) {
             }
             if (dst) write_row(m, e, ql, p.max_steps, dst);
         }
+        TICK(13);
         // ---- episode reset: SAME_STEP envs that just finished, NEXT_STEP envs that finished on the previous call
         const bool reset_now = reset_only || to_final;
         if (__ballot(reset_now)) do_reset(p, reset_now, m, e, ql, D);
         if (D.ovf) m.overflow = 1;
+        TICK(9);
+        // the NEXT step's generator words now, before this step's row stores are issued: the chunk twists and the ring's loads wait
+        // (one in-order memory counter per wave) for every store issued before them — here those are a whole step old
+        if (ROLLOUT) D.prepare();
+        TICK(1);
         if (p.obs) emit_rows(m, e, lane, p.max_steps, image, p.obs + (int64_t)t * p.obs_step_stride + i0 * OBS, rows_live);
+        TICK(10);
 #ifdef CGE_HOSP_TIMING
         if (threadIdx.x == 0 && blockIdx.x < 2048) g_timing[blockIdx.x * 16 + 15] += 1;
 #endif

@@ -1,4 +1,4 @@
-"""Per-phase wall-clock of hospital's wave_step (build with -DCGE_HOSP_TIMING into tools/ab/libcge_htiming.so).
+"""Per-phase wall-clock of hospital's step, one wave = 16 envs (tools/build_variant.sh htiming hospital.hip -DCGE_HOSP_TIMING).
 usage: CGE_AMD_LIBRARY=tools/ab/libcge_htiming.so python tools/probes/hospital_timing.py"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -9,8 +9,8 @@ L = ctypes.CDLL(_native.LIB_PATH)
 env = cge.HospitalVectorEnv(131072, device="cuda:0")
 env.reset(seed=1)
 buf = (ctypes.c_ulonglong * 16)()
-names = ["action + arrivals", "DOC/BED load", "action effects + treatments", "assign_dept x3", "fatigue + store + emit", "update_queue x3 + done",
-         "NUR", "EQ", "events + misc emit", "reset", "  EQ: load", "  EQ: 10 machines", "  EQ: 15 medicines", "  top-of-step refill"]
+names = ["action + arrivals", "prepare: next step's generator words (twists + ring units)", "action effects + treatments", "assign_dept x3", "doctor fatigue",
+         "update_queue x3 + flags", "nurses", "(-)", "events + episode end", "reset", "rows: LDS image + stores", "10 machines", "15 medicines", "terminal row"]
 for chunk in range(3):
     env.rollout(20, action_seed=7, t0=chunk * 20, trajectory=True)
     torch.cuda.synchronize()
