@@ -104,7 +104,15 @@ struct Misc {
     int32_t ep_return;                     // sum of the running episode's (integer) rewards
     double wait[3];
     uint32_t sumarr[3];
-    uint32_t qh[6], qc[6], ql[6];          // ring head, count, "late" prefix length
+    uint32_t q[6];                         // per sub-queue, packed as in the record: ring head (10) | count (11) << 10 | "late" prefix length << 21
+    __device__ __forceinline__ uint32_t qh(int k) const { return q[k] & 1023u; }
+    __device__ __forceinline__ uint32_t qc(int k) const { return (q[k] >> 10) & 2047u; }
+    __device__ __forceinline__ uint32_t ql(int k) const { return q[k] >> 21; }
+    // one entry leaves at the head: head + 1 (mod the ring), count - 1, late - 1 if any (hit: 0 / 1, for the run-time-indexed pop)
+    __device__ __forceinline__ void q_advance(int K, uint32_t hit) {     // K: a constant after unrolling
+        const uint32_t w = q[K];
+        q[K] = ((w & ~1023u) | ((w + hit) & (uint32_t)(q_cap(K) - 1))) - (hit << 10) - ((w >> 21) ? hit << 21 : 0u);
+    }
     uint32_t ndept[3];                     // 25 x 3-bit nurse departments (10 per dword)
 
     uint32_t in_use;                       // 10 machine-in-use bits (was a word of the EQ group: every lane toggles its own machines' bits)
@@ -121,7 +129,7 @@ struct Misc {
 #pragma unroll
         for (int d = 0; d < 3; ++d) { wait[d] = mk_double(r[4 + 2 * d], r[5 + 2 * d]); sumarr[d] = r[10 + d]; ndept[d] = r[19 + d]; }
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { qh[k] = r[13 + k] & 1023u; qc[k] = (r[13 + k] >> 10) & 2047u; ql[k] = r[13 + k] >> 21; }
+        for (int k = 0; k < 6; ++k) q[k] = r[13 + k];
         ep_return = (int32_t)r[22];
     }
     __device__ __forceinline__ void store(uint32_t *__restrict__ rec) const {
@@ -132,12 +140,12 @@ struct Misc {
 #pragma unroll
         for (int d = 0; d < 3; ++d) { r[4 + 2 * d] = d_lo(wait[d]); r[5 + 2 * d] = d_hi(wait[d]); r[10 + d] = sumarr[d]; r[19 + d] = ndept[d]; }
 #pragma unroll
-        for (int k = 0; k < 6; ++k) r[13 + k] = qh[k] | (qc[k] << 10) | (ql[k] << 21);
+        for (int k = 0; k < 6; ++k) r[13 + k] = q[k];
         r[22] = (uint32_t)ep_return; r[23] = in_use | (navail << 16);
 #pragma unroll
         for (int c = 0; c < 6; ++c) reinterpret_cast<uint4 *>(rec)[c] = make_uint4(r[4 * c], r[4 * c + 1], r[4 * c + 2], r[4 * c + 3]);
     }
-    __device__ __forceinline__ uint32_t qlen(int d3) const { return d3 == 0 ? qc[0] + qc[1] + qc[2] : d3 == 1 ? qc[3] : qc[4] + qc[5]; }
+    __device__ __forceinline__ uint32_t qlen(int d3) const { return d3 == 0 ? qc(0) + qc(1) + qc(2) : d3 == 1 ? qc(3) : qc(4) + qc(5); }
     __device__ __forceinline__ uint32_t nurse_dept(int i) const { return (ndept[i / 10] >> (3 * (i % 10))) & 7u; }
 };
 
@@ -151,15 +159,14 @@ __device__ __forceinline__ uint32_t rec_ins(uint32_t r) { return (r >> 23) & 31u
 
 template <int K>
 __device__ __forceinline__ void q_push(Misc &m, const Ring &rg, uint32_t arrival, uint32_t ins, uint32_t ttime) {
-    if (m.qc[K] >= (uint32_t)q_cap(K) || m.next_id >= 4095u) { m.overflow = 1; return; }     // beyond any episode the dynamics can produce
-    const uint32_t p = q_off(K) + ((m.qh[K] + m.qc[K]) & (uint32_t)(q_cap(K) - 1));
+    if (m.qc(K) >= (uint32_t)q_cap(K) || m.next_id >= 4095u) { m.overflow = 1; return; }     // beyond any episode the dynamics can produce
+    const uint32_t p = q_off(K) + ((m.qh(K) + m.qc(K)) & (uint32_t)(q_cap(K) - 1));
     rg.rec[p] = make_uint2(m.next_id | (arrival << 12) | (ins << 23), ttime);
-    m.qc[K] += 1; m.sumarr[q_dept3(K)] += arrival; m.next_id += 1;
+    m.q[K] += 1u << 10; m.sumarr[q_dept3(K)] += arrival; m.next_id += 1;
 }
 template <int K>
 __device__ __forceinline__ void q_pop(Misc &m, uint32_t arrival) {
-    m.qh[K] = (m.qh[K] + 1u) & (uint32_t)(q_cap(K) - 1);
-    m.qc[K] -= 1; m.ql[K] -= m.ql[K] ? 1u : 0u; m.sumarr[q_dept3(K)] -= arrival;
+    m.q_advance(K, 1u); m.sumarr[q_dept3(K)] -= arrival;
 }
 // front of a department's deque: the head with the smallest sequence number.  Returns the sub-queue (or -1).
 template <int K0, int K1>
@@ -168,8 +175,8 @@ __device__ __forceinline__ int q_front(const Misc &m, const Ring &rg, uint32_t &
     uint32_t bseq = 0xFFFFFFFFu;
 #pragma unroll
     for (int k = K0; k <= K1; ++k) {
-        if (m.qc[k] > 0) {
-            const uint32_t p = q_off(k) + m.qh[k];
+        if (m.qc(k) > 0) {
+            const uint32_t p = q_off(k) + m.qh(k);
             const uint2 r2 = rg.rec[p];
             const uint32_t r = r2.x;
             if (rec_seq(r) < bseq) { bseq = rec_seq(r); best = k; rec = r; slot = p; tt = r2.y; }
@@ -178,15 +185,10 @@ __device__ __forceinline__ int q_front(const Misc &m, const Ring &rg, uint32_t &
     return best;
 }
 // pop with a run-time sub-queue index: arithmetic on every entry (an if-chain over q_pop<K> gets merged by the compiler
-// into m.qh[k] with a run-time k, which would move the whole bookkeeping struct to scratch memory)
+// into m.qh(k) with a run-time k, which would move the whole bookkeeping struct to scratch memory)
 __device__ __forceinline__ void q_pop_dyn(Misc &m, int k, uint32_t arrival) {
 #pragma unroll
-    for (int K = 0; K < 6; ++K) {
-        const uint32_t hit = k == K ? 1u : 0u;
-        m.qh[K] = (m.qh[K] + hit) & (uint32_t)(q_cap(K) - 1);
-        m.qc[K] -= hit;
-        m.ql[K] -= hit & (m.ql[K] ? 1u : 0u);
-    }
+    for (int K = 0; K < 6; ++K) m.q_advance(K, k == K ? 1u : 0u);
     const int d3 = k <= 2 ? 0 : k == 3 ? 1 : 2;
 #pragma unroll
     for (int d = 0; d < 3; ++d) m.sumarr[d] -= arrival & (0u - (uint32_t)(d3 == d));
@@ -207,19 +209,19 @@ struct Heads {
     uint2 h[6];
     __device__ __forceinline__ void fetch(const Misc &m, const Ring &rg) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) h[k] = rg.rec[q_off(k) + m.qh[k]];
+        for (int k = 0; k < 6; ++k) h[k] = rg.rec[q_off(k) + m.qh(k)];
     }
     __device__ __forceinline__ void refetch(const Misc &m, const Ring &rg, int k) {
 #pragma unroll
-        for (int K = 0; K < 6; ++K) if (k == K) h[K] = rg.rec[q_off(K) + m.qh[K]];
+        for (int K = 0; K < 6; ++K) if (k == K) h[K] = rg.rec[q_off(K) + m.qh(K)];
     }
 };
 template <int K>
 __device__ __forceinline__ void q_push_h(Misc &m, const Ring &rg, Heads &hd, uint32_t arrival, uint32_t ins, uint32_t ttime) {
-    const bool was_empty = m.qc[K] == 0u;
+    const bool was_empty = m.qc(K) == 0u;
     const uint32_t id = m.next_id;
     q_push<K>(m, rg, arrival, ins, ttime);
-    if (was_empty && m.qc[K] == 1u) hd.h[K] = make_uint2(id | (arrival << 12) | (ins << 23), ttime);
+    if (was_empty && m.qc(K) == 1u) hd.h[K] = make_uint2(id | (arrival << 12) | (ins << 23), ttime);
 }
 // front of a department's deque from the cached heads: the non-empty sub-queue whose front has the smallest sequence number
 template <int K0, int K1>
@@ -228,7 +230,7 @@ __device__ __forceinline__ int q_front_h(const Misc &m, const Heads &hd, uint32_
     uint32_t bseq = 0xFFFFFFFFu;
 #pragma unroll
     for (int k = K0; k <= K1; ++k) {
-        if (m.qc[k] > 0 && rec_seq(hd.h[k].x) < bseq) { bseq = rec_seq(hd.h[k].x); best = k; rec = hd.h[k].x; slot = q_off(k) + m.qh[k]; tt = hd.h[k].y; }
+        if (m.qc(k) > 0 && rec_seq(hd.h[k].x) < bseq) { bseq = rec_seq(hd.h[k].x); best = k; rec = hd.h[k].x; slot = q_off(k) + m.qh(k); tt = hd.h[k].y; }
     }
     return best;
 }
@@ -349,17 +351,17 @@ __device__ __forceinline__ void death_rolls(Misc &m, const Ring &rg, Draws &D, u
     constexpr uint32_t off = q_off(K), msk = q_cap(K) - 1;
     uint32_t j = 0;
 #pragma unroll 1
-    while (j < m.qc[K]) {
-        const uint32_t r = rg.rec[off + ((m.qh[K] + j) & msk)].x;
+    while (j < m.qc(K)) {
+        const uint32_t r = rg.rec[off + ((m.qh(K) + j) & msk)].x;
         if (!(rec_arr(r) + 60u < now)) break;                                   // sorted by arrival: nobody behind has waited longer
         if (D.random53() < 0.1) {
             m.deaths += 1; reward -= 2000;
 #pragma unroll 1
-            for (uint32_t q = j; q + 1u < m.qc[K]; ++q) {                       // close the gap (a handful of entries)
-                const uint32_t src = off + ((m.qh[K] + q + 1u) & msk), dst = off + ((m.qh[K] + q) & msk);
+            for (uint32_t q = j; q + 1u < m.qc(K); ++q) {                       // close the gap (a handful of entries)
+                const uint32_t src = off + ((m.qh(K) + q + 1u) & msk), dst = off + ((m.qh(K) + q) & msk);
                 rg.rec[dst] = rg.rec[src];
             }
-            m.qc[K] -= 1; m.sumarr[q_dept3(K)] -= rec_arr(r);
+            m.q[K] -= 1u << 10; m.sumarr[q_dept3(K)] -= rec_arr(r);
         } else { reward -= 500; ++j; }
     }
 }
@@ -368,11 +370,11 @@ template <int K>
 __device__ __forceinline__ void late_penalty(Misc &m, const Ring &rg, uint32_t now, int32_t &reward) {
     constexpr uint32_t thr = K == 0 ? 30u : 90u;
 #pragma unroll 1
-    while (m.ql[K] < m.qc[K]) {
-        const uint32_t r = rg.rec[q_off(K) + ((m.qh[K] + m.ql[K]) & (uint32_t)(q_cap(K) - 1))].x;
-        if (rec_arr(r) + thr < now) m.ql[K] += 1; else break;
+    while (m.ql(K) < m.qc(K)) {
+        const uint32_t r = rg.rec[q_off(K) + ((m.qh(K) + m.ql(K)) & (uint32_t)(q_cap(K) - 1))].x;
+        if (rec_arr(r) + thr < now) m.q[K] += 1u << 21; else break;
     }
-    reward -= (int32_t)m.ql[K] * (K == 0 ? 50 : 100);
+    reward -= (int32_t)m.ql(K) * (K == 0 ? 50 : 100);
 }
 template <int G>
 __device__ __forceinline__ void update_queue(Misc &m, const Ring &rg, Draws &D, uint32_t now, int32_t &reward) {   // :611-647 for one department
@@ -431,9 +433,9 @@ __device__ __forceinline__ void write_row(const Misc &m, const Ent &e, uint32_t 
         if (c < 30u) {
             const uint32_t d = c / 5u, s1 = c % 5u + 1u;
             uint32_t q = 0;
-            if (d == 0u) q = s1 == 3u ? m.qc[0] : s1 == 4u ? m.qc[1] : s1 == 5u ? m.qc[2] : 0u;
-            else if (d == 1u) q = s1 == 5u ? m.qc[3] : 0u;
-            else if (d == 3u) q = s1 == 1u ? m.qc[4] : s1 == 2u ? m.qc[5] : 0u;
+            if (d == 0u) q = s1 == 3u ? m.qc(0) : s1 == 4u ? m.qc(1) : s1 == 5u ? m.qc(2) : 0u;
+            else if (d == 1u) q = s1 == 5u ? m.qc(3) : 0u;
+            else if (d == 3u) q = s1 == 1u ? m.qc(4) : s1 == 2u ? m.qc(5) : 0u;
             const double v = (double)q / 10.0;
             row[131 + c] = (float)(v < 1.0 ? v : 1.0);
         }
@@ -501,7 +503,7 @@ __device__ __forceinline__ void do_reset(const Params &p, bool mine, Misc &m, En
 #pragma unroll
     for (int d = 0; d < 3; ++d) { m.wait[d] = 0.0; m.sumarr[d] = 0; }
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { m.qh[k] = 0; m.qc[k] = 0; m.ql[k] = 0; }
+    for (int k = 0; k < 6; ++k) m.q[k] = 0;
     m.ndept[0] = 0; m.ndept[1] = 0; m.ndept[2] = 0;
 #pragma unroll
     for (int k = 0; k < NNUR; ++k) m.ndept[k / 10] |= (uint32_t)(k / 4 < 6 ? k / 4 : 5) << (3 * (k % 10));
@@ -545,7 +547,7 @@ __device__ __forceinline__ void quad_step(const Params &p, const Ring &rg, int64
         doc_new = x | (y << 4) | (nd << 8);
         reward += 5;
     } else if (a >= 12 && a <= 17) {
-        const uint32_t crit = a == 12 ? m.qc[1] + m.qc[2] : a == 13 ? m.qc[3] : 0u;       // severity >= 4 in that department's queue
+        const uint32_t crit = a == 12 ? m.qc(1) + m.qc(2) : a == 13 ? m.qc(3) : 0u;       // severity >= 4 in that department's queue
         reward += 20 * (int32_t)crit;
     } else if (a >= 24 && a <= 29) reward -= 5;
     else if (a == 30) reward -= 50;
