@@ -401,6 +401,50 @@ __device__ __forceinline__ double next_gauss(Env &e, uint32_t *__restrict__ blkL
     return want ? draw_gauss(e, blkL, lw) : 0.0;
 }
 
+// reset :301-340 for every lane of a wave that resets (`active`) AT ONCE, the draws taken as in a step: candle k's ten CPython-stream
+// words (volume, regime test, high, low, open) are one plain load of READY words (mt_make_ready is wave-convergent: the lanes of a wave
+// that reset together consume alike), its gaussian comes through next_gauss(); the 1 % regime switch continues draw by draw.  Same
+// draws in the same order as reset_body() on the serial streams.  All lanes of the wave must call it (ballots inside).
+#ifndef CGE_CRYPTO_WAVE_RESET_MIN
+#define CGE_CRYPTO_WAVE_RESET_MIN 2   // resets of a workgroup in one step from which they run side by side (below: one by one through the draw-window slot)
+#endif
+template <class H>
+__device__ __forceinline__ void reset_wave(Env &e, const Params &p, H &hist, int phase, bool active, uint32_t *__restrict__ blkP, uint32_t *__restrict__ blkL) {
+    if (active) { e.cash = p.cfg.initial_balance; e.cash_kind = 0; e.holdings = 0.0; e.step = 0; e.needs_reset = 0; e.ep_return = 0.0; }
+    double price = 50000.0;
+    int slot = phase;
+#pragma unroll 1
+    for (int k = 0; k < HLEN; ++k) {
+        mt_make_ready(blkP, e.ppos, e.ppretw, WP, active);
+        uint32_t pw[WP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (active) mt_load_run<WP>(blkP + e.ppos, pw);
+        const double g = next_gauss(e, blkL, active);
+        if (active) {
+            double U[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) U[q] = u53(mt_temper(pw[2 * q]), mt_temper(pw[2 * q + 1]));
+            const double volume = 0.5 + (2.0 - 0.5) * U[0];
+            double u_hi = U[2], u_lo = U[3], u_op = U[4];
+            if (U[1] < 0.01) {                                    // :135 — rare: consume up to the regime test, continue draw by draw
+                mt_advance(e.ppos, e.ppretw, 4u);
+                MtStream sp(blkP, e.ppos, e.ppretw);
+                update_regime(e, sp);
+                u_hi = sp.random53(); u_lo = sp.random53(); u_op = sp.random53();
+                e.ppos = sp.pos; e.ppretw = sp.pretw;
+            } else {
+                mt_advance(e.ppos, e.ppretw, (uint32_t)WP);
+            }
+            price = price_update(e, p.cfg, price, volume, g);
+            const double hi = price * (1.0 + (1.02 - 1.0) * u_hi);
+            const double lo = price * (0.98 + (1.0 - 0.98) * u_lo);
+            const double op = price * (0.99 + (1.01 - 0.99) * u_op);
+            hist.put(slot, price, make_float4((float)op, (float)hi, (float)lo, (float)volume));
+        }
+        slot = slot + 1 == HLEN ? 0 : slot + 1;
+    }
+    if (active) e.close = price;
+}
+
 // NumPy pairwise sum of 14 / 20 float64 values (loops_utils.h.src): 8 running partials, a balanced
 // tree, then the tail added sequentially.
 struct Pairwise {
@@ -879,6 +923,18 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
         if (rm) {
             full_barrier();                                      // bar3: B's pre-reset rows are out, C's stream state is in LDS
             const uint32_t rank = (uint32_t)__popcll(rm & ((1ull << lane) - 1ull));
+            if ((uint32_t)__popcll(rm) >= (uint32_t)CGE_CRYPTO_WAVE_RESET_MIN) {
+                // several envs of the workgroup at once (every env at a shared time limit): side by side, draws straight from the
+                // streams' ready words — taking turns on the one draw-window slot cost 64 x ~80 us per workgroup, 262 ms of a
+                // 1M-env episode (profiles/r04_crypto_wave_reset.txt)
+                if (reset_now) { lcur_unpack(e, m_lcur); e.gauss = m_lcache; }
+                reset_wave(e, p, hist, next_phase, reset_now, blkP, blkL);
+                if (reset_now) {
+                    m_lcur = lcur_pack(e); m_lcache = e.gauss;
+                    mail[0] = e.cash; mail[64] = e.holdings; mail[128] = e.psych; mail[192] = e.close;
+                    *mailu = e.cash_kind | F_RESET | F_DRAW_NEXT;
+                }
+            } else {
 #pragma unroll 1
             for (uint32_t round = 0; round * RES_SLOTS < (uint32_t)__popcll(rm); ++round) {
                 if (reset_now && rank / RES_SLOTS == round) {
@@ -893,6 +949,7 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
                     mail[0] = e.cash; mail[64] = e.holdings; mail[128] = e.psych; mail[192] = e.close;
                     *mailu = e.cash_kind | F_RESET | F_DRAW_NEXT;
                 }
+            }
             }
             mt_make_ready(blkP, e.ppos, e.ppretw, WP, reset_now);   // the prefetched words belonged to the finished episode's cursor
             if (t + 1 < p.k_steps && reset_now) mt_load_run<WP>(blkP + e.ppos, pw);

@@ -391,16 +391,49 @@ __device__ __forceinline__ void update_queue(Misc &m, const Ring &rg, Draws &D, 
 // LDS image, or — a SAME_STEP terminal row, rare — its row of final_obs in global memory.  Doctors [0:45], nurse counts [45:51],
 // beds [51:131], queue histogram [131:161], machines [161:171], medicines [171:186], utilisation [186:192] (:713-724), waits
 // [192:198], doctor fatigue [198:213], nurse fatigue [213:238], deaths / treated / time / outbreak / mass [238:243].
-__device__ __forceinline__ void write_row(const Misc &m, const Ent &e, uint32_t ql, int32_t max_steps, float *__restrict__ row) {
+//
+// The reference divides in float64 and stores float32.  50 of a lane's ~66 quotients per row are (small integer) / constant: those
+// come from a table of the SAME expression evaluated by the compiler ((float)((double)k / c): IEEE arithmetic, nothing to round
+// differently) parked in LDS; a float64 division is ~30 instructions at half rate on this part and the row was a third of the
+// step's vector instructions.  The float64 fatigues and waits keep a real division: by a constant, as Markstein's correction step.
+constexpr int L20 = 0, L5 = 16, L10 = 24, LOCC = 56, L100 = 184, LUT_N = 448;      // k/20 (16) | k/5 (8) | min(k,10)/10 .. k/10 (32) | k/{8,6,4,22} (4 x 32) | k/100 (256)
+struct RowLut { float v[LUT_N]; };
+constexpr RowLut make_row_lut() {
+    RowLut t{};
+    for (int k = 0; k < 16; ++k) t.v[L20 + k] = (float)((double)k / 20.0);
+    for (int k = 0; k < 8; ++k) t.v[L5 + k] = (float)((double)k / 5.0);
+    for (int k = 0; k < 32; ++k) t.v[L10 + k] = (float)((double)k / 10.0);
+    for (int k = 0; k < 32; ++k) {
+        t.v[LOCC + k] = (float)((double)k / 8.0); t.v[LOCC + 32 + k] = (float)((double)k / 6.0);
+        t.v[LOCC + 64 + k] = (float)((double)k / 4.0); t.v[LOCC + 96 + k] = (float)((double)k / 22.0);
+    }
+    for (int k = 0; k < 256; ++k) t.v[L100 + k] = (float)((double)k / 100.0);
+    return t;
+}
+__device__ const RowLut g_row_lut = make_row_lut();
+__device__ __forceinline__ void park_row_lut(float *__restrict__ lut, uint32_t lane) {      // one workgroup's copy (64 lanes)
+#pragma unroll
+    for (int j = 0; j < LUT_N / 64; ++j) lut[lane + 64u * j] = g_row_lut.v[lane + 64u * j];
+}
+// a / B for a float64 a and a constant B, correctly rounded: q = RN(a y) with y = RN(1 / B) is a faithful quotient, the residual
+// r = a - B q is exact in an fma, and RN(q + r y) is the correctly rounded quotient (Markstein 1990; the exception, a significand of B
+// of all ones, is not 100 or 60).  a is a fatigue or a mean wait: 0 or far above the subnormal range, far below overflow.
+template <int B>
+__device__ __forceinline__ double div_const(double a) {
+    constexpr double b = (double)B, y = 1.0 / b;
+    const double q = a * y, r = __builtin_fma(-b, q, a);
+    return __builtin_fma(r, y, q);
+}
+__device__ __forceinline__ void write_row(const Misc &m, const Ent &e, uint32_t ql, int32_t max_steps, const float *__restrict__ lut, float *__restrict__ row) {
     const uint32_t now = m.time;
 #pragma unroll
     for (int s = 0; s < SDOC; ++s) {
         const uint32_t k = ent(s, ql);
         if (k < (uint32_t)NDOC) {
-            row[3 * k] = (float)((double)(e.dmeta[s] & 15u) / 20.0);
-            row[3 * k + 1] = (float)((double)((e.dmeta[s] >> 4) & 15u) / 20.0);
+            row[3 * k] = lut[L20 + (e.dmeta[s] & 15u)];
+            row[3 * k + 1] = lut[L20 + ((e.dmeta[s] >> 4) & 15u)];
             row[3 * k + 2] = doc_busy(e.dmeta[s]) > now ? 1.0f : 0.0f;
-            row[198 + k] = (float)(e.dfat[s] / 100.0);
+            row[198 + k] = (float)div_const<100>(e.dfat[s]);
         }
     }
     uint32_t occ = 0;                                            // occupied beds per bed department, 5 bits each
@@ -408,7 +441,7 @@ __device__ __forceinline__ void write_row(const Misc &m, const Ent &e, uint32_t 
     for (int s = 0; s < SBED; ++s) {
         const uint32_t b = ent(s, ql), w = e.bed[s];
         row[51 + 2 * b] = (w & 1u) ? 1.0f : 0.0f;
-        row[52 + 2 * b] = (float)((double)((w >> 1) & 7u) / 5.0);
+        row[52 + 2 * b] = lut[L5 + ((w >> 1) & 7u)];
         occ += (w & 1u) << (5u * (b < 8u ? 0u : b < 14u ? 1u : b < 18u ? 2u : 3u));
     }
     occ = gsum(occ);
@@ -417,7 +450,7 @@ __device__ __forceinline__ void write_row(const Misc &m, const Ent &e, uint32_t 
     for (int s = 0; s < SNUR; ++s) {
         const uint32_t k = ent(s, ql);
         if (k < (uint32_t)NNUR) {
-            row[213 + k] = (float)(e.nfat[s] / 100.0);
+            row[213 + k] = (float)div_const<100>(e.nfat[s]);
             nc += 1u << (5u * ((sel<3>(m.ndept, k / 10u) >> (3u * (k % 10u))) & 7u));   // (sel: a run-time index would move Misc to scratch)
         }
     }
@@ -425,7 +458,7 @@ __device__ __forceinline__ void write_row(const Misc &m, const Ent &e, uint32_t 
 #pragma unroll
     for (int s = 0; s < SEQ; ++s) { const uint32_t k = ent(s, ql); if (k < (uint32_t)NEQ) row[161 + k] = (float)e.eqs[s]; }
 #pragma unroll
-    for (int s = 0; s < SMED; ++s) { const uint32_t k = ent(s, ql); if (k < (uint32_t)NMED) row[171 + k] = (float)((double)e.med[s] / 100.0); }
+    for (int s = 0; s < SMED; ++s) { const uint32_t k = ent(s, ql); if (k < (uint32_t)NMED) row[171 + k] = lut[L100 + (e.med[s] & 255u)]; }
     // env-wide columns, dealt to the lanes: lane ql takes the entries j = ql (mod 4) of each block
 #pragma unroll
     for (int j4 = 0; j4 < 8; ++j4) {                               // queue histogram: department d, severity s + 1 -> min(count / 10, 1)
@@ -436,19 +469,17 @@ __device__ __forceinline__ void write_row(const Misc &m, const Ent &e, uint32_t 
             if (d == 0u) q = s1 == 3u ? m.qc(0) : s1 == 4u ? m.qc(1) : s1 == 5u ? m.qc(2) : 0u;
             else if (d == 1u) q = s1 == 5u ? m.qc(3) : 0u;
             else if (d == 3u) q = s1 == 1u ? m.qc(4) : s1 == 2u ? m.qc(5) : 0u;
-            const double v = (double)q / 10.0;
-            row[131 + c] = (float)(v < 1.0 ? v : 1.0);
+            row[131 + c] = lut[L10 + (q < 10u ? q : 10u)];
         }
     }
 #pragma unroll
     for (int j4 = 0; j4 < 2; ++j4) {
         const uint32_t d = 4u * (uint32_t)j4 + ql;
         if (d < 6u) {
-            row[45 + d] = (float)((double)((nc >> (5u * d)) & 31u) / 10.0);
+            row[45 + d] = lut[L10 + ((nc >> (5u * d)) & 31u)];
             const uint32_t o = d < 4u ? (occ >> (5u * d)) & 31u : 0u;
-            row[186 + d] = d == 0u ? (float)((double)o / 8.0) : d == 1u ? (float)((double)o / 6.0) : d == 2u ? (float)((double)o / 4.0)
-                           : d == 3u ? (float)((double)o / 22.0) : 0.0f;
-            const double w = d == 0u ? m.wait[0] : d == 1u ? m.wait[1] : d == 3u ? m.wait[2] : 0.0, v = w / 60.0;
+            row[186 + d] = d < 4u ? lut[LOCC + 32u * d + o] : 0.0f;
+            const double w = d == 0u ? m.wait[0] : d == 1u ? m.wait[1] : d == 3u ? m.wait[2] : 0.0, v = div_const<60>(w);
             row[192 + d] = (float)(v < 1.0 ? v : 1.0);
         }
     }
@@ -797,12 +828,12 @@ __device__ __forceinline__ void quad_step(const Params &p, const Ring &rg, int64
 
 // the rows of the wave's envs, IMG_ROWS at a time through the LDS image (stream_image: whole 16-byte pieces of contiguous kilobytes)
 constexpr int IMG_ROWS = 8;            // (registers, not LDS, bound the waves per SIMD: two passes of 8 rows instead of four of 4)
-__device__ __forceinline__ void emit_rows(const Misc &m, const Ent &e, uint32_t lane, int32_t max_steps, uint32_t *__restrict__ image, float *__restrict__ block,
+__device__ __forceinline__ void emit_rows(const Misc &m, const Ent &e, uint32_t lane, int32_t max_steps, const float *__restrict__ lut, uint32_t *__restrict__ image, float *__restrict__ block,
                                           uint32_t rows_live) {
     const uint32_t ql = lane & (uint32_t)(QL - 1), g = lane / (uint32_t)QL;
 #pragma unroll 1
     for (uint32_t pass = 0; pass * IMG_ROWS < rows_live; ++pass) {
-        if (g / IMG_ROWS == pass) write_row(m, e, ql, max_steps, reinterpret_cast<float *>(image) + (g % IMG_ROWS) * OBS);
+        if (g / IMG_ROWS == pass) write_row(m, e, ql, max_steps, lut, reinterpret_cast<float *>(image) + (g % IMG_ROWS) * OBS);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const uint32_t rows = rows_live - pass * IMG_ROWS < (uint32_t)IMG_ROWS ? rows_live - pass * IMG_ROWS : (uint32_t)IMG_ROWS;
         stream_image<IMG_ROWS * OBS>(image, block + (size_t)pass * IMG_ROWS * OBS, rows * (uint32_t)(OBS * 4), lane, rows_live * QL < 64u ? rows_live * QL : 64u);
@@ -815,11 +846,14 @@ __device__ __forceinline__ void emit_rows(const Misc &m, const Ent &e, uint32_t 
 #endif
 template <bool ROLLOUT>
 __global__ __launch_bounds__(BLOCK, CGE_HOSP_WAVES) void step_kernel(Params p) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[EPW * DROW + IMG_ROWS * OBS];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[EPW * DROW + IMG_ROWS * OBS + LUT_N];
     uint32_t *const image = lds + EPW * DROW;
+    float *const lut = reinterpret_cast<float *>(lds + EPW * DROW + IMG_ROWS * OBS);
     const uint32_t lane = threadIdx.x, ql_ = lane & (uint32_t)(QL - 1), g = lane / (uint32_t)QL;
     const uint32_t chunk = (blockIdx.x & 7u) * p.per_xcd + (blockIdx.x >> 3);      // XCD x serves chunks [x per_xcd, (x + 1) per_xcd)
     const int64_t i0 = (int64_t)chunk * EPW, i = i0 + g;
+    park_row_lut(lut, lane);                                                      // all 64 lanes, before any quad leaves
+    asm volatile("" ::: "memory");
     if (chunk >= p.nwaves || i >= p.n) return;                                    // whole quads leave; no barrier anywhere below
     const uint32_t rows_live = p.n - i0 < EPW ? (uint32_t)(p.n - i0) : (uint32_t)EPW;
     uint32_t *rec = p.state + i * REC_W;
@@ -866,7 +900,7 @@ __global__ __launch_bounds__(BLOCK, CGE_HOSP_WAVES) void step_kernel(Params p) {
                 }
                 fin_used += (uint32_t)__popcll(fin_mask);
             }
-            if (dst) write_row(m, e, ql, p.max_steps, dst);
+            if (dst) write_row(m, e, ql, p.max_steps, lut, dst);
         }
         TICK(13);
         // ---- episode reset: SAME_STEP envs that just finished, NEXT_STEP envs that finished on the previous call
@@ -878,7 +912,7 @@ __global__ __launch_bounds__(BLOCK, CGE_HOSP_WAVES) void step_kernel(Params p) {
         // (one in-order memory counter per wave) for every store issued before them — here those are a whole step old
         if (ROLLOUT) D.prepare();
         TICK(1);
-        if (p.obs) emit_rows(m, e, lane, p.max_steps, image, p.obs + (int64_t)t * p.obs_step_stride + i0 * OBS, rows_live);
+        if (p.obs) emit_rows(m, e, lane, p.max_steps, lut, image, p.obs + (int64_t)t * p.obs_step_stride + i0 * OBS, rows_live);
         TICK(10);
 #ifdef CGE_HOSP_TIMING
         if (threadIdx.x == 0 && blockIdx.x < 2048) g_timing[blockIdx.x * 16 + 15] += 1;
@@ -911,8 +945,11 @@ __global__ __launch_bounds__(BLOCK, CGE_HOSP_WAVES) void step_kernel(Params p) {
 // what: 0 = reset(mask) + obs, 1 = rewind the generator cursor after seeding, 2 = fresh-handle state.  Quads as in the step kernel.
 __global__ __launch_bounds__(BLOCK) void reset_kernel(Params p, int what) {
     __shared__ uint32_t draws[EPW * DROW];
+    __shared__ float lut[LUT_N];
     const uint32_t lane = threadIdx.x, ql = lane & (uint32_t)(QL - 1), g = lane / (uint32_t)QL;
     const int64_t i = (int64_t)blockIdx.x * EPW + g;
+    park_row_lut(lut, lane);
+    asm volatile("" ::: "memory");
     if (i >= p.n) return;
     uint32_t *rec = p.state + i * REC_W;
     Misc m;
@@ -940,7 +977,7 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(Params p, int what) {
         if (ql == 0u) m.store(rec);
         e.store(rec, ql);
     }
-    if (p.obs) write_row(m, e, ql, p.max_steps, p.obs + i * OBS);
+    if (p.obs) write_row(m, e, ql, p.max_steps, lut, p.obs + i * OBS);
 }
 
 __global__ __launch_bounds__(256) void info_kernel(const uint32_t *__restrict__ state, int64_t n, int field, double *__restrict__ out) {
