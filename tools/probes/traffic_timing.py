@@ -11,7 +11,11 @@ env.reset(seed=1)
 buf = (ctypes.c_ulonglong * 16)()
 names = ["kernel start (record load)", "prepare: ring top-up + view (+ the previous step's stores draining)", "actions (hash) + lights", "draws + their effects",
          "process vehicles + reward", "final_obs / reset", "observation row"]
-for chunk in range(3):
+for chunk in (0, 1, 2, 16, 17):                     # steps 0-89 (vehicles still spawning every step), then 480-539 (saturated)
+    if chunk == 16:
+        env.rollout(390, action_seed=7, t0=90)
+        torch.cuda.synchronize()
+        L.cge_traffic_debug_timing(buf, 1)
     env.rollout(30, action_seed=7, t0=chunk * 30, trajectory=True)
     torch.cuda.synchronize()
     L.cge_traffic_debug_timing(buf, 1)
