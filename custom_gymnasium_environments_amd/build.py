@@ -30,10 +30,10 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-# Debug builds (extra_flags): -DCGE_MFG_GUARD bounds-checks every table index of the manufacturing kernel and records the first
-# violation instead of dereferencing it (`python -m custom_gymnasium_environments_amd.build --guard` writes libcge_amd_guard.so next to
-# the release library; tools/probes/mfg_guard.py replays the reference fixtures through it).  -DCGE_<ENV>_TIMING: on-device phase clocks.
-GUARD_FLAGS = ("-DCGE_MFG_GUARD",)
+# Debug builds (extra_flags): -DCGE_MFG_GUARD bounds-checks every table index of the manufacturing kernel, -DCGE_GUARD the ring / draw-window /
+# work-list indices of the hospital and fleet kernels (cge_device.hpp: CGE_GX); the first violation is recorded instead of dereferenced (`python -m custom_gymnasium_environments_amd.build --guard` writes libcge_amd_guard.so next to
+# the release library; tools/probes/guard_run.py replays the reference fixtures through it).  -DCGE_<ENV>_TIMING: on-device phase clocks.
+GUARD_FLAGS = ("-DCGE_MFG_GUARD", "-DCGE_GUARD")
 
 
 def build_native(force=False, verbose=False, extra_flags=(), out=None):

@@ -784,6 +784,23 @@ struct RingDraws {
     }
 };
 
+// Bounds-checked debug build (-DCGE_GUARD: `python -m custom_gymnasium_environments_amd.build --guard`, probe tools/probes/guard_run.py): the
+// ring / work-list / window indices of the hospital and fleet kernels go through CGE_GX(site, index, limit).  An index outside its table
+// is RECORDED (first violation: site, index, limit, block, lane; plus a count; one record per translation unit, read back through
+// cge_<env>_debug_guard) and replaced by 0 instead of being dereferenced.  Release builds: CGE_GX is the index.  (Manufacturing's tables
+// have the same under -DCGE_MFG_GUARD, manufacturing.hip.)
+#ifdef CGE_GUARD
+static __device__ unsigned int g_guard[8];
+__device__ __forceinline__ uint32_t guard_index(int site_, uint32_t index, uint32_t limit) {
+    if (index < limit) return index;
+    if (atomicAdd(&g_guard[0], 1u) == 0u) { g_guard[1] = (unsigned)site_; g_guard[2] = index; g_guard[3] = limit; g_guard[4] = blockIdx.x; g_guard[5] = threadIdx.x; }
+    return 0u;
+}
+#define CGE_GX(site_, index, limit) guard_index(site_, (uint32_t)(index), (uint32_t)(limit))
+#else
+#define CGE_GX(site_, index, limit) (index)
+#endif
+
 // readlane with a wave-uniform lane index; the builtin is typed int, so cast back before widening
 __device__ __forceinline__ uint32_t lane_u32(uint32_t v, int r) { return (uint32_t)__builtin_amdgcn_readlane((int)v, r); }
 __device__ __forceinline__ uint32_t *lane_ptr(uint32_t lo, uint32_t hi, int r) {
@@ -1206,11 +1223,11 @@ struct QuadRing {
     }
     __device__ __forceinline__ uint32_t next() {
         const uint32_t j = p++;
-        return (int32_t)j < nvalid ? ring[slot(j)] : far_word(j);
+        return (int32_t)j < nvalid ? ring[CGE_GX(20, slot(j), RW)] : far_word(j);
     }
     // look-ahead for draw sequences whose word OFFSETS can be computed up front
     __device__ __forceinline__ bool has(uint32_t n) const { return (int32_t)(p + n) <= nvalid; }
-    __device__ __forceinline__ uint32_t peek(uint32_t j) const { return ring[slot(p + j)]; }
+    __device__ __forceinline__ uint32_t peek(uint32_t j) const { return ring[CGE_GX(21, slot(p + j), RW)]; }
     __device__ __forceinline__ void skip(uint32_t n) { p += n; }
     __device__ __forceinline__ uint32_t randbelow(uint32_t n, int kbits) {   // CPython _randbelow_with_getrandbits
         uint32_t r = next() >> (32 - kbits);

@@ -467,7 +467,7 @@ __device__ __forceinline__ void lane_step(const Params &p, Env &e, int64_t i, ui
         (void)wave_id;
         const uint32_t sub = (uint32_t)(i / BLOCK) % (uint32_t)NSUB;
         const uint32_t slot = atomicAdd(work_counter(p.work_count, p.parity, sub), 1u);
-        work_sublist(p, p.parity, sub)[slot] = work_entry(i, work, e.lpos, e.lpretw, e.ppos, e.ppretw);
+        work_sublist(p, p.parity, sub)[CGE_GX(1, slot, p.sub_cap)] = work_entry(i, work, e.lpos, e.lpretw, e.ppos, e.ppretw);
     }
     if (p.accumulate) {
         if (p.reward_sum) p.reward_sum[i] += reward;
@@ -571,8 +571,8 @@ __global__ __launch_bounds__(BLOCK) void dense_kernel(Params p, int what) {
             for (int b = NSUB / 2; b; b >>= 1)
                 if ((uint32_t)__shfl((int)sub_end, (int)(sub + b - 1), 64) <= g) sub += b;
             const uint32_t before = (uint32_t)__shfl((int)(sub_end - sub_n), (int)sub, 64);
-            const uint64_t entry = work_sublist(p, serve, sub)[g - before];
-            i = (int64_t)(entry >> 25);
+            const uint64_t entry = work_sublist(p, serve, sub)[CGE_GX(2, g - before, p.sub_cap)];
+            i = (int64_t)CGE_GX(3, entry >> 25, p.n);
             work = live ? (uint32_t)(entry & 7u) : 0u;
             lcur = (uint32_t)(entry >> 14) & 2047u; pcur = (uint32_t)(entry >> 3) & 2047u;
         } else {
@@ -794,6 +794,12 @@ struct cge_fleet : HandleBase {
 };
 
 extern "C" {
+
+#ifdef CGE_GUARD
+int cge_fleet_debug_guard(unsigned int *out) {         // [count, site, index, limit, block, lane, 0, 0] of the first violation (cge_device.hpp: CGE_GX)
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(cge::g_guard), 8 * sizeof(unsigned int)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 #ifdef CGE_FLEET_TIMING
 int cge_fleet_debug_timing(unsigned long long *out, int clear) {

@@ -161,7 +161,7 @@ template <int K>
 __device__ __forceinline__ void q_push(Misc &m, const Ring &rg, uint32_t arrival, uint32_t ins, uint32_t ttime) {
     if (m.qc(K) >= (uint32_t)q_cap(K) || m.next_id >= 4095u) { m.overflow = 1; return; }     // beyond any episode the dynamics can produce
     const uint32_t p = q_off(K) + ((m.qh(K) + m.qc(K)) & (uint32_t)(q_cap(K) - 1));
-    rg.rec[p] = make_uint2(m.next_id | (arrival << 12) | (ins << 23), ttime);
+    rg.rec[CGE_GX(1, p, RING)] = make_uint2(m.next_id | (arrival << 12) | (ins << 23), ttime);
     m.q[K] += 1u << 10; m.sumarr[q_dept3(K)] += arrival; m.next_id += 1;
 }
 template <int K>
@@ -177,7 +177,7 @@ __device__ __forceinline__ int q_front(const Misc &m, const Ring &rg, uint32_t &
     for (int k = K0; k <= K1; ++k) {
         if (m.qc(k) > 0) {
             const uint32_t p = q_off(k) + m.qh(k);
-            const uint2 r2 = rg.rec[p];
+            const uint2 r2 = rg.rec[CGE_GX(2, p, RING)];
             const uint32_t r = r2.x;
             if (rec_seq(r) < bseq) { bseq = rec_seq(r); best = k; rec = r; slot = p; tt = r2.y; }
         }
@@ -209,11 +209,11 @@ struct Heads {
     uint2 h[6];
     __device__ __forceinline__ void fetch(const Misc &m, const Ring &rg) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) h[k] = rg.rec[q_off(k) + m.qh(k)];
+        for (int k = 0; k < 6; ++k) h[k] = rg.rec[CGE_GX(3, q_off(k) + m.qh(k), RING)];
     }
     __device__ __forceinline__ void refetch(const Misc &m, const Ring &rg, int k) {
 #pragma unroll
-        for (int K = 0; K < 6; ++K) if (k == K) h[K] = rg.rec[q_off(K) + m.qh(K)];
+        for (int K = 0; K < 6; ++K) if (k == K) h[K] = rg.rec[CGE_GX(4, q_off(K) + m.qh(K), RING)];
     }
 };
 template <int K>
@@ -327,7 +327,7 @@ __device__ __forceinline__ void assign_dept(Misc &m, const Ring &rg, Heads &hd, 
         const uint32_t b = (uint32_t)b0 + (uint32_t)__ffs((int)fb) - 1u, di = (uint32_t)__ffs((int)fd) - 1u;
         fb &= fb - 1u; fd &= fd - 1u;
         if (rec_ins(rec) > 0u) {
-            rg.rec[slot].x = rec - (1u << 23);
+            rg.rec[CGE_GX(5, slot, RING)].x = rec - (1u << 23);
 #pragma unroll
             for (int K = 0; K < 6; ++K) if (k == K) hd.h[K].x = rec - (1u << 23);
             continue;
@@ -352,14 +352,14 @@ __device__ __forceinline__ void death_rolls(Misc &m, const Ring &rg, Draws &D, u
     uint32_t j = 0;
 #pragma unroll 1
     while (j < m.qc(K)) {
-        const uint32_t r = rg.rec[off + ((m.qh(K) + j) & msk)].x;
+        const uint32_t r = rg.rec[CGE_GX(6, off + ((m.qh(K) + j) & msk), RING)].x;
         if (!(rec_arr(r) + 60u < now)) break;                                   // sorted by arrival: nobody behind has waited longer
         if (D.random53() < 0.1) {
             m.deaths += 1; reward -= 2000;
 #pragma unroll 1
             for (uint32_t q = j; q + 1u < m.qc(K); ++q) {                       // close the gap (a handful of entries)
                 const uint32_t src = off + ((m.qh(K) + q + 1u) & msk), dst = off + ((m.qh(K) + q) & msk);
-                rg.rec[dst] = rg.rec[src];
+                rg.rec[CGE_GX(7, dst, RING)] = rg.rec[CGE_GX(8, src, RING)];
             }
             m.q[K] -= 1u << 10; m.sumarr[q_dept3(K)] -= rec_arr(r);
         } else { reward -= 500; ++j; }
@@ -371,7 +371,7 @@ __device__ __forceinline__ void late_penalty(Misc &m, const Ring &rg, uint32_t n
     constexpr uint32_t thr = K == 0 ? 30u : 90u;
 #pragma unroll 1
     while (m.ql(K) < m.qc(K)) {
-        const uint32_t r = rg.rec[q_off(K) + ((m.qh(K) + m.ql(K)) & (uint32_t)(q_cap(K) - 1))].x;
+        const uint32_t r = rg.rec[CGE_GX(9, q_off(K) + ((m.qh(K) + m.ql(K)) & (uint32_t)(q_cap(K) - 1)), RING)].x;
         if (rec_arr(r) + thr < now) m.q[K] += 1u << 21; else break;
     }
     reward -= (int32_t)m.ql(K) * (K == 0 ? 50 : 100);
@@ -1039,6 +1039,12 @@ struct cge_hospital : HandleBase {
 };
 
 extern "C" {
+
+#ifdef CGE_GUARD
+int cge_hospital_debug_guard(unsigned int *out) {      // [count, site, index, limit, block, lane, 0, 0] of the first violation (cge_device.hpp: CGE_GX)
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(cge::g_guard), 8 * sizeof(unsigned int)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 #ifdef CGE_HOSP_TIMING
 int cge_hospital_debug_timing(unsigned long long *out, int clear) {

@@ -170,7 +170,7 @@ struct Env {
     }
 };
 
-// Bounds-checked debug build (-DCGE_MFG_GUARD: `python -m custom_gymnasium_environments_amd.build --guard`, probe tools/probes/mfg_guard.py):
+// Bounds-checked debug build (-DCGE_MFG_GUARD: `python -m custom_gymnasium_environments_amd.build --guard`, probe tools/probes/guard_run.py):
 // every [row][env] table index goes through GX(site, index, limit); an index outside its table is RECORDED (first violation: site,
 // index, limit, block, lane; plus a count) and replaced by row 0 instead of being dereferenced — the out-of-range store of round 3's
 // dense-list rewrite aborted the process at the next copy to the host, far from its cause.  Release builds: GX is the index.
