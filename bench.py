@@ -317,7 +317,7 @@ def main():
     ap.add_argument("--path", default="rollout", choices=["rollout", "step"])
     ap.add_argument("--traj-gib", type=float, default=None,
                     help="cap on the per-env-type trajectory buffer of the rollout leg (default 24; crypto_1m 128: its rows are 1,044 B, and a launch "
-                         "should be long enough to amortise the 1,200-byte window load — 117 steps per launch on the 288-GB part)")
+                         "should be long enough to amortise the 1,200-byte window load — 125 steps per launch on the 288-GB part)")
     ap.add_argument("--manifest", default=None, help="write {kernel: env-steps launched} here (tools/profile.sh uses it to turn PMC bytes into bytes per env-step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--repeats", type=int, default=9, help="the K-step timed region is run this many times; value / ms_per_step = the median region")

@@ -24,8 +24,10 @@
 //     view (rare) redoes the step's draws word by word (slow_draws);
 //   * the ring is refilled 16 words (64 B, one 16-byte load per lane) at a time from words the group twisted ahead of the cursor,
 //     32 words = one 128-byte line per cooperative twist (twist_chunk_group; layout and ready marks as cge_device.hpp: mt_twist_chunk);
-//   * a lane stores the 16-byte pieces of its intersections' observation columns straight from registers; a quad's pieces are
-//     64 contiguous bytes, the four global features one dword per lane;
+//   * the observation rows leave through an LDS image of 8 consecutive rows that the wave streams out as whole 128-byte lines
+//     (emit_staged / stream_image); stored as 16-byte pieces from the registers where they arise — 64 contiguous bytes per quad and
+//     instruction, every line completed by several instructions — they cost 1.38x the bytes at the memory side and 40 of a step's
+//     54 us (profiles/r04_traffic_store_pattern_ab.txt); only the rare terminal rows still go out piecewise (emit_row);
 //   * the state is array-of-structs (one 8 + 6 NI dword record per env): a wave loads / stores 16 consecutive records;
 //   * waves are dealt to the XCDs in contiguous runs (block b -> chunk (b % 8) * per_xcd + b / 8), so the 64-byte reward and
 //     16-byte flag pieces that neighbouring waves write into one 128-byte line meet in ONE L2;

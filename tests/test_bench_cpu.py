@@ -87,3 +87,15 @@ def test_hetero_coresident_weak_scaling_at_2():
     assert p.returncode == 0, p.stderr[-2000:]
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
     assert out["scaling"] == "weak" and out["n_gpus"] == 2 and len(out["config"]["env_types"]) == 8
+
+
+def test_episode_and_repeats_shape_the_line():
+    """--episode: K := the workload's episode length; --repeats R: the K-step region is timed R times, `ms_per_step` is the median
+    region and `spread` carries min / max / every sample."""
+    p = _run([sys.executable, "bench.py", "--workload", "fleet_131k", "--episode", "--warmup", "1", "--repeats", "3", "--no-cpu-baseline"],
+             {"CGE_BENCH_DRYRUN": "1", "OMP_NUM_THREADS": "1"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["steps"] == 800 and out["spread"]["repeats"] == 3 and len(out["spread"]["all_ms_per_step"]) == 3
+    assert out["spread"]["min_ms_per_step"] <= out["ms_per_step"] <= out["spread"]["max_ms_per_step"]
+    assert sorted(out["spread"]["all_ms_per_step"])[1] == out["ms_per_step"]
