@@ -714,8 +714,8 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // wait for the waves' own stores and loads.
 __device__ __forceinline__ void full_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #ifdef CGE_CRYPTO_TIMING
-__device__ unsigned long long g_timing[16384 * 8];
-#define TICK(k) do { const unsigned long long now_ = wall_clock64(); if (lane == 0) { g_timing[blockIdx.x * 8 + k] += now_ - t_last; } t_last = now_; } while (0)
+__device__ unsigned long long g_timing[16384 * 16];     // slots 0-6: the phases between the barriers; 8-10: inside wave A's first half; 15: workgroup-steps
+#define TICK(k) do { const unsigned long long now_ = wall_clock64(); if (lane == 0) { g_timing[blockIdx.x * 16 + k] += now_ - t_last; } t_last = now_; } while (0)
 #else
 #define TICK(k)
 #endif
@@ -879,7 +879,17 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
                     a = p.actions ? reinterpret_cast<const int32_t *>(p.actions)[(int64_t)t * p.n + i]
                                   : (int32_t)hash_action_from_key(key, (uint64_t)(p.t0 + t), 5u, 0u);
                 }
+#ifdef CGE_CRYPTO_TIMING
+                asm volatile("" :: "v"(a), "v"(ab), "v"(as));
+                TICK(8);                                         // action (hash / load)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                TICK(9);                                         // this step's generator words have arrived (loaded a step ago)
+#endif
                 market_step(e, p, li, a, ab, as, reward, pw, so);
+#ifdef CGE_CRYPTO_TIMING
+                asm volatile("" :: "v"(so.u_hi), "v"(so.u_lo), "v"(reward));
+                TICK(10);                                        // the trade and the draws
+#endif
                 stepped = true;
             }
         }
@@ -964,7 +974,7 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
         }
         TICK(3);
 #ifdef CGE_CRYPTO_TIMING
-        if (lane == 0) g_timing[blockIdx.x * 8 + 7] += 1;
+        if (lane == 0) g_timing[blockIdx.x * 16 + 15] += 1;
 #endif
         phase = next_phase;
     }
@@ -1077,11 +1087,11 @@ extern "C" {
 
 #ifdef CGE_CRYPTO_TIMING
 int cge_crypto_debug_timing(unsigned long long *out, int clear) {
-    static unsigned long long all[16384 * 8];
+    static unsigned long long all[16384 * 16];
     if (hipMemcpyFromSymbol(all, HIP_SYMBOL(crypto::g_timing), sizeof all) != hipSuccess) return 1;
-    for (int k = 0; k < 8; ++k) out[k] = 0;
+    for (int k = 0; k < 16; ++k) out[k] = 0;
     for (int b = 0; b < 16384; ++b)
-        for (int k = 0; k < 8; ++k) out[k] += all[b * 8 + k];
+        for (int k = 0; k < 16; ++k) out[k] += all[b * 16 + k];
     if (clear) { memset(all, 0, sizeof all); if (hipMemcpyToSymbol(HIP_SYMBOL(crypto::g_timing), all, sizeof all) != hipSuccess) return 1; }
     return 0;
 }

@@ -1,20 +1,25 @@
-"""profiles/r02_bench_all.jsonl -> the markdown table of DESIGN.md section 6"""
+"""profiles/r0N_bench_all.jsonl -> the markdown table of DESIGN.md section 6"""
 import json
 import sys
 rows = []
-for l in open(sys.argv[1] if len(sys.argv) > 1 else "profiles/r02_bench_all.jsonl"):
+for l in open(sys.argv[1] if len(sys.argv) > 1 else "profiles/r04_bench_all.jsonl"):
     d = json.loads(l)
+    if d.get("failed"):
+        rows.append(f"| {d['workload']} | — | FAILED | | | | | | |")
+        continue
     w = d["config"]["workload"].split(":")[0]
     n = d["config"]["envs_per_gpu"]
+    k = d["steps"]
     if w.startswith("hetero"):
-        rows.append(f"| {w}: 8 types × 131,072 | both | — | {d['ms_per_step'] * 1e3:.0f} / {d['api_step']['ms_per_step'] * 1e3:.0f} per step of all eight (rollout / `step()`) | {d['value']:.2e} / {d['api_step']['value']:.2e} | — | — | — | — |")
+        rows.append(f"| {w}: 8 types × 131,072 | both | — | {k} | {d['ms_per_step'] * 1e3:.0f} / {d['api_step']['ms_per_step'] * 1e3:.0f} per step of all eight (rollout / `step()`) | {d['value']:.2e} / {d['api_step']['value']:.2e} | — | — | — | — |")
         continue
     for path, blk in (("fused rollout", d), ("`step()`", d["api_step"])):
         r = blk["roofline"]
         steps_per_launch = r["env_steps_per_launch"] / n
         us = r["avg_launch_us"] / steps_per_launch
         tr = r.get("traffic_bytes_per_env_step")
-        rows.append(f"| {w} ({n:,}) | {path} | `{r['kernel'].replace('cge::', '')}` | {us:.1f} | {blk['value']:.2e} | {r['algorithmic_bytes_per_env_step']:.0f} | {r['achieved']:.0f} | {r['frac']:.2f} / {r.get('frac_of_measured', 0):.2f} | {'%.0f (%.2f×)' % (tr, r['traffic_over_algorithmic']) if tr else '—'} |")
-print("| workload (envs per GPU) | path | kernel | µs per step (HIP events) | env-steps/s | obliged B / env-step | achieved GB/s | frac of 8 TB/s / of measured copy | PMC B / env-step (÷ obliged) |")
-print("|---|---|---|---|---|---|---|---|---|")
+        fr = f"{r['frac']:.2f} / {r.get('frac_of_copy', 0):.2f} / {r.get('frac_of_fill', 0):.2f}"
+        rows.append(f"| {w} ({n:,}) | {path} | `{r['kernel'].replace('cge::', '')}` | {k} | {us:.1f} | {blk['value']:.2e} | {r['algorithmic_bytes_per_env_step']:.0f} | {r['achieved']:.0f} | {fr} | {'%.0f (%.2f×)' % (tr, r['traffic_over_algorithmic']) if tr else '—'} |")
+print("| workload (envs per GPU) | path | kernel | K (steps timed) | µs per step (HIP events) | env-steps/s | obliged B / env-step | achieved GB/s | frac of 8 TB/s / of the box's copy / of its fill | PMC B / env-step (÷ obliged) |")
+print("|---|---|---|---|---|---|---|---|---|---|")
 print("\n".join(rows))
