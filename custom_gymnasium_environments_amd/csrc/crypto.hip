@@ -39,8 +39,9 @@ constexpr int HLEN = 50;
 constexpr int OBS = 261;
 constexpr int CH = 12;            // candles per chunk: 60 floats = 15 sixteen-byte stores per row
 constexpr int ROW = CH * 5 + 1;   // LDS row stride (dwords), odd
-constexpr int WP = 10;            // P words per step: trade slippage + volume + regime test + high + low = 5 doubles
-constexpr int WL = 8;             // L words per gaussian pair: two polar-method attempts
+constexpr int WPC = 10;           // P words of a step's common path: trade slippage + volume + regime test + high + low = 5 doubles
+constexpr int WP = 16;            // P words handed to a step: the common path's and, behind them, what a regime switch (1 % of the steps) draws
+constexpr int WL = 16;            // L words per gaussian pair: four polar-method attempts (a fifth is needed by 0.2 % of the pairs)
 constexpr int MAX_STEPS_LIMIT = 16383;   // `step` has 14 bits in the record
 constexpr int BLOCK = 64;
 enum { BULL = 0, BEAR = 1, SIDEWAYS = 2, CRASH = 3, RECOVERY = 4 };
@@ -127,17 +128,19 @@ __device__ __forceinline__ double vol_mult(uint32_t r) { return r == BULL ? 1.2 
 __device__ __forceinline__ double base_trend(uint32_t r) { return r == BULL ? 0.001 : r == BEAR ? -0.001 : r == SIDEWAYS ? 0.0 : r == CRASH ? -0.005 : 0.002; }   // :202-208
 
 // _update_market_regime :166-186, draws from the serial P stream (1 % of steps)
-template <class STREAM>
-__device__ __forceinline__ void update_regime(Env &e, STREAM &sp) {
-    const uint32_t pick = sp.randbelow(2u, 2);   // random.choice of the two successors
+__device__ __forceinline__ void update_regime_with(Env &e, uint32_t pick, double u) {   // pick: random.choice of the two successors; u: the trend draw
     const uint32_t r = e.regime;
     const uint32_t nx0 = r == BULL ? SIDEWAYS : r == BEAR ? SIDEWAYS : r == SIDEWAYS ? BULL : r == CRASH ? RECOVERY : BULL;
     const uint32_t nx1 = r == BULL ? CRASH : r == BEAR ? RECOVERY : r == SIDEWAYS ? BEAR : r == CRASH ? BEAR : SIDEWAYS;
     e.regime = pick ? nx1 : nx0;
-    const double u = sp.random53();
     if (e.regime == BULL || e.regime == RECOVERY) e.trend = 0.5 + (1.0 - 0.5) * u;
     else if (e.regime == BEAR || e.regime == CRASH) e.trend = -1.0 + (-0.5 - -1.0) * u;
     else e.trend = -0.2 + (0.2 - -0.2) * u;
+}
+template <class STREAM>
+__device__ __forceinline__ void update_regime(Env &e, STREAM &sp) {
+    const uint32_t pick = sp.randbelow(2u, 2);
+    update_regime_with(e, pick, sp.random53());
 }
 
 // legacy_gauss (polar method) from the serial L stream
@@ -328,13 +331,33 @@ __device__ __forceinline__ void market_step(Env &e, const Params &p, int64_t i, 
     const double ureg = traded ? U[2] : U[1];
     const uint32_t tq = traded ? 1u : 0u;
     double u_hi = traded ? U[3] : U[2], u_lo = traded ? U[4] : U[3];
-    if (ureg < 0.01) {                                            // :135 — rare: consume up to the regime test, continue draw by draw
-        mt_advance(e.ppos, e.ppretw, 2u * (tq + 2u));
-        MtStream sp(blkP, e.ppos, e.ppretw);
-        update_regime(e, sp);
-        u_hi = sp.random53();
-        u_lo = sp.random53();
-        e.ppos = sp.pos; e.ppretw = sp.pretw;
+    if (ureg < 0.01) {
+        // :135 — a regime switch: _randbelow(2) (two-bit words until one is < 2), the trend draw, then high and low.  1 % of the
+        // env-steps but SOME lane of a 64-env wave in every second step, so it is served from the words behind the common path's
+        // (pw[2 (tq + 2) ..]: up to four _randbelow attempts fit) instead of draw by draw — seven or eight dependent memory round trips
+        // that made wave A the last at bar1 whenever they ran.  A fifth attempt (6 % of the switches) continues on the serial stream.
+        uint32_t rem[WP - 6];
+#pragma unroll
+        for (int k = 0; k < WP - 6; ++k) rem[k] = mt_temper(traded ? pw[6 + k] : pw[4 + k]);
+        uint32_t att = 0, pick = rem[0] >> 30;
+#pragma unroll
+        for (uint32_t j = 1; j < 4u; ++j) if (pick >= 2u) { pick = rem[j] >> 30; att = j; }
+        if (pick < 2u) {
+            uint32_t w[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) w[q] = att == 0u ? rem[1 + q] : att == 1u ? rem[2 + q] : att == 2u ? rem[3 + q] : rem[4 + q];
+            update_regime_with(e, pick, u53(w[0], w[1]));
+            u_hi = u53(w[2], w[3]);
+            u_lo = u53(w[4], w[5]);
+            mt_advance(e.ppos, e.ppretw, 2u * (tq + 2u) + att + 7u);
+        } else {
+            mt_advance(e.ppos, e.ppretw, 2u * (tq + 2u) + 4u);
+            MtStream sp(blkP, e.ppos, e.ppretw);
+            update_regime(e, sp);
+            u_hi = sp.random53();
+            u_lo = sp.random53();
+            e.ppos = sp.pos; e.ppretw = sp.pretw;
+        }
     } else {
         mt_advance(e.ppos, e.ppretw, 2u * (tq + 4u));
     }
@@ -356,7 +379,9 @@ __device__ __forceinline__ bool finish_step(Env &e, const Params &p, H &hist, in
 }
 
 // one legacy_gauss() value (polar method) from the NumPy stream whose state (cursor, ready mark, cached half) is in `e`.  `lw`: the
-// WL ready words at the cursor (two attempts); only a third attempt (4.6 % of the pairs) goes draw by draw.
+// WL ready words at the cursor = four attempts; only a fifth attempt (0.2 % of the pairs) goes draw by draw.  (Round 3 handed in two
+// attempts: a third is needed by 4.6 % of the pairs, i.e. by SOME lane of a 64-env wave in 3 steps of 4, and the draw-by-draw path —
+// four dependent memory round trips — was 4.7 us of wave B's 13.5-us step, profiles/r04_crypto_phase_clocks.txt.)
 __device__ __forceinline__ double draw_gauss(Env &e, uint32_t *__restrict__ blkL, const uint32_t (&lw)[WL]) {
     if (e.has_gauss) {
         e.has_gauss = 0;
@@ -364,17 +389,18 @@ __device__ __forceinline__ double draw_gauss(Env &e, uint32_t *__restrict__ blkL
         e.gauss = 0.0;
         return g;
     }
-    double x1 = 2.0 * u53(mt_temper(lw[0]), mt_temper(lw[1])) - 1.0;
-    double x2 = 2.0 * u53(mt_temper(lw[2]), mt_temper(lw[3])) - 1.0;
-    double r2 = x1 * x1 + x2 * x2;
-    uint32_t used = 4;
-    bool ok = !(r2 >= 1.0 || r2 == 0.0);
-    if (!ok) {
-        x1 = 2.0 * u53(mt_temper(lw[4]), mt_temper(lw[5])) - 1.0;
-        x2 = 2.0 * u53(mt_temper(lw[6]), mt_temper(lw[7])) - 1.0;
-        r2 = x1 * x1 + x2 * x2;
-        used = 8;
-        ok = !(r2 >= 1.0 || r2 == 0.0);
+    double x1 = 0.0, x2 = 0.0, r2 = 0.0;
+    uint32_t used = 0;
+    bool ok = false;
+#pragma unroll
+    for (int a = 0; a < WL / 4; ++a) {
+        if (!ok) {
+            x1 = 2.0 * u53(mt_temper(lw[4 * a]), mt_temper(lw[4 * a + 1])) - 1.0;
+            x2 = 2.0 * u53(mt_temper(lw[4 * a + 2]), mt_temper(lw[4 * a + 3])) - 1.0;
+            r2 = x1 * x1 + x2 * x2;
+            used = 4u * (uint32_t)(a + 1);
+            ok = !(r2 >= 1.0 || r2 == 0.0);
+        }
     }
     mt_advance(e.lpos, e.lpretw, used);
     if (!ok) {
@@ -396,7 +422,7 @@ __device__ __forceinline__ double draw_gauss(Env &e, uint32_t *__restrict__ blkL
 __device__ __forceinline__ double next_gauss(Env &e, uint32_t *__restrict__ blkL, bool want) {
     const bool fresh = want && !e.has_gauss;
     mt_make_ready(blkL, e.lpos, e.lpretw, WL, fresh);
-    uint32_t lw[WL] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t lw[WL] = {};
     if (fresh) mt_load_run<WL>(blkL + e.lpos, lw);
     return want ? draw_gauss(e, blkL, lw) : 0.0;
 }
@@ -416,7 +442,7 @@ __device__ __forceinline__ void reset_wave(Env &e, const Params &p, H &hist, int
 #pragma unroll 1
     for (int k = 0; k < HLEN; ++k) {
         mt_make_ready(blkP, e.ppos, e.ppretw, WP, active);
-        uint32_t pw[WP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        uint32_t pw[WP] = {};
         if (active) mt_load_run<WP>(blkP + e.ppos, pw);
         const double g = next_gauss(e, blkL, active);
         if (active) {
@@ -432,7 +458,7 @@ __device__ __forceinline__ void reset_wave(Env &e, const Params &p, H &hist, int
                 u_hi = sp.random53(); u_lo = sp.random53(); u_op = sp.random53();
                 e.ppos = sp.pos; e.ppretw = sp.pretw;
             } else {
-                mt_advance(e.ppos, e.ppretw, (uint32_t)WP);
+                mt_advance(e.ppos, e.ppretw, (uint32_t)WPC);
             }
             price = price_update(e, p.cfg, price, volume, g);
             const double hi = price * (1.0 + (1.02 - 1.0) * u_hi);
@@ -611,13 +637,17 @@ __device__ __forceinline__ void feed_closes(Indicators &ind, const HistLds &hist
         feed_closes<K + 1, KEND>(ind, hist, oldest);
     }
 }
-__device__ __forceinline__ void features_resident(const Env &e, const Params &p, const HistLds &hist, int oldest, float *row, bool mine) {
+// the 11 scalar features of the lane's env from its 50 closes in the LDS window (computed; stored by the caller)
+__device__ __forceinline__ void features_compute(const Env &e, const Params &p, const HistLds &hist, int oldest, float (&ft)[11]) {
     Indicators ind;
     ind.ef = ind.es = ind.sig = ind.macd = ind.mx = ind.mn = ind.prev = 0.0;
     ind.pg.res = ind.pl.res = ind.pm.res = 0.0;
     feed_closes<0, HLEN>(ind, hist, oldest);
-    float ft[11];
     scalar_features(e, p, ind, e.close, ft);
+}
+__device__ __forceinline__ void features_resident(const Env &e, const Params &p, const HistLds &hist, int oldest, float *row, bool mine) {
+    float ft[11];
+    features_compute(e, p, hist, oldest, ft);
     store_own_row<11>(row, HLEN * 5, ft, mine);
 }
 // The (env, candle) pairs of envs [env_lo, env_hi) are dealt to the 64 lanes as one stream (pair q -> env q / 50, candle q % 50), so
@@ -812,9 +842,10 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
             // (a step with resets hands the stream to wave A first: then the words are fetched afterwards)
             const bool more = t + 1 < p.k_steps;
             const bool wn_early = more && !slow && live && (u & F_DRAW_NEXT);
-            uint32_t lw[WL] = {0, 0, 0, 0, 0, 0, 0, 0};
+            uint32_t lw[WL] = {};
             if (more && !slow) {
-                mt_make_ready(blkL, v.lpos, v.lpretw, WL, wn_early && !v.has_gauss);
+                // (slack: the lanes' cursors drift apart — 4 to 16 words per pair — and without it SOME lane twists in nearly every step)
+                mt_make_ready(blkL, v.lpos, v.lpretw, WL, wn_early && !v.has_gauss, nullptr, (uint32_t)MT_CHUNK);
                 if (wn_early && !v.has_gauss) mt_load_run<WL>(blkL + v.lpos, lw);
             }
             v.cash = mail[0]; v.holdings = mail[64]; v.psych = mail[128]; v.close = mail[192]; v.cash_kind = u & 3u;
@@ -823,7 +854,16 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
             float *row = dest != DEST_FINAL ? obs_row
                          : p.fin.rows ? static_cast<float *>(p.fin.rows) + ((int64_t)blockIdx.x * p.fin.cap + (u >> 8)) * OBS : p.final_obs + li * OBS;
             const bool want = dest != DEST_NONE && row != nullptr;
-            if (__ballot(want)) features_resident(v, p, hist, next_phase, want ? row : obs_row, want);
+            // The features are computed, then step t+1's gaussian is drawn, THEN the features are stored: the gaussian's words were
+            // requested before any store of this step, so waiting for them (one in-order counter for a wave's loads and stores) waits
+            // for nothing else; drawn after the row stores, the same wait also sat out those stores' way to memory — wave B was the last
+            // at bar1 by 2-3 us in every step (profiles/r04_crypto_phase_clocks.txt).
+            const bool any_row = __ballot(want) != 0ull;
+            float ft[11];
+            if (any_row) features_compute(v, p, hist, next_phase, ft);
+            double gn = 0.0;
+            if (!slow && more && wn_early) gn = draw_gauss(v, blkL, lw);
+            if (any_row) store_own_row<11>(want ? row : obs_row, HLEN * 5, ft, want);
             TICK(5);
             if (slow) {
                 m_lcur = lcur_pack(v); m_lcache = v.gauss;
@@ -840,7 +880,7 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
                     if (wn) m_gauss = gn;
                 }
             } else if (more) {
-                if (wn_early) m_gauss = draw_gauss(v, blkL, lw);
+                if (wn_early) m_gauss = gn;
             }
             phase = next_phase;
         }
@@ -895,7 +935,7 @@ __global__ __launch_bounds__(RES_WAVES * BLOCK) void resident_kernel(Params p) {
         }
         // the next step's words (the cursor is final): a chunk twist every ~3 steps, in wave A's slack before bar1, then a plain load.
         // After the launch's last step the twist still happens (the next launch then starts with nothing but the load).
-        mt_make_ready(blkP, e.ppos, e.ppretw, WP, stepped, nullptr, 2u * WP);
+        mt_make_ready(blkP, e.ppos, e.ppretw, WP, stepped, nullptr, (uint32_t)MT_CHUNK);
         if (t + 1 < p.k_steps && stepped) mt_load_run<WP>(blkP + e.ppos, pw);
         TICK(0);
         lds_barrier();                                          // bar1: B is done with window(t-1), C's gaussian for this step is in LDS
