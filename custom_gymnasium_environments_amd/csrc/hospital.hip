@@ -320,8 +320,13 @@ __device__ __forceinline__ void assign_dept(Misc &m, const Ring &rg, Heads &hd, 
         fd |= (k < (uint32_t)NDOC && doc_dept(e.dmeta[s]) == dept && doc_busy(e.dmeta[s]) <= now) ? 1u << k : 0u;
     }
     fb = gor(fb); fd = gor(fd);
+    int stale = -1;                                              // the sub-queue whose cached front went with the last pop
 #pragma unroll 1
     while (fb && fd && m.qlen(G) > 0u) {
+        // A pop leaves its sub-queue's cached front stale; the new front is fetched only by a quad that comes round again in the SAME
+        // step (the next step fetches all six anyway).  Fetched right after the pop, the load hung on every later use of `hd` — the next
+        // department's assignment, whatever it popped — and the three departments were three dependent round trips in most wave-steps.
+        if (stale >= 0) { hd.refetch(m, rg, stale); stale = -1; }
         uint32_t rec = 0, slot = 0, tt = 0;
         const int k = dept_front_h<G>(m, hd, rec, slot, tt);
         const uint32_t b = (uint32_t)b0 + (uint32_t)__ffs((int)fb) - 1u, di = (uint32_t)__ffs((int)fd) - 1u;
@@ -341,7 +346,7 @@ __device__ __forceinline__ void assign_dept(Misc &m, const Ring &rg, Heads &hd, 
             if (di == ent(s, ql)) { e.dmeta[s] = (e.dmeta[s] & 2047u) | ((now + tt / 2u) << 11); e.dfat[s] = dmin(100.0, e.dfat[s] + (double)(sev * 2u)); }
         m.total_wait += now - rec_arr(rec);
         q_pop_dyn(m, k, rec_arr(rec));
-        hd.refetch(m, rg, k);                                    // (a second assignment of this department in the same step: rare)
+        stale = k;
     }
 }
 
