@@ -52,21 +52,22 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 
 # record once per launch (2 x resident / kc); it reads no actions (device-side hash).
 ENVS = {
     # the 16-byte hot record is all a launch reads and writes of the state (snakes of <= 25 cells); the digit ring adds < 1 B / env-step
-    "snake":   dict(algo=145,  obs=100, state=16, resident=16, stream=0, n_act=4, act_shape=(),   dtype="i8",
+    # ep_typ: a typical episode length under random actions — sizes the terminal-row side output of the rollout leg (collect_final_obs)
+    "snake":   dict(algo=145,  obs=100, state=16, resident=16, stream=0, ep_typ=12, n_act=4, act_shape=(),   dtype="i8",
                     ref_py="3.4e5-4.2e5 steps/s/process"),
     # rollout: the 50-candle window (1,200 B) is resident in LDS for a launch (read once: resident_ro); per step only the new candle
     # (24 B, written through) and the generator words (144 B) stream
     "crypto":  dict(algo=2346, obs=1044, state=64, resident=64, resident_ro=1200, stream=168, n_act=5, act_shape=(),   dtype="f64", ref_py="1.64e3-1.68e3 steps/s/process"),
-    # round 4: array-of-structs record of 62 dwords padded to 256 B, register-resident over a fused launch; SAME_STEP rollouts also deliver the
-    # terminal row of every episode that ends (final_per_step: 520 B once per 1000-step episode)
-    "traffic": dict(algo=1134, obs=520, state=256, resident=256, stream=60, final_per_step=0.52, n_act=3, act_shape=(9,), dtype="int32", ref_py="1.75e3-1.90e3 steps/s/process"),
+    # round 4: array-of-structs record of 62 dwords padded to 256 B, register-resident over a fused launch
+    "traffic": dict(algo=1134, obs=520, state=256, resident=256, stream=60, n_act=3, act_shape=(9,), dtype="int32", ref_py="1.75e3-1.90e3 steps/s/process"),
     "parking": dict(algo=662,  obs=52, state=288, resident=288, stream=24, n_act=8, act_shape=(),   dtype="f64", ref_py="2.66e4 steps/s/process"),
     "climate": dict(algo=218,  obs=36, state=80, resident=80, stream=0, n_act=None, act_shape=None, dtype="f64", ref_py="1.27e4 steps/s/process"),
     # fleet's rollout is K (step, dense) launch pairs: the record goes through HBM every step
-    "fleet":   dict(algo=642,  obs=304, state=160, resident=0, stream=0, n_act=8, act_shape=(3,), dtype="f64", launches_per_step=True, ref_py="2.01e4 steps/s/process"),
-    # 972 obs + 2 x 768 state + action/reward/flags + ~70 MT19937 words read and written per step (2 x 280); only the 96-byte
-    # MISC group stays in registers across fused steps, the doctor / nurse / bed / equipment groups are re-loaded per step
-    "hospital": dict(algo=3078, obs=972, state=768, resident=96, stream=560, n_act=35, act_shape=(), dtype="f64", ref_py="not in BASELINE.md"),
+    "fleet":   dict(algo=642,  obs=304, state=160, resident=0, stream=0, ep_typ=30, n_act=8, act_shape=(3,), dtype="f64", launches_per_step=True, ref_py="2.01e4 steps/s/process"),
+    # step(): SURVEY 8d's figure (972 obs + 2 x 768 state + action/reward/flags + ~70 MT19937 words read and written per step, 2 x 280).
+    # Fused rollout, round 4: the whole 848-byte record stays in registers for the launch (rounds 1-3 re-loaded 672 of 768 bytes per step
+    # and the rollout was credited 2 x 672 B per env-step for it): obs + reward + flag + the generator words
+    "hospital": dict(algo=3078, obs=972, state=848, resident=848, stream=560, n_act=35, act_shape=(), dtype="f64", ref_py="not in BASELINE.md"),
     # 292 obs + 2 x 336 state + action/reward/flags; plus 10 bytes (quality f64 + meta u16) per product in the system, which the
     # per-type np.mean of the observation has to read every step: added from the measured mean occupancy (algo_per_product)
     "manufacturing": dict(algo=1028, algo_per_product=8, obs=292, state=368, resident=368, stream=0, n_act=25, act_shape=(), dtype="f64", ref_py="not in BASELINE.md"),
@@ -99,10 +100,12 @@ WORKLOADS = {
 }
 
 
-def roll_algo(name, kc, occupancy=0.0):
+def roll_algo(name, kc, occupancy=0.0, final_rate=0.0):
+    """final_rate: terminal rows delivered per env-step (measured: the rollout leg registers the side output of SAME_STEP rollouts, so
+    that a fused launch hands over everything the k step() calls it replaces return): obs bytes + the 8-byte index entry each"""
     s = ENVS[name]
     return (s["obs"] + 4 + 1 + s["stream"] + 2 * (s["state"] - s["resident"]) + (2.0 * s["resident"] + s.get("resident_ro", 0)) / max(kc, 1)
-            + s.get("algo_per_product", 0) * occupancy + s.get("final_per_step", 0.0))
+            + s.get("algo_per_product", 0) * occupancy + (s["obs"] + 8) * final_rate)
 
 
 def step_algo(name, occupancy=0.0):
@@ -215,9 +218,9 @@ def measure_copy_bandwidth(dev):
     return out
 
 
-def roofline(name, path, kernel, gpu_ms, launches, steps_per_launch, n, occupancy, measured):
-    algo = roll_algo(name, steps_per_launch, occupancy) if path == "rollout" and not ENVS[name].get("launches_per_step") else \
-        (roll_algo(name, 1, occupancy) if path == "rollout" else step_algo(name, occupancy))
+def roofline(name, path, kernel, gpu_ms, launches, steps_per_launch, n, occupancy, measured, final_rate=0.0):
+    algo = roll_algo(name, steps_per_launch, occupancy, final_rate) if path == "rollout" and not ENVS[name].get("launches_per_step") else \
+        (roll_algo(name, 1, occupancy, final_rate) if path == "rollout" else step_algo(name, occupancy))
     launch_s = gpu_ms * 1e-3 / launches
     env_steps = n * steps_per_launch
     achieved = algo * env_steps / launch_s / 1e9
@@ -403,6 +406,13 @@ def main():
     traj_gib = args.traj_gib if args.traj_gib is not None else wl.get("traj_gib", 24.0)
     budget = traj_gib * (1 << 30) / (1 if len(names) == 1 else 4)
     kc = {nm: max(1, min(K, int(budget // (n * ENVS[nm]["obs"])))) for nm in names}
+    # SAME_STEP: the rollout leg also takes delivery of the terminal observation of every episode that ends (cge_<env>_rollout_final_obs),
+    # what infos["final_obs"] carries on the step() leg; sized for ~3x the episode ends a launch is expected to see
+    fin_rows = {nm: min(kc[nm], 3 * -(-kc[nm] // ENVS[nm].get("ep_typ", 1000)) + 2) for nm in names}
+    final_stats = {}
+    if not dry:
+        for nm in names:
+            envs[nm].collect_final_obs(rows_per_env=fin_rows[nm])
     launched = {}                                        # kernel name -> env-steps launched (for --manifest)
     ran = {}                                             # (env type, path) -> the kernel the library says it launched last
 
@@ -412,6 +422,8 @@ def main():
         ran[(nm, path)] = kern
         launched[kern] = launched.get(kern, 0) + n * steps
 
+    last_launch = {}
+
     def run_rollout(k_total, t0, marks=None):
         for nm in names:
             with on_stream(nm):
@@ -419,6 +431,7 @@ def main():
                 while done < k_total:
                     k = min(kc[nm], k_total - done)
                     envs[nm].rollout(k, action_seed=123, t0=t0 + done, trajectory=True, per_step=True)
+                    last_launch[nm] = k
                     count(nm, "rollout", k)
                     done += k
                     if marks is not None and not dry:                # one event per launch: the cost of a step early / late in the region
@@ -536,6 +549,12 @@ def main():
     # workloads that restart their episodes before every region
     same_work = len(names) == 1 and (names[0] == "snake" or bool(wl.get("episode_start")))
     results["rollout"] = timed(lambda rep, marks: run_rollout(K, t_roll if wl.get("episode_start") else t_roll + rep * K, marks), "rollout", same_work)
+    if not dry:                                          # terminal rows of the LAST launch: per env-step (-> obliged bytes) and whether the side output held them all
+        for nm in names:
+            _, _, cnt, cap = envs[nm]._fin
+            tot = int(cnt.sum().item())
+            final_stats[nm] = {"rows_per_env": fin_rows[nm], "delivered_last_launch": tot, "dropped_last_launch": envs[nm].final_obs_dropped(),
+                               "per_env_step": tot / float(n * max(last_launch.get(nm, 1), 1))}
     if not dry:
         for e in envs.values():                                      # the trajectory buffers are not needed by the API leg
             e._bufs.pop("traj", None)
@@ -601,7 +620,8 @@ def main():
                 # fleet's rollout is K (step, dense) launch pairs, not one fused launch: price it per pair
                 fused = path == "rollout" and not ENVS[nm].get("launches_per_step")
                 launches = -(-K // kc[nm]) if fused else K
-                rl[nm] = roofline(nm, path, kern, gpu_ms[nm], launches, K / launches, n, occupancy[path].get(nm, 0.0), measured)
+                rl[nm] = roofline(nm, path, kern, gpu_ms[nm], launches, K / launches, n, occupancy[path].get(nm, 0.0), measured,
+                                  final_stats.get(nm, {}).get("per_env_step", 0.0) if path == "rollout" else 0.0)
                 hl = host_latency_ms.get(path)
                 if hl is not None:
                     rl[nm]["timing"] = ("HIP events on the launch stream around a second pass of the same K steps, queued behind a 1-GiB device copy so "
@@ -650,6 +670,11 @@ def main():
             out["roofline"] = None
         if hb.get("phases"):
             out["phases"] = hb["phases"]
+        if final_stats:
+            out["final_obs"] = {"note": "SAME_STEP rollouts deliver the terminal observation of every episode that ends to a side output compacted per "
+                                        "wave segment (cge_<env>_rollout_final_obs): trajectory + side output = what the K step() calls return; "
+                                        "its bytes are part of the rollout's obliged bytes",
+                                **(final_stats[names[0]] if len(names) == 1 else {"per_env_type": final_stats})}
         if graph_leg:
             out["graph_step"] = graph_leg
         if len(names) > 1:
