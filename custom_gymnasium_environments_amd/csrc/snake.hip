@@ -28,7 +28,7 @@
 #include "snake_place.hpp"
 
 #ifndef CGE_SNAKE_FINCOPY
-#define CGE_SNAKE_FINCOPY 1     // A/B knob: 0 every finishing lane stores its own terminal row, 1 via the LDS rows, one store per env, 2 one contiguous run
+#define CGE_SNAKE_FINCOPY 1     // A/B knob: 0 every finishing lane builds and stores its own terminal row, 1 via the LDS rows, one coalesced store per env
 #endif
 namespace cge {
 namespace snake {
@@ -519,7 +519,7 @@ __device__ __forceinline__ void dq_place_food(Env<G> &e, DqCtx<G> &q, bool need)
     }
 }
 
-enum : uint32_t { T_NEED_FOOD = 1u, T_WAS_RESET = 2u, T_DEFERRED = 4u };
+enum : uint32_t { T_NEED_FOOD = 1u, T_WAS_RESET = 2u, T_DEFERRED = 4u, T_FIN_ROW = 8u };   // T_FIN_ROW: the lane's LDS row now holds its terminal observation
 
 // SameStep: the terminal observation of a lane whose episode just ended (rare lanes only: direct row store).  step(): row i of
 // final_obs_out; fused rollout: the next slots of the wave's segment of the compacted side output (FinalSeg, cge_device.hpp) — the
@@ -554,10 +554,9 @@ __device__ __forceinline__ void write_final_obs(const Env<G> &e, const Params &p
 template <int G, int MODE>
 __device__ __forceinline__ uint32_t transition(Env<G> &e, const Params &p, int64_t i, uint32_t action, bool valid_action,
                                                uint32_t *__restrict__ obs_row, float &reward, bool &term, bool short_wave, int64_t t = 0,
-                                               uint32_t fin_base = 0, int8_t *__restrict__ fin_rowb = nullptr, uint32_t old_tail = 0,
-                                               int64_t *fin_gs = nullptr) {
+                                               uint32_t fin_base = 0, int8_t *__restrict__ fin_rowb = nullptr, uint32_t old_tail = 0) {
     using L = Lay<G>;
-    bool need_food = false, was_reset = false, deferred = false;
+    bool need_food = false, was_reset = false, deferred = false, fin_row = false;
     reward = 0.0f;
     term = false;
     if (MODE == CGE_AUTORESET_NEXT_STEP && (e.flags & F_NEEDS_RESET)) {
@@ -590,7 +589,7 @@ __device__ __forceinline__ uint32_t transition(Env<G> &e, const Params &p, int64
                         // stored dword by dword by every finishing lane — SOME lane of a 64-env wave in 99 % of the steps — the terminal
                         // rows cost the 1M-env rollout 7 us of its 23 per step.)
                         if (!crashed) { fin_rowb[e.head] = 1; if (e.tail != old_tail) fin_rowb[old_tail] = 0; }
-                        *fin_gs = final_slot(p.fin, i >> 6, fin_base, true, t, i);
+                        fin_row = true;                          // slot, index entry and the copy: by the caller, on wave-uniform values
                     } else {
                         write_final_obs(e, p, i, t, fin_base);
                     }
@@ -605,7 +604,7 @@ __device__ __forceinline__ uint32_t transition(Env<G> &e, const Params &p, int64
     if (need_food) need_food = e.can_place_food();
     if (obs_row) e.write_obs_body(obs_row);
     // the caller runs dq_place_food with the whole wave, then (T_DEFERRED, rare) finish_deferred + a second round, then write_obs_food
-    return (need_food ? T_NEED_FOOD : 0u) | (was_reset ? T_WAS_RESET : 0u) | (deferred ? T_DEFERRED : 0u);
+    return (need_food ? T_NEED_FOOD : 0u) | (was_reset ? T_WAS_RESET : 0u) | (deferred ? T_DEFERRED : 0u) | (fin_row ? T_FIN_ROW : 0u);
 }
 
 // second half of a SameStep episode end whose last step also ate (see transition): terminal obs with the post-eat food, reset.
@@ -767,6 +766,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
     uint32_t *wave_rows = tile + (threadIdx.x & ~63u) * L::OBS_DW;
     // SAME_STEP terminal rows through the LDS rows (dword-aligned 4 G^2-byte rows only; else every finishing lane stores its own)
     int8_t *const fin_rowb = (CGE_SNAKE_FINCOPY != 0 && MODE == CGE_AUTORESET_SAME_STEP && L::PACKED && row && p.fin.rows) ? rowb : nullptr;
+    uint32_t *const fin_rows_seg = static_cast<uint32_t *>(p.fin.rows) + (wfirst >> 6) * p.fin.cap * L::OBS_DW;    // this wave's segment (wave-uniform)
+    int64_t *const fin_index_seg = p.fin.index + (wfirst >> 6) * p.fin.cap;
     if (row && live_lane) { e.write_obs_body(row); e.write_obs_food(row); }
     // ACTIONS (compile time): explicit [k, n] actions, fetched one step ahead so the load's latency hides behind the previous step.
     // The hash-action instance has NO global load in its step loop on the common path — on purpose: gfx950 counts loads and
@@ -786,7 +787,6 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
         uint32_t tf = 0;
         const uint32_t old_head = e.head, old_tail = e.tail;
         const bool short_wave = __ballot(e.len > 15u) == 0ull;  // every history of this wave fits one word (see Env::move)
-        int64_t fin_gs = -1;
         if (live_lane) {
             uint32_t a;
             if constexpr (ACTIONS) {
@@ -795,34 +795,26 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
             } else {
                 a = hash_action_from_key(key, (uint64_t)(p.t0 + t), 4u, 0u);
             }
-            tf = transition<G, MODE>(e, p, i, a, a <= 3u, nullptr, r, term, short_wave, t, fin_used, fin_rowb, old_tail, &fin_gs);
+            tf = transition<G, MODE>(e, p, i, a, a <= 3u, nullptr, r, term, short_wave, t, fin_used, fin_rowb, old_tail);
             need_food = tf & T_NEED_FOOD; was_reset = tf & T_WAS_RESET;
         }
-        if (fin_rowb) {                                        // terminal rows staged in the lanes' LDS rows -> their slots of the side output
-            unsigned long long fm = __ballot(fin_gs >= 0);
-            const uint32_t glo = (uint32_t)(uint64_t)fin_gs, ghi = (uint32_t)((uint64_t)fin_gs >> 32);
-#if CGE_SNAKE_FINCOPY == 2
-            // the slots are consecutive: one contiguous run of nfin x 100 bytes, 256 bytes per store instruction
+        if (fin_rowb) {
+            // terminal rows staged in the lanes' LDS rows -> the segment's next slots, in lane order; everything but the lane's own index
+            // entry is wave-uniform (the segment's pointers and fill count live in scalar registers)
+            unsigned long long fm = __ballot((tf & T_FIN_ROW) != 0u);
             if (fm) {
-                const uint32_t nfin = (uint32_t)__popcll(fm), first = (uint32_t)__builtin_ctzll(fm);
-                const int64_t gs0 = (int64_t)(((uint64_t)lane_u32(ghi, (int)first) << 32) | (uint64_t)lane_u32(glo, (int)first));
-                uint32_t *dst = static_cast<uint32_t *>(p.fin.rows) + gs0 * L::OBS_DW;
-#pragma unroll 1
-                for (uint32_t d = lane; d < nfin * (uint32_t)L::OBS_DW; d += 64u) {
-                    const uint32_t r = d / (uint32_t)L::OBS_DW, c = d - r * (uint32_t)L::OBS_DW;
-                    unsigned long long m = fm;
-                    for (uint32_t k = 0; k < r; ++k) m &= m - 1ull;
-                    dst[d] = wave_rows[(uint32_t)__builtin_ctzll(m) * L::OBS_DW + c];
+                if (tf & T_FIN_ROW) {
+                    const uint32_t slot = fin_used + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull));
+                    if ((int64_t)slot < p.fin.cap) fin_index_seg[slot] = (int64_t)t * p.fin.n + i;
+                }
+                uint32_t k = fin_used;
+                while (fm) {                                   // one coalesced 100-byte store per finishing env
+                    const uint32_t rl = (uint32_t)__builtin_ctzll(fm);
+                    fm &= fm - 1ull;
+                    if ((int64_t)k < p.fin.cap && lane < (uint32_t)L::OBS_DW) fin_rows_seg[k * (uint32_t)L::OBS_DW + lane] = wave_rows[rl * L::OBS_DW + lane];
+                    ++k;
                 }
             }
-#else
-            while (fm) {                                       // one coalesced 100-byte store per finishing env
-                const int rl = __builtin_ctzll(fm);
-                fm &= fm - 1ull;
-                const int64_t gs = (int64_t)(((uint64_t)lane_u32(ghi, rl) << 32) | (uint64_t)lane_u32(glo, rl));
-                if (lane < (uint32_t)L::OBS_DW) static_cast<uint32_t *>(p.fin.rows)[gs * L::OBS_DW + lane] = wave_rows[(uint32_t)rl * L::OBS_DW + lane];
-            }
-#endif
         }
         // terminal rows: the lanes that finished without eating wrote theirs inside transition(); those that also ate follow below
         const uint32_t fin_deferred = MODE == CGE_AUTORESET_SAME_STEP ? fin_used + (uint32_t)__popcll(__ballot(term && !(tf & T_DEFERRED))) : 0u;
