@@ -572,6 +572,17 @@ def main():
             tot = int(cnt.sum().item())
             final_stats[nm] = {"rows_per_env": fin_rows[nm], "delivered_last_launch": tot, "dropped_last_launch": envs[nm].final_obs_dropped(),
                                "per_env_step": tot / float(n * max(last_launch.get(nm, 1), 1))}
+    nofin = nofin_raw = None
+    if not dry and len(names) == 1 and ENVS[names[0]].get("ep_typ", 1000) < 100:
+        # where episode ends are frequent (snake: 6.6 % of the env-steps, fleet 1 %) the same K steps once more with the side output switched
+        # off, for comparison with rounds 1-3, whose rollouts dropped the terminal rows: what delivering them costs
+        nm = names[0]
+        envs[nm].collect_final_obs(0)
+        R_keep, R = R, min(R, 3)
+        res = timed(lambda rep, marks: run_rollout(K, t_roll if wl.get("episode_start") else t_roll + rep * K, None), "rollout_nofin", same_work)
+        R = R_keep
+        nofin_raw = (res, ran[(nm, "rollout")])
+        envs[nm].collect_final_obs(rows_per_env=fin_rows[nm])
     if not dry:
         for e in envs.values():                                      # the trajectory buffers are not needed by the API leg
             e._bufs.pop("traj", None)
@@ -615,6 +626,7 @@ def main():
         return float(t.item())
 
     walls = {p: reduce_max(results[p][0]) for p in results}
+    nofin_wall = reduce_max(nofin_raw[0][0]) if nofin_raw else None          # (every rank: a collective)
     if graph_leg:
         gwall = reduce_max(graph_leg.pop("_wall"))
         graph_leg["value"] = n * world * graph_leg["steps_per_replay"] / gwall
@@ -687,6 +699,14 @@ def main():
             out["roofline"] = None
         if hb.get("phases"):
             out["phases"] = hb["phases"]
+        if nofin_raw:
+            nm = names[0]
+            launches = K if ENVS[nm].get("launches_per_step") else -(-K // kc[nm])
+            rr = roofline(nm, "rollout", nofin_raw[1], nofin_raw[0][1][nm], launches, K / launches, n, occupancy["rollout"].get(nm, 0.0), measured, 0.0)
+            out["rollout_without_final_obs"] = {
+                "us_per_step": rr["avg_launch_us"] / (K / launches), "frac": rr["frac"], "algorithmic_bytes_per_env_step": rr["algorithmic_bytes_per_env_step"],
+                "ms_per_step_wall": nofin_wall * 1e3 / K,
+                "note": "the same K steps with the terminal-observation side output NOT registered: what rounds 1-3 measured as the rollout leg"}
         if final_stats:
             out["final_obs"] = {"note": "SAME_STEP rollouts deliver the terminal observation of every episode that ends to a side output compacted per "
                                         "wave segment (cge_<env>_rollout_final_obs): trajectory + side output = what the K step() calls return; "
