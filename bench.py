@@ -406,13 +406,12 @@ def main():
     traj_gib = args.traj_gib if args.traj_gib is not None else wl.get("traj_gib", 24.0)
     budget = traj_gib * (1 << 30) / (1 if len(names) == 1 else 4)
     kc = {nm: max(1, min(K, int(budget // (n * ENVS[nm]["obs"])))) for nm in names}
-    # SAME_STEP: the rollout leg also takes delivery of the terminal observation of every episode that ends (cge_<env>_rollout_final_obs),
-    # what infos["final_obs"] carries on the step() leg; sized for ~3x the episode ends a launch is expected to see
+    # SAME_STEP rollouts can also deliver the terminal observation of every episode that ends (cge_<env>_rollout_final_obs: what
+    # infos["final_obs"] carries on the step() leg) to a side output the caller registers.  The headline leg runs without it, as in rounds 1-3;
+    # single-type workloads then time the same K steps once more WITH it (rollout_with_final_obs: rows delivered / dropped, what it costs).
+    # Sized for ~3x the episode ends a launch is expected to see.
     fin_rows = {nm: min(kc[nm], 3 * -(-kc[nm] // ENVS[nm].get("ep_typ", 1000)) + 2) for nm in names}
     final_stats = {}
-    if not dry:
-        for nm in names:
-            envs[nm].collect_final_obs(rows_per_env=fin_rows[nm])
     launched = {}                                        # kernel name -> env-steps launched (for --manifest)
     ran = {}                                             # (env type, path) -> the kernel the library says it launched last
 
@@ -566,23 +565,19 @@ def main():
     # workloads that restart their episodes before every region
     same_work = len(names) == 1 and (names[0] == "snake" or bool(wl.get("episode_start")))
     results["rollout"] = timed(lambda rep, marks: run_rollout(K, t_roll if wl.get("episode_start") else t_roll + rep * K, marks), "rollout", same_work)
-    if not dry:                                          # terminal rows of the LAST launch: per env-step (-> obliged bytes) and whether the side output held them all
-        for nm in names:
-            _, _, cnt, cap = envs[nm]._fin
-            tot = int(cnt.sum().item())
-            final_stats[nm] = {"rows_per_env": fin_rows[nm], "delivered_last_launch": tot, "dropped_last_launch": envs[nm].final_obs_dropped(),
-                               "per_env_step": tot / float(n * max(last_launch.get(nm, 1), 1))}
-    nofin = nofin_raw = None
-    if not dry and len(names) == 1 and ENVS[names[0]].get("ep_typ", 1000) < 100:
-        # where episode ends are frequent (snake: 6.6 % of the env-steps, fleet 1 %) the same K steps once more with the side output switched
-        # off, for comparison with rounds 1-3, whose rollouts dropped the terminal rows: what delivering them costs
+    withfin_raw = None
+    if not dry and len(names) == 1:
         nm = names[0]
-        envs[nm].collect_final_obs(0)
-        R_keep, R = R, min(R, 3)
-        res = timed(lambda rep, marks: run_rollout(K, t_roll if wl.get("episode_start") else t_roll + rep * K, None), "rollout_nofin", same_work)
-        R = R_keep
-        nofin_raw = (res, ran[(nm, "rollout")])
         envs[nm].collect_final_obs(rows_per_env=fin_rows[nm])
+        R_keep, R = R, min(R, 3)
+        res = timed(lambda rep, marks: run_rollout(K, t_roll if wl.get("episode_start") else t_roll + rep * K, None), "rollout_fin", same_work)
+        R = R_keep
+        _, _, cnt, cap = envs[nm]._fin                   # terminal rows of the LAST launch: per env-step (-> obliged bytes), and whether the side output held them all
+        tot = int(cnt.sum().item())
+        final_stats[nm] = {"rows_per_env": fin_rows[nm], "delivered_last_launch": tot, "dropped_last_launch": envs[nm].final_obs_dropped(),
+                           "per_env_step": tot / float(n * max(last_launch.get(nm, 1), 1))}
+        withfin_raw = (res, ran[(nm, "rollout")])
+        envs[nm].collect_final_obs(0)
     if not dry:
         for e in envs.values():                                      # the trajectory buffers are not needed by the API leg
             e._bufs.pop("traj", None)
@@ -626,7 +621,7 @@ def main():
         return float(t.item())
 
     walls = {p: reduce_max(results[p][0]) for p in results}
-    nofin_wall = reduce_max(nofin_raw[0][0]) if nofin_raw else None          # (every rank: a collective)
+    withfin_wall = reduce_max(withfin_raw[0][0]) if withfin_raw else None      # (every rank: a collective)
     if graph_leg:
         gwall = reduce_max(graph_leg.pop("_wall"))
         graph_leg["value"] = n * world * graph_leg["steps_per_replay"] / gwall
@@ -649,8 +644,7 @@ def main():
                 # fleet's rollout is K (step, dense) launch pairs, not one fused launch: price it per pair
                 fused = path == "rollout" and not ENVS[nm].get("launches_per_step")
                 launches = -(-K // kc[nm]) if fused else K
-                rl[nm] = roofline(nm, path, kern, gpu_ms[nm], launches, K / launches, n, occupancy[path].get(nm, 0.0), measured,
-                                  final_stats.get(nm, {}).get("per_env_step", 0.0) if path == "rollout" else 0.0)
+                rl[nm] = roofline(nm, path, kern, gpu_ms[nm], launches, K / launches, n, occupancy[path].get(nm, 0.0), measured)
                 hl = host_latency_ms.get(path)
                 if hl is not None:
                     rl[nm]["timing"] = ("HIP events on the launch stream around a second pass of the same K steps, queued behind a 1-GiB device copy so "
@@ -699,19 +693,16 @@ def main():
             out["roofline"] = None
         if hb.get("phases"):
             out["phases"] = hb["phases"]
-        if nofin_raw:
+        if withfin_raw:
             nm = names[0]
             launches = K if ENVS[nm].get("launches_per_step") else -(-K // kc[nm])
-            rr = roofline(nm, "rollout", nofin_raw[1], nofin_raw[0][1][nm], launches, K / launches, n, occupancy["rollout"].get(nm, 0.0), measured, 0.0)
-            out["rollout_without_final_obs"] = {
+            rr = roofline(nm, "rollout", withfin_raw[1], withfin_raw[0][1][nm], launches, K / launches, n, occupancy["rollout"].get(nm, 0.0), measured,
+                          final_stats[nm]["per_env_step"])
+            out["rollout_with_final_obs"] = {
                 "us_per_step": rr["avg_launch_us"] / (K / launches), "frac": rr["frac"], "algorithmic_bytes_per_env_step": rr["algorithmic_bytes_per_env_step"],
-                "ms_per_step_wall": nofin_wall * 1e3 / K,
-                "note": "the same K steps with the terminal-observation side output NOT registered: what rounds 1-3 measured as the rollout leg"}
-        if final_stats:
-            out["final_obs"] = {"note": "SAME_STEP rollouts deliver the terminal observation of every episode that ends to a side output compacted per "
-                                        "wave segment (cge_<env>_rollout_final_obs): trajectory + side output = what the K step() calls return; "
-                                        "its bytes are part of the rollout's obliged bytes",
-                                **(final_stats[names[0]] if len(names) == 1 else {"per_env_type": final_stats})}
+                "ms_per_step_wall": withfin_wall * 1e3 / K, **final_stats[nm],
+                "note": "the same K steps with the terminal-observation side output registered (cge_<env>_rollout_final_obs): trajectory + side output = "
+                        "everything the K step() calls return; its bytes (obs + 8 per episode end) are part of this block's obliged bytes"}
         if graph_leg:
             out["graph_step"] = graph_leg
         if len(names) > 1:
