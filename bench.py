@@ -326,6 +326,8 @@ def main():
     ap.add_argument("--repeats", type=int, default=9, help="the K-step timed region is run this many times; value / ms_per_step = the median region")
     ap.add_argument("--graph", action="store_true", help="third leg: the step() calls captured in ONE HIP graph (torch.cuda.CUDAGraph) and replayed — "
                                                          "what the host-bound small batches gain when the per-call launch path is taken off the clock")
+    ap.add_argument("--no-final-obs-leg", action="store_true", help="skip the second rollout leg (the same K steps with the terminal-observation side "
+                                                                    "output registered): tools/profile.sh, so that a kernel's PMC bytes are the headline leg's")
     ap.add_argument("--episode", action="store_true", help="--steps := the workload's episode length (one whole episode per timed region)")
     args = ap.parse_args()
 
@@ -566,7 +568,7 @@ def main():
     same_work = len(names) == 1 and (names[0] == "snake" or bool(wl.get("episode_start")))
     results["rollout"] = timed(lambda rep, marks: run_rollout(K, t_roll if wl.get("episode_start") else t_roll + rep * K, marks), "rollout", same_work)
     withfin_raw = None
-    if not dry and len(names) == 1:
+    if not dry and len(names) == 1 and not args.no_final_obs_leg:
         nm = names[0]
         envs[nm].collect_final_obs(rows_per_env=fin_rows[nm])
         R_keep, R = R, min(R, 3)
