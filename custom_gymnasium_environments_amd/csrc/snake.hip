@@ -524,11 +524,12 @@ enum : uint32_t { T_NEED_FOOD = 1u, T_WAS_RESET = 2u, T_DEFERRED = 4u, T_FIN_ROW
 // SameStep: the terminal observation of a lane whose episode just ended (rare lanes only: direct row store).  step(): row i of
 // final_obs_out; fused rollout: the next slots of the wave's segment of the compacted side output (FinalSeg, cge_device.hpp) — the
 // lanes that are in here together rank themselves by a ballot; fin_base = rows the segment holds before them
-template <int G>
+// FIN: the kernel instance serves the rollouts' compacted side output (p.fin); the instances without it carry none of its code
+template <int G, bool FIN = false>
 __device__ __forceinline__ void write_final_obs(const Env<G> &e, const Params &p, int64_t i, int64_t t = 0, uint32_t fin_base = 0) {
     using L = Lay<G>;
     int8_t *dst;
-    if (p.fin.rows) {
+    if (FIN && p.fin.rows) {
         const int64_t gs = final_slot(p.fin, i >> 6, fin_base, true, t, i);
         if (gs < 0) return;
         dst = static_cast<int8_t *>(p.fin.rows) + gs * L::CELLS;
@@ -551,7 +552,7 @@ __device__ __forceinline__ void write_final_obs(const Env<G> &e, const Params &p
 
 // One env transition with fused auto-reset.  Everything except the food draw happens first; the RNG
 // window load is issued, the obs body is staged while it is in flight, then the food is placed.
-template <int G, int MODE>
+template <int G, int MODE, bool FIN = false>
 __device__ __forceinline__ uint32_t transition(Env<G> &e, const Params &p, int64_t i, uint32_t action, bool valid_action,
                                                uint32_t *__restrict__ obs_row, float &reward, bool &term, bool short_wave, int64_t t = 0,
                                                uint32_t fin_base = 0, int8_t *__restrict__ fin_rowb = nullptr, uint32_t old_tail = 0) {
@@ -581,7 +582,7 @@ __device__ __forceinline__ uint32_t transition(Env<G> &e, const Params &p, int64
                     // then writes the terminal obs, resets, and the caller runs a second round.
                     deferred = true;
                 } else {
-                    if (fin_rowb) {
+                    if (FIN && fin_rowb) {
                         // fused rollout: the lane's LDS row — the previous step's observation, kept incrementally — BECOMES the terminal one:
                         // a crash returns the unchanged board (snake_env.py:88-94), a time limit the board after the move (head on, vacated
                         // tail off; the food stays: this branch did not eat).  The caller copies the row to the lane's slot of the side
@@ -591,7 +592,7 @@ __device__ __forceinline__ uint32_t transition(Env<G> &e, const Params &p, int64
                         if (!crashed) { fin_rowb[e.head] = 1; if (e.tail != old_tail) fin_rowb[old_tail] = 0; }
                         fin_row = true;                          // slot, index entry and the copy: by the caller, on wave-uniform values
                     } else {
-                        write_final_obs(e, p, i, t, fin_base);
+                        write_final_obs<G, FIN>(e, p, i, t, fin_base);
                     }
                     e.reset_body();
                     need_food = true; was_reset = true;
@@ -609,10 +610,10 @@ __device__ __forceinline__ uint32_t transition(Env<G> &e, const Params &p, int64
 
 // second half of a SameStep episode end whose last step also ate (see transition): terminal obs with the post-eat food, reset.
 // Returns whether the fresh episode needs its food placed (always, unless the board were full).
-template <int G>
+template <int G, bool FIN = false>
 __device__ __forceinline__ bool finish_deferred(Env<G> &e, const Params &p, int64_t i, uint32_t *__restrict__ obs_row, int64_t t = 0,
                                                 uint32_t fin_base = 0) {
-    write_final_obs(e, p, i, t, fin_base);
+    write_final_obs<G, FIN>(e, p, i, t, fin_base);
     e.reset_body();
     if (obs_row) e.write_obs_body(obs_row);
     return e.can_place_food();
@@ -726,7 +727,10 @@ __global__ __launch_bounds__(BLOCK, MINW) void step_kernel(Params p) {
 // STORES.  Pre-drawn digits (round 2: a per-launch queue; now the env's persistent ring, DigitQ) removed the global loads from
 // the step loop, and with them the reason for the writer: measured on 1M envs with every step's obs written to a [K, N, 100]
 // trajectory, writer-wave kernel 28.5-38 us per step (74 % of wave time parked at the barriers), this kernel see DESIGN.md 6.
-template <int G, int BLOCK, int MINW, int MODE, bool ACTIONS>
+// FIN: launched when the caller registered the terminal-observation side output.  Two instances on purpose: with the side output's code
+// compiled in, the SAME_STEP instance needs 157 registers instead of 116 and 410 more instructions, and runs 7-10 % slower even with the
+// side output idle (same box, 22.3-23.0 vs 24.1-25.6 us per 1M-env step: profiles/r04_snake_final_rows_ab.txt).
+template <int G, int BLOCK, int MINW, int MODE, bool ACTIONS, bool FIN>
 __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
     using L = Lay<G>;
     using Q = DigitQ<G>;
@@ -765,7 +769,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t *wave_rows = tile + (threadIdx.x & ~63u) * L::OBS_DW;
     // SAME_STEP terminal rows through the LDS rows (dword-aligned 4 G^2-byte rows only; else every finishing lane stores its own)
-    int8_t *const fin_rowb = (CGE_SNAKE_FINCOPY != 0 && MODE == CGE_AUTORESET_SAME_STEP && L::PACKED && row && p.fin.rows) ? rowb : nullptr;
+    int8_t *const fin_rowb = (FIN && CGE_SNAKE_FINCOPY != 0 && MODE == CGE_AUTORESET_SAME_STEP && L::PACKED && row && p.fin.rows) ? rowb : nullptr;
     uint32_t *const fin_rows_seg = static_cast<uint32_t *>(p.fin.rows) + (wfirst >> 6) * p.fin.cap * L::OBS_DW;    // this wave's segment (wave-uniform)
     int64_t *const fin_index_seg = p.fin.index + (wfirst >> 6) * p.fin.cap;
     if (row && live_lane) { e.write_obs_body(row); e.write_obs_food(row); }
@@ -795,10 +799,10 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
             } else {
                 a = hash_action_from_key(key, (uint64_t)(p.t0 + t), 4u, 0u);
             }
-            tf = transition<G, MODE>(e, p, i, a, a <= 3u, nullptr, r, term, short_wave, t, fin_used, fin_rowb, old_tail);
+            tf = transition<G, MODE, FIN>(e, p, i, a, a <= 3u, nullptr, r, term, short_wave, t, fin_used, fin_rowb, old_tail);
             need_food = tf & T_NEED_FOOD; was_reset = tf & T_WAS_RESET;
         }
-        if (fin_rowb) {
+        if (FIN && fin_rowb) {
             // terminal rows staged in the lanes' LDS rows -> the segment's next slots, in lane order; everything but the lane's own index
             // entry is wave-uniform (the segment's pointers and fill count live in scalar registers)
             unsigned long long fm = __ballot((tf & T_FIN_ROW) != 0u);
@@ -817,7 +821,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
             }
         }
         // terminal rows: the lanes that finished without eating wrote theirs inside transition(); those that also ate follow below
-        const uint32_t fin_deferred = MODE == CGE_AUTORESET_SAME_STEP ? fin_used + (uint32_t)__popcll(__ballot(term && !(tf & T_DEFERRED))) : 0u;
+        const uint32_t fin_deferred = (FIN && MODE == CGE_AUTORESET_SAME_STEP) ? fin_used + (uint32_t)__popcll(__ballot(term && !(tf & T_DEFERRED))) : 0u;
         // one inlined copy of the placement code, run a second time only when some lane ate on the very step its time limit fired
         // (SameStep: post-eat food, then reset, then the fresh episode's food — rare, wave-uniform)
         bool want = need_food;
@@ -825,10 +829,10 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
         for (int round = 0; round < 2; ++round) {
             dq_place_food<G, false>(e, q, want);
             if (round == 1 || __ballot(tf & T_DEFERRED) == 0ull) break;
-            want = (tf & T_DEFERRED) && finish_deferred<G>(e, p, i, nullptr, t, fin_deferred);
+            want = (tf & T_DEFERRED) && finish_deferred<G, FIN>(e, p, i, nullptr, t, fin_deferred);
             if (tf & T_DEFERRED) { was_reset = true; need_food = want; }
         }
-        if (MODE == CGE_AUTORESET_SAME_STEP) fin_used += (uint32_t)__popcll(__ballot(term));
+        if (FIN && MODE == CGE_AUTORESET_SAME_STEP) fin_used += (uint32_t)__popcll(__ballot(term));
         if (row) {
             unsigned long long rm = __ballot(was_reset);
             while (rm) {                                       // wave-uniform: clear the rows of the envs that were reset
@@ -860,7 +864,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void rollout_kernel(Params p) {
         q.write_back();
         if (p.reward_sum) p.reward_sum[i] = rsum;
         if (p.done_count) p.done_count[i] = dcount;
-        if (p.fin.count && (threadIdx.x & 63u) == 0u) p.fin.count[wfirst >> 6] = (int32_t)fin_used;
+        if (FIN && p.fin.count && (threadIdx.x & 63u) == 0u) p.fin.count[wfirst >> 6] = (int32_t)fin_used;
     }
 }
 
@@ -1047,9 +1051,12 @@ void launch_mode(const Params &p, bool rollout, hipStream_t s, std::string *name
         hipLaunchKernelGGL((step_kernel<G, BLOCK, MINW, MODE>), grid, block, 0, s, p);
         snprintf(buf, sizeof buf, "cge::snake::step_kernel<%d, %d, %d, %d>", G, BLOCK, MINW, MODE);
     } else {
-        if (p.actions) hipLaunchKernelGGL((rollout_kernel<G, BLOCK, MINW, MODE, true>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((rollout_kernel<G, BLOCK, MINW, MODE, false>), grid, block, 0, s, p);
-        snprintf(buf, sizeof buf, "cge::snake::rollout_kernel<%d, %d, %d, %d, %s>", G, BLOCK, MINW, MODE, p.actions ? "true" : "false");
+        const bool fin = p.fin.rows != nullptr;
+        if (p.actions) { if (fin) hipLaunchKernelGGL((rollout_kernel<G, BLOCK, MINW, MODE, true, true>), grid, block, 0, s, p);
+                         else hipLaunchKernelGGL((rollout_kernel<G, BLOCK, MINW, MODE, true, false>), grid, block, 0, s, p); }
+        else { if (fin) hipLaunchKernelGGL((rollout_kernel<G, BLOCK, MINW, MODE, false, true>), grid, block, 0, s, p);
+               else hipLaunchKernelGGL((rollout_kernel<G, BLOCK, MINW, MODE, false, false>), grid, block, 0, s, p); }
+        snprintf(buf, sizeof buf, "cge::snake::rollout_kernel<%d, %d, %d, %d, %s, %s>", G, BLOCK, MINW, MODE, p.actions ? "true" : "false", fin ? "true" : "false");
     }
     if (name) *name = buf;
 }
