@@ -572,6 +572,7 @@ def main():
         nm = names[0]
         envs[nm].collect_final_obs(rows_per_env=fin_rows[nm])
         R_keep, R = R, min(R, 3)
+        kern_main, launched_main = ran[(nm, "rollout")], dict(launched)   # the with-rows leg may be another kernel instance (snake) and is not in the manifest
         res = timed(lambda rep, marks: run_rollout(K, t_roll if wl.get("episode_start") else t_roll + rep * K, None), "rollout_fin", same_work)
         R = R_keep
         _, _, cnt, cap = envs[nm]._fin                   # terminal rows of the LAST launch: per env-step (-> obliged bytes), and whether the side output held them all
@@ -579,6 +580,8 @@ def main():
         final_stats[nm] = {"rows_per_env": fin_rows[nm], "delivered_last_launch": tot, "dropped_last_launch": envs[nm].final_obs_dropped(),
                            "per_env_step": tot / float(n * max(last_launch.get(nm, 1), 1))}
         withfin_raw = (res, ran[(nm, "rollout")])
+        ran[(nm, "rollout")] = kern_main
+        launched.clear(); launched.update(launched_main)
         envs[nm].collect_final_obs(0)
     if not dry:
         for e in envs.values():                                      # the trajectory buffers are not needed by the API leg
