@@ -455,6 +455,7 @@ def main():
 
     occupancy = {}
     host_latency_ms = {}
+    second_ms = {}
     spread = {}
     segments = {}
     primer = [None]
@@ -549,7 +550,11 @@ def main():
                 seconds.append({nm: ev2[nm][0].elapsed_time(ev2[nm][1]) for nm in names})
             second = {nm: median([x[nm] for x in seconds]) for nm in names}
             host_latency_ms[tag] = {nm: first[nm] - second[nm] for nm in names}
-            return wall, second
+            second_ms[tag] = second
+        # The roofline's launch duration is the MEDIAN REGION's own events (the regions `value` is made of).  Rounds 3 and early 4 used the
+        # second pass: with R = 9 repeats it runs after ten back-to-back regions, and rocprofv3's per-dispatch times of the 1M-env snake
+        # launch drift from 23 us per step in the first regions to 28-29 in the last (the card's clocks come down under the sustained load:
+        # profiles/r04_snake_summary.txt) — the second pass then reports the end of that drift, not the regions that were timed.
         return wall, first
 
     sync()
@@ -651,11 +656,13 @@ def main():
                 launches = -(-K // kc[nm]) if fused else K
                 rl[nm] = roofline(nm, path, kern, gpu_ms[nm], launches, K / launches, n, occupancy[path].get(nm, 0.0), measured)
                 hl = host_latency_ms.get(path)
+                rl[nm]["timing"] = ("HIP events on the launch stream around each of the R timed regions, median region (the regions `value` / `ms_per_step` "
+                                    "are the wall clock of); the interval includes the host's way to the region's first launch")
                 if hl is not None:
-                    rl[nm]["timing"] = ("HIP events on the launch stream around a second pass of the same K steps, queued behind a 1-GiB device copy so "
-                                        "that the host's way to the first launch is not inside the interval; `value` / `ms_per_step` are the "
-                                        "first pass's wall clock")
-                    rl[nm]["host_latency_us_in_first_pass_events"] = hl[nm] * 1e3
+                    rl[nm]["second_pass_launch_us"] = second_ms[path][nm] * 1e3 / launches
+                    rl[nm]["second_pass_note"] = ("the same K steps once more after the R regions, queued behind a 1-GiB device copy so that the host's way to "
+                                                  "the first launch is outside the events: shorter than avg_launch_us by the host latency on a card that holds "
+                                                  "its clocks, LONGER where the clocks came down during the R regions")
             b["roofline"] = rl[names[0]] if len(names) == 1 else rl
             if len(names) > 1:
                 # co-resident types: their kernels share the card (and its hardware queues), so one type's launch-stream events
