@@ -472,6 +472,13 @@ def main():
         xs = sorted(xs)
         return xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2])
 
+    def cool():
+        # every leg starts from the same state: under back-to-back 1M-env launches the card's clocks come down within a few regions (the
+        # repeats of one leg show it: spread.all_ms_per_step), and a leg measured right behind another would inherit its end state
+        sync()
+        if not dry:
+            time.sleep(0.5)
+
     def timed(fn, tag, second_pass):
         """R repeats of one timed region = fn(rep, marks): K steps between two barriers (the contract's clock).  Returns (median wall
         seconds, per-env GPU milliseconds of the median region's launches).  The wall clock is `value` / `ms_per_step`.  The GPU time
@@ -480,6 +487,7 @@ def main():
         same launches run again queued behind a primer that keeps the card busy while the host enqueues event, launches and event —
         those events see the kernels back to back.  Without it the first passes' events are used."""
         walls, firsts, occ = [], [], []
+        cool()
         for rep in range(R):
             restart_episodes()
             before = mean_occupancy()
