@@ -28,7 +28,11 @@ cores: reported, not the target).  roofline fields:
   peak         8 TB/s (spec); peak_measured = the larger of this box's device-to-device copy bandwidth (bytes read + written) and its
                pure fill_ (store) rate, both measured in this run and both reported — a write-dominated kernel is held against the fill rate
 The K-step timed region (barrier + synchronize on both sides, max over ranks) is run `--repeats` times (default 9; episodes restarted
-before each one where the workload fixes the episode phase): `value` / `ms_per_step` are the MEDIAN region, `spread` holds min and max.
+before each one where the workload fixes the episode phase): `value` / `ms_per_step` are the MEDIAN region, `spread` holds min, max and
+every region; the roofline's launch time is the median region's own HIP events (a second pass of the same steps behind a primer copy is
+reported beside it: `second_pass_launch_us`).  Every leg starts after half a second of idle: under back-to-back 1M-env launches the card's
+clocks come down within a few regions (visible in `spread.all_ms_per_step`).  Single-type workloads time the rollout once more with the
+terminal-observation side output registered (`rollout_with_final_obs`; the headline leg runs without it, like rounds 1-3).
 """
 import argparse
 import json
