@@ -29,8 +29,8 @@ cores: reported, not the target).  roofline fields:
                pure fill_ (store) rate, both measured in this run and both reported — a write-dominated kernel is held against the fill rate
 The K-step timed region (barrier + synchronize on both sides, max over ranks) is run `--repeats` times (default 9; episodes restarted
 before each one where the workload fixes the episode phase): `value` / `ms_per_step` are the MEDIAN region, `spread` holds min, max and
-every region; the roofline's launch time is the median region's own HIP events (a second pass of the same steps behind a primer copy is
-reported beside it: `second_pass_launch_us`).  Every leg starts after half a second of idle: under back-to-back 1M-env launches the card's
+every region; the roofline's launch time is the tighter of two HIP-event brackets of the same K steps — the median region's own events and a
+second pass queued behind a primer copy (`first_pass_launch_us`, `second_pass_launch_us`, `roofline.timing`).  Every leg starts after half a second of idle: under back-to-back 1M-env launches the card's
 clocks come down within a few regions (visible in `spread.all_ms_per_step`).  Single-type workloads time the rollout once more with the
 terminal-observation side output registered (`rollout_with_final_obs`; the headline leg runs without it, like rounds 1-3).
 """
@@ -460,6 +460,7 @@ def main():
     occupancy = {}
     host_latency_ms = {}
     second_ms = {}
+    first_ms = {}
     spread = {}
     segments = {}
     primer = [None]
@@ -563,10 +564,13 @@ def main():
             second = {nm: median([x[nm] for x in seconds]) for nm in names}
             host_latency_ms[tag] = {nm: first[nm] - second[nm] for nm in names}
             second_ms[tag] = second
-        # The roofline's launch duration is the MEDIAN REGION's own events (the regions `value` is made of).  Rounds 3 and early 4 used the
-        # second pass: with R = 9 repeats it runs after ten back-to-back regions, and rocprofv3's per-dispatch times of the 1M-env snake
-        # launch drift from 23 us per step in the first regions to 28-29 in the last (the card's clocks come down under the sustained load:
-        # profiles/r04_snake_summary.txt) — the second pass then reports the end of that drift, not the regions that were timed.
+            first_ms[tag] = first
+            # Both brackets can only OVER-estimate the kernels' time for the K steps: the median region's own events also hold the host's way
+            # to the first launch and, on the step() leg, whatever gaps the host leaves between calls; the second pass runs after R
+            # back-to-back regions, and rocprofv3's per-dispatch times of the 1M-env snake launch drift from 23 us per step in the first
+            # regions to 28-29 in the last (the card's clocks come down under the sustained load: profiles/r04_snake_summary.txt).  The
+            # roofline takes the tighter of the two and reports both.
+            return wall, {nm: min(first[nm], second[nm]) for nm in names}
         return wall, first
 
     sync()
@@ -668,13 +672,14 @@ def main():
                 launches = -(-K // kc[nm]) if fused else K
                 rl[nm] = roofline(nm, path, kern, gpu_ms[nm], launches, K / launches, n, occupancy[path].get(nm, 0.0), measured)
                 hl = host_latency_ms.get(path)
-                rl[nm]["timing"] = ("HIP events on the launch stream around each of the R timed regions, median region (the regions `value` / `ms_per_step` "
-                                    "are the wall clock of); the interval includes the host's way to the region's first launch")
+                rl[nm]["timing"] = "HIP events on the launch stream around the K steps of the median timed region"
                 if hl is not None:
+                    rl[nm]["first_pass_launch_us"] = first_ms[path][nm] * 1e3 / launches
                     rl[nm]["second_pass_launch_us"] = second_ms[path][nm] * 1e3 / launches
-                    rl[nm]["second_pass_note"] = ("the same K steps once more after the R regions, queued behind a 1-GiB device copy so that the host's way to "
-                                                  "the first launch is outside the events: shorter than avg_launch_us by the host latency on a card that holds "
-                                                  "its clocks, LONGER where the clocks came down during the R regions")
+                    rl[nm]["timing"] = ("HIP events on the launch stream, the TIGHTER of two brackets of the same K steps: first_pass_launch_us = the median timed "
+                                        "region's own events (they also hold the host's way to the first launch and any gap the host leaves between step() calls); "
+                                        "second_pass_launch_us = the same K steps once more after the R regions, queued behind a 1-GiB device copy (no host "
+                                        "latency inside, but the card's clocks may have come down during the R regions)")
             b["roofline"] = rl[names[0]] if len(names) == 1 else rl
             if len(names) > 1:
                 # co-resident types: their kernels share the card (and its hardware queues), so one type's launch-stream events
