@@ -142,7 +142,7 @@ __device__ __forceinline__ void observe(const Env &e, const RowMap &rm, float *_
 }
 
 template <bool ROLLOUT>
-__global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
+__global__ __launch_bounds__(BLOCK, 4) void step_kernel(Params p) {   // four waves per SIMD (128 registers: round 3 took 127, round 4, left alone, 129)
     __shared__ uint32_t tile[64 * OBS];
     const int64_t i0 = (int64_t)blockIdx.x * BLOCK;
     const int64_t i = i0 + threadIdx.x;

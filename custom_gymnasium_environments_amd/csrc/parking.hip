@@ -318,7 +318,7 @@ __device__ __forceinline__ void observe(const Env &e, const RowMap &rm, float *_
 }
 
 template <bool ROLLOUT>
-__global__ __launch_bounds__(BLOCK) void step_kernel(Params p) {
+__global__ __launch_bounds__(BLOCK, 2) void step_kernel(Params p) {   // two waves per SIMD: 131,072 envs are 2,048 waves = two per SIMD, all resident at once (left alone the allocator took 258 registers in round 4: one wave per SIMD, two rounds)
     __shared__ uint32_t tile[64 * OBS];
     __shared__ uint32_t draws[64 * DROW];
     const int64_t i0 = (int64_t)blockIdx.x * BLOCK;
