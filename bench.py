@@ -322,6 +322,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="snake_1m", choices=sorted(WORKLOADS))
     ap.add_argument("--path", default="rollout", choices=["rollout", "step"])
+    ap.add_argument("--steady-steps", type=int, default=2000,
+                    help="workloads timed without a reset before every region (snake_1m): after the legs, this many more untimed rollout steps, "
+                         "then the same K steps timed again -> the `steady_state` block (0: skip)")
     ap.add_argument("--traj-gib", type=float, default=None,
                     help="cap on the per-env-type trajectory buffer of the rollout leg (default 24; crypto_1m 128: its rows are 1,044 B, and a launch "
                          "should be long enough to amortise the 1,200-byte window load — 125 steps per launch on the 288-GB part)")
@@ -478,8 +481,7 @@ def main():
         return xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2])
 
     def cool():
-        # every leg starts from the same state: under back-to-back 1M-env launches the card's clocks come down within a few regions (the
-        # repeats of one leg show it: spread.all_ms_per_step), and a leg measured right behind another would inherit its end state
+        # every leg starts after half a second of idle, so that no leg is measured right behind another one's last launch
         sync()
         if not dry:
             time.sleep(0.5)
@@ -567,9 +569,11 @@ def main():
             first_ms[tag] = first
             # Both brackets can only OVER-estimate the kernels' time for the K steps: the median region's own events also hold the host's way
             # to the first launch and, on the step() leg, whatever gaps the host leaves between calls; the second pass runs after R
-            # back-to-back regions, and rocprofv3's per-dispatch times of the 1M-env snake launch drift from 23 us per step in the first
-            # regions to 28-29 in the last (the card's clocks come down under the sustained load: profiles/r04_snake_summary.txt).  The
-            # roofline takes the tighter of the two and reports both.
+            # regions, and where the regions are not preceded by a reset (snake_1m) the batch is R x K steps further from the reset it
+            # started with: rocprofv3's per-dispatch times of the 1M-env snake launch go from 23 us per step in the first regions to
+            # 28-29 in the last (profiles/r04_snake_summary.txt) - read as a clock drift at first, it is the batch leaving the state
+            # it was reset into (the steady_state leg below and profiles/r04_snake_warmup_sweep.txt).  The roofline takes the tighter
+            # of the two and reports both.
             return wall, {nm: min(first[nm], second[nm]) for nm in names}
         return wall, first
 
@@ -604,6 +608,18 @@ def main():
         ran[(nm, "rollout")] = kern_main
         launched.clear(); launched.update(launched_main)
         envs[nm].collect_final_obs(0)
+    # Steady state.  A batch that was reset together is not in its steady state for hundreds of steps: every env starts with a full digit
+    # ring, no ring needs topping up for the first ~100 steps, and the share of waves in which SOME lane refills grows until the envs are
+    # out of phase (snake_1m, K = 20: 20.6 us per step 25-45 steps after the reset, 23.2 after 500, 25.7 after 2,000 and flat from there:
+    # profiles/r04_snake_warmup_sweep.txt).  The contract's W warm-up steps decide where `value` is measured; this leg says what a consumer
+    # that never resets the batch sees: --steady-steps more untimed steps, then the same K steps, 3 regions.
+    steady_raw = None
+    if not dry and len(names) == 1 and not wl.get("episode_start") and args.steady_steps > 0:
+        t_ss = t_roll + (R + 8) * K
+        run_rollout(args.steady_steps, t_ss)
+        R_keep, R = R, min(R, 3)
+        steady_raw = timed(lambda rep, marks: run_rollout(K, t_ss + args.steady_steps + rep * K, None), "rollout_steady", False)
+        R = R_keep
     if not dry:
         for e in envs.values():                                      # the trajectory buffers are not needed by the API leg
             e._bufs.pop("traj", None)
@@ -648,6 +664,7 @@ def main():
 
     walls = {p: reduce_max(results[p][0]) for p in results}
     withfin_wall = reduce_max(withfin_raw[0][0]) if withfin_raw else None      # (every rank: a collective)
+    steady_wall = reduce_max(steady_raw[0]) if steady_raw else None
     if graph_leg:
         gwall = reduce_max(graph_leg.pop("_wall"))
         graph_leg["value"] = n * world * graph_leg["steps_per_replay"] / gwall
@@ -679,7 +696,7 @@ def main():
                     rl[nm]["timing"] = ("HIP events on the launch stream, the TIGHTER of two brackets of the same K steps: first_pass_launch_us = the median timed "
                                         "region's own events (they also hold the host's way to the first launch and any gap the host leaves between step() calls); "
                                         "second_pass_launch_us = the same K steps once more after the R regions, queued behind a 1-GiB device copy (no host "
-                                        "latency inside, but the card's clocks may have come down during the R regions)")
+                                        "latency inside; for snake_1m the batch is R x K steps further from its reset by then: see steady_state)")
             b["roofline"] = rl[names[0]] if len(names) == 1 else rl
             if len(names) > 1:
                 # co-resident types: their kernels share the card (and its hardware queues), so one type's launch-stream events
@@ -714,7 +731,8 @@ def main():
                        "episode_phase": (f"steps 1..{K} of an episode (envs reset right before every timed region"
                                          + (f"; a whole episode is {wl['episode']} steps: --episode" if wl.get("episode") and K != wl["episode"] else "") + ")"
                                          if wl.get("episode_start")
-                                         else f"steady state: the timed region starts {K + max(W, 1) + min(kc[names[0]], K)} steps after reset")},
+                                         else f"the timed regions start {K + max(W, 1) + min(kc[names[0]], K)} steps after the batch was reset together (W warm-up steps + one priming launch); "
+                                              "the batch's steady state is the steady_state block")},
             "roofline": hb["roofline"] if len(names) == 1 else hb["roofline_aggregate"],
         }
         if dry:
@@ -732,6 +750,17 @@ def main():
                 "ms_per_step_wall": withfin_wall * 1e3 / K, **final_stats[nm],
                 "note": "the same K steps with the terminal-observation side output registered (cge_<env>_rollout_final_obs): trajectory + side output = "
                         "everything the K step() calls return; its bytes (obs + 8 per episode end) are part of this block's obliged bytes"}
+        if steady_raw:
+            nm = names[0]
+            launches = -(-K // kc[nm])
+            rr = roofline(nm, "rollout", ran[(nm, "rollout")], steady_raw[1][nm], launches, K / launches, n, occupancy["rollout"].get(nm, 0.0), measured)
+            out["steady_state"] = {
+                "value": total_envs * K / steady_wall, "unit": "env-steps/s", "ms_per_step": steady_wall * 1e3 / K, "spread": spread["rollout_steady"],
+                "us_per_step": rr["avg_launch_us"] / (K / launches), "frac": rr["frac"], "kernel": rr["kernel"],
+                "after_steps": args.steady_steps,
+                "note": f"the same fused rollout of K = {K} steps, timed again after {args.steady_steps} more untimed steps (3 regions, median; us_per_step / frac from "
+                        "HIP events on the launch stream): the batch's steady state - envs out of phase, digit rings topped up at their steady rate. "
+                        "`value` above is measured W warm-up steps after the reset, as the contract says, where every ring is still full"}
         if graph_leg:
             out["graph_step"] = graph_leg
         if len(names) > 1:

@@ -1252,6 +1252,9 @@ int cge_snake_rollout(cge_snake *h, int32_t k_steps, const int32_t *actions, uin
     // 25.1-25.9 / 23.4-25.7; 64 (every ring full at the start): 31.5 / 29.2 / 25.9 / 22.8-24.8 — topping every ring up at every
     // launch costs a block visit per env per launch for a handful of digits each.
     p.dq_topup = 12u;
+#ifdef CGE_SNAKE_TOPUP_ENV                                        // A/B build only (tools/build_variant.sh): the threshold from the environment
+    if (const char *ev = getenv("CGE_SNAKE_TOPUP")) p.dq_topup = (uint32_t)atoi(ev);
+#endif
     h->ops.rollout(p, as_stream(stream), &h->last_kernel);
     CGE_TRY(h, hipGetLastError());
     return CGE_OK;
