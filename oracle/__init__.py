@@ -179,7 +179,7 @@ class MT:
         self.h = lib().orc_mt_new()
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:          # (module globals are None at interpreter shutdown)
             lib().orc_mt_free(self.h)
             self.h = None
 
@@ -207,7 +207,7 @@ class PCG:
         lib().orc_pcg_seed_export(self.h, seed)
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:          # (module globals are None at interpreter shutdown)
             lib().orc_pcg_free(self.h)
             self.h = None
 
@@ -244,7 +244,7 @@ class SnakeOracle(_EpisodeStats):
             lib().orc_snake_set_max_steps(self.h, int(max_steps))
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:          # (module globals are None at interpreter shutdown)
             lib().orc_snake_destroy(self.h)
             self.h = None
 
@@ -329,7 +329,7 @@ class CryptoOracle(_EpisodeStats):
             lib().orc_crypto_set_config(self.h, _p(cfg))
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:          # (module globals are None at interpreter shutdown)
             lib().orc_crypto_destroy(self.h)
             self.h = None
 
@@ -409,7 +409,7 @@ class TrafficOracle(_EpisodeStats):
         self.ni = int(lib().orc_traffic_num_intersections(self.h))
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:          # (module globals are None at interpreter shutdown)
             lib().orc_traffic_destroy(self.h)
             self.h = None
 
@@ -486,7 +486,7 @@ class _SimpleOracle(_EpisodeStats):
             getattr(lib(), f"orc_{self._name}_set_max_steps")(self.h, int(max_steps))
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:          # (module globals are None at interpreter shutdown)
             getattr(lib(), f"orc_{self._name}_destroy")(self.h)
             self.h = None
 
