@@ -30,8 +30,10 @@ cores: reported, not the target).  roofline fields:
 The K-step timed region (barrier + synchronize on both sides, max over ranks) is run `--repeats` times (default 9; episodes restarted
 before each one where the workload fixes the episode phase): `value` / `ms_per_step` are the MEDIAN region, `spread` holds min, max and
 every region; the roofline's launch time is the tighter of two HIP-event brackets of the same K steps — the median region's own events and a
-second pass queued behind a primer copy (`first_pass_launch_us`, `second_pass_launch_us`, `roofline.timing`).  Every leg starts after half a second of idle: under back-to-back 1M-env launches the card's
-clocks come down within a few regions (visible in `spread.all_ms_per_step`).  Single-type workloads time the rollout once more with the
+second pass queued behind a primer copy (`first_pass_launch_us`, `second_pass_launch_us`, `roofline.timing`).  Every leg starts after half a second of idle.
+snake_1m's regions are not preceded by a reset, and W warm-up steps after the batch was reset together it is still leaving that state (every digit
+ring full; `spread.all_ms_per_step` shows the regions getting slower): `steady_state` times the same K steps again `--steady-steps` (2,000) steps later.
+Single-type workloads time the rollout once more with the
 terminal-observation side output registered (`rollout_with_final_obs`; the headline leg runs without it, like rounds 1-3).
 """
 import argparse
