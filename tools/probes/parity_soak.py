@@ -20,7 +20,7 @@ TYPES = [("Snake", dict(grid_size=10), "SnakeOracle", (10,)), ("Crypto", dict(ac
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 4000
 SEEDS = [int(s) for s in sys.argv[3:]] or [7, 1234567]
-CH = 125
+CH = int(os.environ.get("SOAK_CHUNK", "125"))             # fused steps per launch
 bad = 0
 for name, kw, oname, oargs in TYPES:
     for mode, omode in (("SameStep", oracle.SAME_STEP), ("NextStep", oracle.NEXT_STEP)):
